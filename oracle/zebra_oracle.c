@@ -1,0 +1,614 @@
+/*
+ * zebra_oracle.c -- CPU restatement of emmyoh/zebra's LSH bucket-scan + distance hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library, and only as the checker / the reported CPU baseline.  The product path
+ * (zebra_amd/, include/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (/root/reference, Rust) has no tests, golden vectors or fixtures
+ * (SURVEY.md s4), cannot be compiled here (no cargo/rustc), and its arithmetic lives in the
+ * un-vendored crates simsimd = "6.2.3" and distances = "1.8.0" (Cargo.toml:27,38).  This file
+ * restates the algorithm from the reference's own call sites; simsimd semantics (f32 accumulation,
+ * cos() returning the *distance* 1-cos, clip at 0, the two zero-norm special cases) are restated
+ * from that crate's published behaviour.  It is cross-checked against numpy/scipy float64 brute
+ * force in tests/test_oracle_kat.py.
+ *
+ * What follows which reference lines:
+ *   zo_dot32 / zo_point_is_above   src/database/index/lsh.rs:39-43
+ *   make_hyperplane                src/database/index/lsh.rs:174-190, 192-231
+ *   build_node (classification)    src/database/index/lsh.rs:233-267
+ *   walk (tree_result)             src/database/index/lsh.rs:290-348
+ *   zo_search                      src/database/index/lsh.rs:544-565
+ *   zo_distance (keys)             src/distance.rs:13-49, 99-114
+ *   zo_search_batch                src/database/core.rs:290-313
+ *
+ * Choices the reference leaves open (it is non-deterministic: unseeded RNG lsh.rs:201, unstable
+ * sorts lsh.rs:318,561, Uuid::now_v7 ids lsh.rs:415) and that this restatement FIXES, identically
+ * to the HIP path, so that "bit-exact" is well defined:
+ *   - ids are dense row indices in insertion order;
+ *   - the two sample rows of a hyperplane come from a counter RNG keyed by (seed, tree, node path);
+ *   - the hash dot product is a sequential k-ascending f32 fmaf chain starting from +0
+ *     (bitwise what a non-split-K f32 MFMA produces);
+ *   - distance accumulations use 256 strided f32 accumulators (element e -> accumulator e mod 256,
+ *     ascending e, fmaf), combined as ((a0+a1)+(a2+a3)) per group of four and then a 64-way
+ *     xor-butterfly 1,2,4,8,16,32 -- the order a wave64 produces with one float4 per lane;
+ *   - ties sort by (key, id) ascending.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ZO_EXPORT __attribute__((visibility("default")))
+
+enum { ZO_COSINE = 0, ZO_L2SQ = 1, ZO_L2 = 2 };
+enum { ZO_PARITY = 0, ZO_CORRECTED = 1 };
+#define ZO_MAX_DEPTH 60 /* guard: the reference recurses forever on an unsplittable node */
+
+/* ---------------------------------------------------------------- counter RNG / synthetic data */
+
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* Irwin-Hall(4) of four 16-bit fields: integer arithmetic + one exact int->float + one f32 multiply,
+ * so the CPU and the GPU generator agree bit for bit (no libm). mean 0, variance 1. */
+static inline int32_t synth_centered(uint64_t seed, uint64_t idx) {
+    uint64_t z = splitmix64(seed ^ (idx * 0xD1342543DE82EF95ull));
+    uint32_t s = (uint32_t)(z & 0xFFFF) + (uint32_t)((z >> 16) & 0xFFFF) + (uint32_t)((z >> 32) & 0xFFFF) +
+                 (uint32_t)(z >> 48);
+    return (int32_t)s - 131070;
+}
+static inline float synth_value(uint64_t seed, uint64_t idx, int kind) {
+    int32_t t = synth_centered(seed, idx);
+    if (kind == 1) { /* "SIFT-style": integer-valued in [0,255] -> L2^2 exact in f32 */
+        int32_t v = 30 + (t * 35) / 37837;
+        if (v < 0) v = 0;
+        if (v > 255) v = 255;
+        return (float)v;
+    }
+    return (float)t * (1.0f / 37837.2f);
+}
+
+ZO_EXPORT void zo_synth_rows(uint64_t seed, uint64_t row0, uint64_t n, uint32_t d, int kind, float *out) {
+    for (uint64_t r = 0; r < n; r++)
+        for (uint32_t c = 0; c < d; c++) out[r * d + c] = synth_value(seed, (row0 + r) * d + c, kind);
+}
+
+/* query b = stored row r_b + 0.3 * noise (planted neighbour); r_b from the query stream */
+ZO_EXPORT uint64_t zo_synth_query_row(uint64_t seed_q, uint64_t b, uint64_t n_rows) {
+    return splitmix64(seed_q ^ (b * 0xA24BAED4963EE407ull)) % n_rows;
+}
+ZO_EXPORT void zo_synth_queries(uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0, uint64_t b,
+                                uint32_t d, int kind, float *out) {
+    for (uint64_t i = 0; i < b; i++) {
+        uint64_t r = zo_synth_query_row(seed_q, b0 + i, n_rows);
+        for (uint32_t c = 0; c < d; c++) {
+            float x = synth_value(seed_rows, r * d + c, kind);
+            float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, (b0 + i) * d + c) * (1.0f / 37837.2f);
+            out[i * d + c] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : fmaf(0.3f, g, x);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------- hash (lsh.rs:39-43) */
+
+/* simsimd f32 dot: f32 accumulation, returned widened.  Order fixed: sequential fmaf chain. */
+ZO_EXPORT float zo_dot32(const float *w, const float *x, uint32_t d) {
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < d; k++) acc = fmaf(w[k], x[k], acc);
+    return acc;
+}
+
+/* lsh.rs:40-42: dot (f64 from f32 accumulator) + constant as f64 >= 0.0 ; NaN -> false */
+ZO_EXPORT int zo_point_is_above(const float *w, float c, const float *x, uint32_t d) {
+    return ((double)zo_dot32(w, x, d) + (double)c) >= 0.0;
+}
+
+/* eight rows at once (independent chains -> hides fma latency); same per-row order as zo_dot32 */
+static void dot32_rows8(const float *w, const float *const *rows, int n, uint32_t d, float *out) {
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    const float *r[8];
+    for (int i = 0; i < 8; i++) r[i] = rows[i < n ? i : 0];
+    for (uint32_t k = 0; k < d; k++) {
+        float wk = w[k];
+        a0 = fmaf(wk, r[0][k], a0);
+        a1 = fmaf(wk, r[1][k], a1);
+        a2 = fmaf(wk, r[2][k], a2);
+        a3 = fmaf(wk, r[3][k], a3);
+        a4 = fmaf(wk, r[4][k], a4);
+        a5 = fmaf(wk, r[5][k], a5);
+        a6 = fmaf(wk, r[6][k], a6);
+        a7 = fmaf(wk, r[7][k], a7);
+    }
+    float a[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+    for (int i = 0; i < n; i++) out[i] = a[i];
+}
+
+/* --------------------------------------------------------------------- keys (distance.rs:13-49,99-114) */
+
+typedef struct {
+    float ab, a2, b2, l2;
+} zo_sums;
+
+static inline float combine256(const float *acc) {
+    float s[64], t[64];
+    for (int l = 0; l < 64; l++) s[l] = (acc[4 * l] + acc[4 * l + 1]) + (acc[4 * l + 2] + acc[4 * l + 3]);
+    for (int m = 1; m < 64; m <<= 1) {
+        for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ m];
+        memcpy(s, t, sizeof s);
+    }
+    return s[0];
+}
+
+static inline float sum_l2sq(const float *a, const float *b, uint32_t d) {
+    float acc[256];
+    memset(acc, 0, sizeof acc);
+    for (uint32_t base = 0; base < d; base += 256) {
+        uint32_t m = d - base < 256 ? d - base : 256;
+        for (uint32_t i = 0; i < m; i++) {
+            float df = a[base + i] - b[base + i];
+            acc[i] = fmaf(df, df, acc[i]);
+        }
+    }
+    return combine256(acc);
+}
+static inline float sum_prod(const float *a, const float *b, uint32_t d) {
+    float acc[256];
+    memset(acc, 0, sizeof acc);
+    for (uint32_t base = 0; base < d; base += 256) {
+        uint32_t m = d - base < 256 ? d - base : 256;
+        for (uint32_t i = 0; i < m; i++) acc[i] = fmaf(a[base + i], b[base + i], acc[i]);
+    }
+    return combine256(acc);
+}
+
+static inline uint64_t bits64(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    return u;
+}
+
+/* simsimd cos(): the cosine DISTANCE, clipped at 0, with the two zero-norm cases */
+static inline double cos_distance(float ab, float a2, float b2) {
+    if (a2 == 0.0f && b2 == 0.0f) return 0.0;
+    if (ab == 0.0f) return 1.0;
+    double r = 1.0 - (double)ab / sqrt((double)a2 * (double)b2);
+    return r > 0.0 ? r : 0.0;
+}
+
+static inline uint64_t key_from_sums(int metric, int mode, float ab, float a2, float b2, float l2) {
+    switch (metric) {
+    case ZO_COSINE: {
+        double c = cos_distance(ab, a2, b2);
+        /* distance.rs:23-25: `.map(|c| 1.0 - c)` applied to what is already a distance */
+        return bits64(mode == ZO_PARITY ? 1.0 - c : c);
+    }
+    case ZO_L2SQ: return bits64((double)l2);        /* distance.rs:41-42 */
+    default: return bits64(sqrt((double)l2));       /* distance.rs:106-107 */
+    }
+}
+
+/* Metric::distance(a = stored, b = query) -> DistanceUnit (u64 bit pattern) */
+ZO_EXPORT uint64_t zo_distance(int metric, int mode, const float *a, const float *b, uint32_t d) {
+    if (metric == ZO_COSINE)
+        return key_from_sums(metric, mode, sum_prod(a, b, d), sum_prod(a, a, d), sum_prod(b, b, d), 0.0f);
+    return key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, b, d));
+}
+
+ZO_EXPORT void zo_distance_batch(int metric, int mode, const float *rows, const float *q, uint64_t n, uint32_t d,
+                                 uint64_t *out_keys) {
+    float b2 = metric == ZO_COSINE ? sum_prod(q, q, d) : 0.0f;
+    for (uint64_t i = 0; i < n; i++) {
+        const float *a = rows + i * d;
+        out_keys[i] = metric == ZO_COSINE
+                          ? key_from_sums(metric, mode, sum_prod(a, q, d), sum_prod(a, a, d), b2, 0.0f)
+                          : key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, q, d));
+    }
+}
+
+/* raw sums, for tests that want to look under the key */
+ZO_EXPORT void zo_distance_sums(const float *a, const float *b, uint32_t d, float *out4) {
+    out4[0] = sum_prod(a, b, d);
+    out4[1] = sum_prod(a, a, d);
+    out4[2] = sum_prod(b, b, d);
+    out4[3] = sum_l2sq(a, b, d);
+}
+
+/* ------------------------------------------------------------------------------------------- forest */
+
+typedef struct zo_forest {
+    uint64_t n_rows;
+    uint32_t d, M, T;
+    uint64_t seed;
+    /* nodes: plane >= 0 -> inner (left = below child, right = above child, lsh.rs:260-264);
+     *        plane == -1 -> leaf (left = offset into leaf_ids, right = length) */
+    int32_t *plane, *left, *right;
+    uint8_t *depth;
+    uint32_t n_nodes, cap_nodes;
+    uint32_t *roots;
+    float *planes, *consts;
+    uint32_t n_planes, cap_planes;
+    uint32_t *leaf_ids;
+    uint64_t n_leaf_ids, cap_leaf_ids;
+} zo_forest;
+
+static uint32_t new_node(zo_forest *f) {
+    if (f->n_nodes == f->cap_nodes) {
+        f->cap_nodes = f->cap_nodes ? f->cap_nodes * 2 : 1024;
+        f->plane = realloc(f->plane, f->cap_nodes * sizeof(int32_t));
+        f->left = realloc(f->left, f->cap_nodes * sizeof(int32_t));
+        f->right = realloc(f->right, f->cap_nodes * sizeof(int32_t));
+        f->depth = realloc(f->depth, f->cap_nodes);
+    }
+    return f->n_nodes++;
+}
+static uint32_t new_plane(zo_forest *f) {
+    if (f->n_planes == f->cap_planes) {
+        f->cap_planes = f->cap_planes ? f->cap_planes * 2 : 256;
+        f->planes = realloc(f->planes, (size_t)f->cap_planes * f->d * sizeof(float));
+        f->consts = realloc(f->consts, f->cap_planes * sizeof(float));
+    }
+    return f->n_planes++;
+}
+static uint64_t push_leaf(zo_forest *f, const uint32_t *ids, uint32_t n) {
+    if (f->n_leaf_ids + n > f->cap_leaf_ids) {
+        while (f->n_leaf_ids + n > f->cap_leaf_ids) f->cap_leaf_ids = f->cap_leaf_ids ? f->cap_leaf_ids * 2 : 4096;
+        f->leaf_ids = realloc(f->leaf_ids, f->cap_leaf_ids * sizeof(uint32_t));
+    }
+    uint64_t off = f->n_leaf_ids;
+    memcpy(f->leaf_ids + off, ids, n * sizeof(uint32_t));
+    f->n_leaf_ids += n;
+    return off;
+}
+
+/* two distinct rows, uniform over the WHOLE database (lsh.rs:197-201), keyed by
+ * (seed, tree, heap path of the node: root 1, below child 2p, above child 2p+1) */
+ZO_EXPORT void zo_sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint64_t n_rows, uint64_t *i, uint64_t *j) {
+    uint64_t h = splitmix64(seed ^ splitmix64(0x7EE5ull + tree) ^ splitmix64(path * 0xC2B2AE3D27D4EB4Full));
+    uint64_t h1 = splitmix64(h), h2 = splitmix64(h1);
+    if (n_rows < 2) { *i = 0; *j = 0; return; }
+    *i = h1 % n_rows;
+    *j = h2 % (n_rows - 1);
+    if (*j >= *i) (*j)++;
+}
+
+/* lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 */
+ZO_EXPORT void zo_make_hyperplane(const float *a, const float *b, uint32_t d, float *w, float *c) {
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < d; k++) {
+        w[k] = b[k] - a[k];
+        float p = (a[k] + b[k]) / 2.0f;
+        acc = fmaf(w[k], p, acc);
+    }
+    *c = -acc;
+}
+
+static int32_t build_node(zo_forest *f, const float *X, uint32_t tree, uint64_t path, int depth, uint32_t *ids,
+                          uint32_t n, uint32_t *scratch) {
+    uint32_t me = new_node(f);
+    f->depth[me] = (uint8_t)depth;
+    if (n < f->M || depth >= ZO_MAX_DEPTH) { /* lsh.rs:251-252 */
+        f->plane[me] = -1;
+        f->left[me] = (int32_t)push_leaf(f, ids, n);
+        f->right[me] = (int32_t)n;
+        return (int32_t)me;
+    }
+    uint32_t d = f->d;
+    uint64_t si, sj;
+    zo_sample_pair(f->seed, tree, path, f->n_rows, &si, &sj);
+    uint32_t p = new_plane(f);
+    float *w = f->planes + (size_t)p * d;
+    float *zero = NULL;
+    const float *a = X + si * d, *b = X + sj * d;
+    if (f->n_rows < 2) { /* lsh.rs:203-220: missing samples decode to the all-zero default */
+        zero = calloc(d, sizeof(float));
+        if (f->n_rows == 0) a = zero;
+        b = zero;
+    }
+    zo_make_hyperplane(a, b, d, w, &f->consts[p]);
+    free(zero);
+    float c = f->consts[p];
+    /* lsh.rs:236-241: classify; keep ascending id order on both sides (stable) */
+    uint32_t na = 0, nb = 0;
+    uint32_t *above = scratch, *below = scratch + n;
+    for (uint32_t i = 0; i < n; i += 8) {
+        int m = n - i < 8 ? (int)(n - i) : 8;
+        const float *rows[8];
+        float dots[8];
+        for (int r = 0; r < m; r++) rows[r] = X + (size_t)ids[i + r] * d;
+        dot32_rows8(f->planes + (size_t)p * d, rows, m, d, dots);
+        for (int r = 0; r < m; r++) {
+            if (((double)dots[r] + (double)c) >= 0.0) above[na++] = ids[i + r];
+            else below[nb++] = ids[i + r];
+        }
+    }
+    memcpy(ids, below, nb * sizeof(uint32_t));
+    memcpy(ids + nb, above, na * sizeof(uint32_t));
+    f->plane[me] = (int32_t)p;
+    /* lsh.rs:257-264: above first, then below; left = below, right = above */
+    int32_t r = build_node(f, X, tree, 2 * path + 1, depth + 1, ids + nb, na, scratch);
+    int32_t l = build_node(f, X, tree, 2 * path, depth + 1, ids, nb, scratch);
+    f->left[me] = l;
+    f->right[me] = r;
+    return (int32_t)me;
+}
+
+/* lsh.rs:411-429 build_index: T independent trees over all ids */
+ZO_EXPORT zo_forest *zo_forest_build(const float *X, uint64_t n_rows, uint32_t d, uint32_t M, uint32_t T,
+                                     uint64_t seed) {
+    zo_forest *f = calloc(1, sizeof *f);
+    f->n_rows = n_rows; f->d = d; f->M = M; f->T = T; f->seed = seed;
+    f->roots = calloc(T ? T : 1, sizeof(uint32_t));
+    uint32_t *ids = malloc((n_rows ? n_rows : 1) * sizeof(uint32_t));
+    uint32_t *scratch = malloc((n_rows ? n_rows : 1) * 2 * sizeof(uint32_t));
+    for (uint32_t t = 0; t < T; t++) {
+        for (uint64_t i = 0; i < n_rows; i++) ids[i] = (uint32_t)i;
+        f->roots[t] = (uint32_t)build_node(f, X, t, 1, 0, ids, (uint32_t)n_rows, scratch);
+    }
+    free(ids); free(scratch);
+    return f;
+}
+
+/* hand-built forests for known-answer tests and for forests exported by the HIP build */
+ZO_EXPORT zo_forest *zo_forest_from_arrays(uint64_t n_rows, uint32_t d, uint32_t M, uint32_t T, uint32_t n_nodes,
+                                           const int32_t *plane, const int32_t *left, const int32_t *right,
+                                           const uint32_t *roots, uint32_t n_planes, const float *planes,
+                                           const float *consts, uint64_t n_leaf_ids, const uint32_t *leaf_ids) {
+    zo_forest *f = calloc(1, sizeof *f);
+    f->n_rows = n_rows; f->d = d; f->M = M; f->T = T;
+    f->n_nodes = f->cap_nodes = n_nodes;
+    f->plane = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->plane, plane, n_nodes * sizeof(int32_t));
+    f->left = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->left, left, n_nodes * sizeof(int32_t));
+    f->right = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->right, right, n_nodes * sizeof(int32_t));
+    f->depth = calloc(n_nodes + 1, 1);
+    f->roots = malloc((T + 1) * sizeof(uint32_t)); memcpy(f->roots, roots, T * sizeof(uint32_t));
+    f->n_planes = f->cap_planes = n_planes;
+    f->planes = malloc(((size_t)n_planes * d + 1) * sizeof(float)); memcpy(f->planes, planes, (size_t)n_planes * d * sizeof(float));
+    f->consts = malloc((n_planes + 1) * sizeof(float)); memcpy(f->consts, consts, n_planes * sizeof(float));
+    f->n_leaf_ids = f->cap_leaf_ids = n_leaf_ids;
+    f->leaf_ids = malloc((n_leaf_ids + 1) * sizeof(uint32_t)); memcpy(f->leaf_ids, leaf_ids, n_leaf_ids * sizeof(uint32_t));
+    return f;
+}
+
+ZO_EXPORT void zo_forest_free(zo_forest *f) {
+    if (!f) return;
+    free(f->plane); free(f->left); free(f->right); free(f->depth); free(f->roots);
+    free(f->planes); free(f->consts); free(f->leaf_ids); free(f);
+}
+
+ZO_EXPORT void zo_forest_sizes(const zo_forest *f, uint32_t *n_nodes, uint32_t *n_planes, uint64_t *n_leaf_ids) {
+    *n_nodes = f->n_nodes; *n_planes = f->n_planes; *n_leaf_ids = f->n_leaf_ids;
+}
+ZO_EXPORT void zo_forest_export(const zo_forest *f, int32_t *plane, int32_t *left, int32_t *right, uint32_t *roots,
+                                float *planes, float *consts, uint32_t *leaf_ids) {
+    memcpy(plane, f->plane, f->n_nodes * sizeof(int32_t));
+    memcpy(left, f->left, f->n_nodes * sizeof(int32_t));
+    memcpy(right, f->right, f->n_nodes * sizeof(int32_t));
+    memcpy(roots, f->roots, f->T * sizeof(uint32_t));
+    memcpy(planes, f->planes, (size_t)f->n_planes * f->d * sizeof(float));
+    memcpy(consts, f->consts, f->n_planes * sizeof(float));
+    memcpy(leaf_ids, f->leaf_ids, f->n_leaf_ids * sizeof(uint32_t));
+}
+
+/* --------------------------------------------------------------------------- walk (lsh.rs:290-348) */
+
+typedef struct {
+    uint32_t id;
+    uint64_t key;
+} zo_pair;
+
+static int pair_cmp(const void *a, const void *b) {
+    const zo_pair *x = a, *y = b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1; /* unsigned order of the bit pattern */
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+typedef struct {
+    const zo_forest *f;
+    const float *X, *q;
+    int metric, mode;
+    float qq; /* sum_prod(q,q): the query-side norm, same value for every stored row */
+    uint32_t *stamp, epoch; /* candidate set (DashSet, lsh.rs:550) */
+    uint32_t *cand; uint64_t n_cand;
+    zo_pair *buf; /* leaf scoring buffer, >= max leaf length */
+    /* optional visit trace: (leaf offset, leaf length, n taken) triples */
+    uint64_t *visits; uint64_t n_visits, cap_visits;
+    uint64_t rows_scored, planes_evaluated, leaves_visited;
+} zo_ctx;
+
+static inline uint64_t ctx_key(zo_ctx *c, uint32_t id) {
+    const float *a = c->X + (size_t)id * c->f->d;
+    if (c->metric == ZO_COSINE)
+        return key_from_sums(c->metric, c->mode, sum_prod(a, c->q, c->f->d), sum_prod(a, a, c->f->d), c->qq, 0.0f);
+    return key_from_sums(c->metric, c->mode, 0, 0, 0, sum_l2sq(a, c->q, c->f->d));
+}
+static inline void cand_insert(zo_ctx *c, uint32_t id) {
+    if (c->stamp[id] != c->epoch) { c->stamp[id] = c->epoch; c->cand[c->n_cand++] = id; }
+}
+
+static int32_t walk(zo_ctx *c, int32_t node, int32_t n) {
+    const zo_forest *f = c->f;
+    if (f->plane[node] < 0) {
+        uint32_t off = (uint32_t)f->left[node], len = (uint32_t)f->right[node];
+        const uint32_t *ids = f->leaf_ids + off;
+        c->leaves_visited++;
+        int32_t ret;
+        if ((int64_t)len < (int64_t)n) { /* lsh.rs:300-306: fewer than n -> all of them, unscored */
+            for (uint32_t i = 0; i < len; i++) cand_insert(c, ids[i]);
+            ret = (int32_t)len;
+        } else { /* lsh.rs:308-329: score all, sort ascending by key, take n */
+            for (uint32_t i = 0; i < len; i++) { c->buf[i].id = ids[i]; c->buf[i].key = ctx_key(c, ids[i]); }
+            c->rows_scored += len;
+            qsort(c->buf, len, sizeof(zo_pair), pair_cmp);
+            for (int32_t i = 0; i < n; i++) cand_insert(c, c->buf[i].id);
+            ret = n;
+        }
+        if (c->visits && c->n_visits < c->cap_visits) {
+            c->visits[3 * c->n_visits] = off; c->visits[3 * c->n_visits + 1] = len;
+            c->visits[3 * c->n_visits + 2] = (uint64_t)(ret < 0 ? 0 : ret);
+            c->n_visits++;
+        }
+        return ret;
+    }
+    int32_t p = f->plane[node];
+    c->planes_evaluated++;
+    int above = zo_point_is_above(f->planes + (size_t)p * f->d, f->consts[p], c->q, f->d);
+    int32_t main_n = above ? f->right[node] : f->left[node];   /* lsh.rs:335-338 */
+    int32_t backup = above ? f->left[node] : f->right[node];
+    int32_t k = walk(c, main_n, n);
+    if (k < n) return walk(c, backup, n - k); /* lsh.rs:341-343: the backup's count ALONE */
+    return k;
+}
+
+typedef struct {
+    uint64_t rows_scored, planes_evaluated, leaves_visited, candidates;
+} zo_stats;
+
+static uint32_t max_leaf_len(const zo_forest *f) {
+    uint32_t m = 1;
+    for (uint32_t i = 0; i < f->n_nodes; i++)
+        if (f->plane[i] < 0 && (uint32_t)f->right[i] > m) m = (uint32_t)f->right[i];
+    return m;
+}
+
+static void ctx_init(zo_ctx *c, const zo_forest *f, const float *X, int metric, int mode) {
+    memset(c, 0, sizeof *c);
+    c->f = f; c->X = X; c->metric = metric; c->mode = mode;
+    c->stamp = calloc(f->n_rows ? f->n_rows : 1, sizeof(uint32_t));
+    c->cand = malloc((f->n_rows ? f->n_rows : 1) * sizeof(uint32_t));
+    c->buf = malloc(((size_t)max_leaf_len(f) + f->n_rows + 1) * sizeof(zo_pair));
+}
+static void ctx_free(zo_ctx *c) { free(c->stamp); free(c->cand); free(c->buf); }
+
+/* lsh.rs:544-565 search: every tree with n = top_k; union; RE-score every candidate; sort; take k */
+static uint32_t search_one(zo_ctx *c, const float *q, uint32_t k, uint64_t *out_ids, uint64_t *out_keys) {
+    const zo_forest *f = c->f;
+    c->q = q; c->epoch++; c->n_cand = 0;
+    c->qq = c->metric == ZO_COSINE ? sum_prod(q, q, f->d) : 0.0f;
+    if (f->n_rows == 0) return 0; /* core.rs:295-297 */
+    for (uint32_t t = 0; t < f->T; t++) walk(c, (int32_t)f->roots[t], (int32_t)k);
+    zo_pair *r = c->buf;
+    for (uint64_t i = 0; i < c->n_cand; i++) { r[i].id = c->cand[i]; r[i].key = ctx_key(c, c->cand[i]); }
+    c->rows_scored += c->n_cand;
+    qsort(r, c->n_cand, sizeof(zo_pair), pair_cmp);
+    uint32_t m = c->n_cand < k ? (uint32_t)c->n_cand : k;
+    for (uint32_t i = 0; i < m; i++) { out_ids[i] = r[i].id; out_keys[i] = r[i].key; }
+    return m;
+}
+
+ZO_EXPORT uint32_t zo_search(const zo_forest *f, const float *X, const float *q, uint32_t k, int metric, int mode,
+                             uint64_t *out_ids, uint64_t *out_keys, zo_stats *st) {
+    zo_ctx c; ctx_init(&c, f, X, metric, mode);
+    uint32_t m = search_one(&c, q, k, out_ids, out_keys);
+    if (st) { st->rows_scored = c.rows_scored; st->planes_evaluated = c.planes_evaluated;
+              st->leaves_visited = c.leaves_visited; st->candidates = c.n_cand; }
+    ctx_free(&c);
+    return m;
+}
+
+/* core.rs:290-313 query_vectors: queries are independent; rayon par_iter -> OpenMP threads here.
+ * out arrays are b*k (unused tail entries of a row are left untouched), counts[b]. */
+ZO_EXPORT void zo_search_batch(const zo_forest *f, const float *X, const float *Q, uint64_t b, uint32_t k, int metric,
+                               int mode, uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts, int nthreads,
+                               zo_stats *st) {
+    uint64_t rs = 0, pe = 0, lv = 0, cd = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel reduction(+ : rs, pe, lv, cd)
+#endif
+    {
+        zo_ctx c; ctx_init(&c, f, X, metric, mode);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (uint64_t i = 0; i < b; i++) {
+            out_counts[i] = search_one(&c, Q + i * f->d, k, out_ids + i * k, out_keys + i * k);
+            cd += c.n_cand;
+        }
+        rs += c.rows_scored; pe += c.planes_evaluated; lv += c.leaves_visited;
+        ctx_free(&c);
+    }
+    if (st) { st->rows_scored = rs; st->planes_evaluated = pe; st->leaves_visited = lv; st->candidates = cd; }
+}
+
+/* one tree_result call, exposing the return value, the candidate ids (insertion order) and the
+ * visit trace -- for the walk-quirk known-answer tests */
+ZO_EXPORT int32_t zo_tree_result(const zo_forest *f, const float *X, uint32_t tree, const float *q, int32_t n,
+                                 int metric, int mode, uint32_t *cand_out, uint64_t *n_cand_out, uint64_t *visits_out,
+                                 uint64_t cap_visits, uint64_t *n_visits_out) {
+    zo_ctx c; ctx_init(&c, f, X, metric, mode);
+    c.q = q; c.epoch = 1; c.qq = metric == ZO_COSINE ? sum_prod(q, q, f->d) : 0.0f;
+    c.visits = visits_out; c.cap_visits = cap_visits;
+    int32_t r = walk(&c, (int32_t)f->roots[tree], n);
+    if (cand_out) memcpy(cand_out, c.cand, c.n_cand * sizeof(uint32_t));
+    if (n_cand_out) *n_cand_out = c.n_cand;
+    if (n_visits_out) *n_visits_out = c.n_visits;
+    ctx_free(&c);
+    return r;
+}
+
+/* sign of every plane of the forest for one query (the dense hash the HIP path computes with MFMA) */
+ZO_EXPORT void zo_hash_signs(const zo_forest *f, const float *q, uint8_t *out_signs, float *out_dots) {
+    for (uint32_t p = 0; p < f->n_planes; p++) {
+        float dt = zo_dot32(f->planes + (size_t)p * f->d, q, f->d);
+        if (out_dots) out_dots[p] = dt;
+        out_signs[p] = ((double)dt + (double)f->consts[p]) >= 0.0;
+    }
+}
+
+/* S-shard merge: per query, S lists of <= k (key,id) pairs sorted or not; keep the k
+ * smallest by (key,id).  lists are [S][b][k] with counts [S][b]. */
+ZO_EXPORT void zo_merge_topk(uint32_t S, uint64_t b, uint32_t k, const uint64_t *ids, const uint64_t *keys,
+                             const uint32_t *counts, uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts) {
+    typedef struct { uint64_t id, key; } mp;
+    mp *buf = malloc((size_t)S * k * sizeof(mp) + 16);
+    for (uint64_t q = 0; q < b; q++) {
+        uint32_t n = 0;
+        for (uint32_t s = 0; s < S; s++)
+            for (uint32_t i = 0; i < counts[s * b + q]; i++) {
+                buf[n].id = ids[((size_t)s * b + q) * k + i];
+                buf[n].key = keys[((size_t)s * b + q) * k + i];
+                n++;
+            }
+        for (uint32_t i = 1; i < n; i++) { /* insertion sort: S*k is small */
+            mp v = buf[i]; int64_t j = (int64_t)i - 1;
+            while (j >= 0 && (buf[j].key > v.key || (buf[j].key == v.key && buf[j].id > v.id))) { buf[j + 1] = buf[j]; j--; }
+            buf[j + 1] = v;
+        }
+        uint32_t m = n < k ? n : k;
+        for (uint32_t i = 0; i < m; i++) { out_ids[q * k + i] = buf[i].id; out_keys[q * k + i] = buf[i].key; }
+        out_counts[q] = m;
+    }
+    free(buf);
+}
+
+/* exact brute force over all rows (recall ground truth at oracle sizes) */
+ZO_EXPORT void zo_brute_force(const float *X, uint64_t n, uint32_t d, const float *q, uint32_t k, int metric, int mode,
+                              uint64_t *out_ids, uint64_t *out_keys) {
+    zo_pair *r = malloc((n + 1) * sizeof(zo_pair));
+    float qq = metric == ZO_COSINE ? sum_prod(q, q, d) : 0.0f;
+    for (uint64_t i = 0; i < n; i++) {
+        const float *a = X + i * d;
+        r[i].id = (uint32_t)i;
+        r[i].key = metric == ZO_COSINE ? key_from_sums(metric, mode, sum_prod(a, q, d), sum_prod(a, a, d), qq, 0.0f)
+                                       : key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, q, d));
+    }
+    qsort(r, n, sizeof(zo_pair), pair_cmp);
+    for (uint32_t i = 0; i < k && i < n; i++) { out_ids[i] = r[i].id; out_keys[i] = r[i].key; }
+    free(r);
+}
+
+ZO_EXPORT int zo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
