@@ -1,0 +1,197 @@
+/*
+ * zebra_hip.h -- C ABI of the MI355X (gfx950) implementation of Zebra's LSH bucket-scan + distance
+ * hot path.  This is the drop-in boundary: what the reference crate's FFI for this path binds
+ * (INTEGRATION.md shows the Rust `extern "C"` block and the shim that keeps `space::Metric`,
+ * `LSHIndex<N>` and `Database<N,Met,Mod>` signatures on top of it).
+ *
+ * Reference interfaces replaced (all paths relative to /root/reference):
+ *   zh_index_create / zh_index_destroy   LSHIndex::new            src/database/index/lsh.rs:162-167
+ *   zh_index_add                         LSHIndex::add            src/database/index/lsh.rs:440-466
+ *                                        (first call = build_index, lsh.rs:411-429)
+ *   zh_index_build                       build_a_tree x num_trees src/database/index/lsh.rs:250-267
+ *   zh_search_batch[_device]             LSHIndex::search         src/database/index/lsh.rs:544-565
+ *                                        driven per batch as Database::query_vectors does,
+ *                                        src/database/core.rs:290-313
+ *   zh_hash_signs                        Hyperplane::point_is_above  src/database/index/lsh.rs:39-43
+ *   zh_distance_batch / zh_distance_pair Metric::distance for CosineDistance, L2SquaredDistance,
+ *                                        L2Distance               src/distance.rs:19-49, 103-114
+ *   zh_index_count / zh_index_num_trees  LSHIndex::no_vectors / no_trees / is_empty  lsh.rs:389-409
+ *   zh_index_clear                       LSHIndex::clear          src/database/index/lsh.rs:506-529
+ *   zh_merge_topk_device                 (new) shard merge after the RCCL all-gather
+ *
+ * Conventions
+ *   - Every function returns ZH_OK (0) or a negative zh_status; zh_last_error() gives the message
+ *     of the calling thread's last failure.  Nothing throws or aborts across this boundary.
+ *   - The caller owns every buffer it passes; the library owns all device memory behind zh_index.
+ *   - ids are dense row numbers in insertion order (the Rust shim keeps row -> Uuid, lsh.rs:415);
+ *     results carry id_base + row so that shards of one logical index return global ids.
+ *   - keys are the reference's DistanceUnit (distance.rs:13): the IEEE-754 bit pattern of the f64
+ *     distance, compared as an unsigned integer; ties order by id.
+ *   - search/hash/distance calls on one index may come from several host threads (the reference
+ *     calls search from rayon workers, core.rs:299-303); they serialise on an internal lock.
+ *     add/build/set_forest/clear/destroy need external exclusion, like any &mut in the crate.
+ *   - There is NO CPU fallback: every entry point that computes runs gfx950 kernels and fails with
+ *     ZH_EHIP when no device is usable.
+ */
+#ifndef ZEBRA_HIP_H
+#define ZEBRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define ZH_API __attribute__((visibility("default")))
+#else
+#define ZH_API
+#endif
+
+typedef struct zh_index zh_index;
+
+typedef enum zh_status {
+    ZH_OK = 0,
+    ZH_EINVAL = -1,       /* bad argument */
+    ZH_ENOMEM = -2,       /* host or device allocation failed */
+    ZH_EHIP = -3,         /* HIP runtime / no usable gfx950 device */
+    ZH_ESTATE = -4,       /* call not valid in the index's current state */
+    ZH_ELIMIT = -5,       /* a documented limit was exceeded (e.g. top_k > ZH_MAX_TOPK) */
+    ZH_EUNSUPPORTED = -6
+} zh_status;
+
+typedef enum zh_metric { ZH_COSINE = 0, ZH_L2SQ = 1, ZH_L2 = 2 } zh_metric;
+
+/* distance.rs:23-25 applies `1.0 - c` to simsimd's cosine, which is already a distance, so the
+ * reference key is the bit pattern of the cosine SIMILARITY.  PARITY reproduces that literally;
+ * CORRECTED keys on the distance.  Ignored by the L2 metrics. */
+typedef enum zh_cosine_mode { ZH_COSINE_PARITY = 0, ZH_COSINE_CORRECTED = 1 } zh_cosine_mode;
+
+#define ZH_MAX_TOPK 1024u
+#define ZH_MAX_DEPTH 60u /* the reference recurses without bound on an unsplittable node */
+
+typedef struct zh_options {
+    uint32_t dim;           /* N of Embedding<N>, lib.rs:18 */
+    uint32_t max_node_size; /* LSHIndexOptions::max_node_size, default 5  (lsh.rs:126,134) */
+    uint32_t num_trees;     /* LSHIndexOptions::num_trees,     default 15 (lsh.rs:128,135) */
+    uint64_t seed;          /* hyperplane sampling seed (the reference uses an unseeded RNG, lsh.rs:201) */
+    int32_t device;         /* HIP device ordinal; -1 = the calling thread's current device */
+    uint64_t id_base;       /* global id of local row 0 (shard offset) */
+    uint64_t reserve_rows;  /* capacity hint: avoids a reallocating copy on growth */
+} zh_options;
+
+/* Flat forest (host pointers).  Node i is inner when plane[i] >= 0: left[i] is the child holding
+ * the rows BELOW the plane, right[i] the rows ABOVE (lsh.rs:260-264).  It is a leaf when
+ * plane[i] == -1: (uint32_t)left[i] is an offset into leaf_ids and right[i] the leaf's length.
+ * planes is n_planes x dim row-major, consts the matching offsets (Hyperplane, lsh.rs:16-25). */
+typedef struct zh_forest_view {
+    uint32_t n_nodes, n_planes, n_trees;
+    uint64_t n_leaf_ids;
+    const int32_t *plane, *left, *right;
+    const uint32_t *roots;
+    const float *planes, *consts;
+    const uint32_t *leaf_ids;
+} zh_forest_view;
+
+typedef struct zh_forest_sizes {
+    uint32_t n_nodes, n_planes, n_trees;
+    uint64_t n_leaf_ids;
+} zh_forest_sizes;
+
+/* Counters and timings of the most recent search batch on this index (zh_stats). */
+typedef struct zh_stats_t {
+    uint64_t batch;            /* queries in the batch */
+    uint64_t visits;           /* leaf visits (bucket probes) */
+    uint64_t rows_scored;      /* R_total: stored rows whose distance was computed */
+    uint64_t rows_unique;      /* R_unique: rows of the distinct leaves touched (0 unless stats level >= 2) */
+    uint64_t candidates;       /* ids handed to the final top-k (before de-duplication) */
+    uint64_t planes_dense;     /* hyperplanes hashed by the dense MFMA kernel, per query */
+    uint64_t planes_total;     /* hyperplanes in the forest */
+    uint64_t sweep_bytes;      /* algorithmic bytes of the sweep: 4*dim*rows_scored + 4*rows_scored + 8*rows_scored */
+    /* accumulated since zh_stats_reset, in milliseconds, measured with hipEvents on the stream the
+     * kernels run on (only when profiling is enabled with zh_set_profiling) */
+    double ms_hash, ms_walk, ms_sweep, ms_select, ms_final, ms_total;
+    uint64_t timed_batches;
+    uint64_t sweep_rows_accum;  /* rows_scored summed over the timed batches */
+} zh_stats_t;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+ZH_API void zh_options_default(zh_options *opt); /* dim 0, max_node_size 5, num_trees 15 (lsh.rs:131-138) */
+ZH_API int zh_index_create(const zh_options *opt, zh_index **out);
+ZH_API void zh_index_destroy(zh_index *idx);
+ZH_API int zh_index_clear(zh_index *idx); /* drops vectors AND trees (what lsh.rs:506-529 intends) */
+
+/* ---- insert --------------------------------------------------------------------------------- */
+/* LSHIndex::add: rows is n x dim row-major host memory.  If the index has no trees the forest is
+ * built over everything stored so far plus these rows (build_index); otherwise the rows descend
+ * the existing trees and split full leaves (insert, lsh.rs:350-382).  out_row_ids (may be NULL)
+ * receives id_base + row for each new row. */
+ZH_API int zh_index_add(zh_index *idx, const float *rows, size_t n, uint64_t *out_row_ids);
+/* staged loading for large shards: append without building, then zh_index_build once */
+ZH_API int zh_index_append(zh_index *idx, const float *rows, size_t n, uint64_t *out_row_ids);
+ZH_API int zh_index_append_device(zh_index *idx, const float *d_rows, size_t n);
+/* append n synthetic rows generated on the device (bit-identical to oracle zo_synth_rows);
+ * kind 0 = ~N(0,1), kind 1 = integer-valued "SIFT-style" in [0,255] */
+ZH_API int zh_index_append_synthetic(zh_index *idx, size_t n, uint64_t seed, uint64_t first_row, int kind);
+ZH_API int zh_index_build(zh_index *idx); /* (re)build all trees on the GPU */
+
+/* ---- forest exchange (parity tests inject / extract the exact same forest) ----------------- */
+ZH_API int zh_index_set_forest(zh_index *idx, const zh_forest_view *forest);
+ZH_API int zh_index_forest_sizes(zh_index *idx, zh_forest_sizes *out);
+/* caller-allocated arrays of the sizes reported above */
+ZH_API int zh_index_get_forest(zh_index *idx, int32_t *plane, int32_t *left, int32_t *right, uint32_t *roots,
+                        float *planes, float *consts, uint32_t *leaf_ids);
+
+/* ---- queries -------------------------------------------------------------------------------- */
+ZH_API uint64_t zh_index_count(const zh_index *idx);     /* stored vectors (0 <=> no_vectors) */
+ZH_API uint32_t zh_index_num_trees(const zh_index *idx); /* built trees    (0 <=> no_trees)   */
+ZH_API uint32_t zh_index_dim(const zh_index *idx);
+ZH_API const float *zh_index_rows_device(const zh_index *idx); /* device pointer to the stored rows (read-only) */
+/* copy n stored rows starting at local row `first` back to host memory (KeyValue::embedding, lsh.rs:107-119) */
+ZH_API int zh_index_read_rows(zh_index *idx, uint64_t first, size_t n, float *out);
+
+/* point_is_above for every plane of the forest (numbered as zh_index_get_forest returns them) and
+ * every query: out_bits is b x ceil(n_planes/32) words, bit p%32 of word p/32 = above.
+ * out_dots (may be NULL) is b x n_planes raw f32 dot products.  q is b x dim host memory. */
+ZH_API int zh_hash_signs(zh_index *idx, const float *q, size_t b, uint32_t *out_bits, float *out_dots);
+
+/* LSHIndex::search for a batch: q is b x dim; out_ids/out_keys are b x k (entries past
+ * out_counts[i] are set to UINT64_MAX); ascending by (key, id).  Host pointers. */
+ZH_API int zh_search_batch(zh_index *idx, const float *q, size_t b, size_t k, int metric, int cosine_mode,
+                    uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts);
+/* The same with queries and results already resident in device memory; kernels are enqueued on
+ * `stream` (a hipStream_t; NULL = the index's own stream) and have completed on return. */
+ZH_API int zh_search_batch_device(zh_index *idx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode,
+                           uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
+
+/* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers). */
+ZH_API int zh_distance_batch(int metric, int cosine_mode, const float *a, const float *q, size_t n, size_t dim,
+                      uint64_t *out_keys, int device);
+ZH_API int zh_distance_pair(int metric, int cosine_mode, const float *a, const float *b, size_t dim, uint64_t *out_key,
+                     int device);
+
+/* Shard merge: S lists of b x k (ids, keys) with counts S x b, all in device memory (e.g. the
+ * output of an RCCL all-gather of every rank's zh_search_batch_device result) -> b x k merged. */
+ZH_API int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_ids,
+                         const uint64_t *d_keys, const uint32_t *d_counts, uint64_t *d_out_ids,
+                         uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
+
+/* synthetic queries on the device (bit-identical to oracle zo_synth_queries) */
+ZH_API int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,
+                            uint64_t b0, size_t b, uint32_t dim, int kind, void *stream);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+ZH_API int zh_set_profiling(zh_index *idx, int level); /* 0 off, 1 per-stage hipEvent timing, 2 + unique-row count */
+ZH_API int zh_stats(zh_index *idx, zh_stats_t *out);
+ZH_API int zh_stats_reset(zh_index *idx);
+/* number of leading tree levels hashed by the dense MFMA kernel; -1 = choose per batch (default) */
+ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
+
+ZH_API const char *zh_last_error(void);
+ZH_API const char *zh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEBRA_HIP_H */

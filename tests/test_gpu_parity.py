@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP path (through the C ABI, zebra_amd -> libzebra_hip.so) against the CPU
+oracle on the same seeded inputs.  Bars (BASELINE.json north_star): hash sign bits, bucket
+membership, returned ids and counts BIT-EXACT; distance keys bit-exact as well (the summation order
+is fixed on both sides), which is stronger than the 1e-5 relative the north_star asks for."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zebra_oracle as zo  # noqa: E402  (the checker; tests may use it)
+
+
+@pytest.fixture(scope="module")
+def za():
+    import zebra_amd
+    return zebra_amd
+
+
+def metrics(za):
+    return [("l2sq", za.L2SquaredDistance(), zo.L2SQ, 0), ("l2", za.L2Distance(), zo.L2, 0),
+            ("cos_parity", za.CosineDistance(parity=True), zo.COSINE, zo.PARITY),
+            ("cos_corrected", za.CosineDistance(parity=False), zo.COSINE, zo.CORRECTED)]
+
+
+# --------------------------------------------------------------------------- src/distance.rs
+@pytest.mark.parametrize("d", [1, 3, 4, 100, 128, 256, 384, 768, 1000, 1536])
+def test_distance_keys_bit_exact(za, d):
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((257, d)).astype(np.float32)
+    X[3] = 0  # zero-norm row
+    q = rng.standard_normal(d).astype(np.float32)
+    for name, m, om, omode in metrics(za):
+        got = m.distance_batch(X, q)
+        want = zo.distance_batch(om, omode, X, q)
+        assert (got == want).all(), name
+        # 1e-5 relative against float64 numpy (independent of the summation order)
+    l2 = ((X.astype(np.float64) - q.astype(np.float64)) ** 2).sum(1)
+    np.testing.assert_allclose(za.L2SquaredDistance().distance_batch(X, q).view(np.float64), l2, rtol=1e-5)
+    assert za.L2SquaredDistance().distance(X[0], q) == zo.distance(zo.L2SQ, 0, X[0], q)
+    # zero query: both zero-norm branches of simsimd's cosine
+    z = np.zeros(d, np.float32)
+    for name, m, om, omode in metrics(za):
+        assert (m.distance_batch(X[:5], z) == zo.distance_batch(om, omode, X[:5], z)).all(), name
+
+
+def test_distance_special_values(za):
+    X = np.array([[np.inf, 1, 2, 3], [np.nan, 0, 0, 0], [1e-30, 1e-30, 0, 0], [3e38, 3e38, 3e38, 3e38],
+                  [-0.0, 0, 0, 0], [1, 2, 3, 4]], np.float32)
+    q = np.array([1, 2, 3, 4], np.float32)
+    for name, m, om, omode in metrics(za):
+        got, want = m.distance_batch(X, q), zo.distance_batch(om, omode, X, q)
+        gf, wf = got.view(np.float64), want.view(np.float64)
+        same = (got == want) | (np.isnan(gf) & np.isnan(wf))
+        assert same.all(), (name, got, want)
+
+
+# ------------------------------------------------------------------ lsh.rs:39-43 (the hash)
+@pytest.mark.parametrize("n,d,M,T", [(3000, 32, 64, 4), (2000, 384, 48, 3), (1500, 768, 64, 2), (800, 100, 16, 2)])
+def test_hash_signs_and_dots_bit_exact(za, n, d, M, T):
+    X = zo.synth_rows(n, d)
+    f = zo.Forest.build(X, M, T, seed=9)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X)
+    ix.set_forest(f.arrays())
+    g = zo.Forest.from_arrays(X, M, ix.get_forest())  # the library renumbers planes level-major
+    Q = zo.synth_queries(70, d, n)
+    signs, dots = ix.hash_signs(Q, dots=True)
+    for b in range(Q.shape[0]):
+        s, dt = g.hash_signs(Q[b])
+        assert (dots[b].view(np.uint32) == dt.view(np.uint32)).all() or np.array_equal(dots[b], dt)
+        assert (signs[b] == s.astype(bool)).all()
+    # renumbering did not change the forest
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+
+
+# --------------------------------------------------- lsh.rs:290-348 + 544-565 (walk + search)
+CASES = [
+    # n, d, M, T, k, batch, kind
+    (5000, 64, 5, 15, 10, 24, 0),      # reference defaults: near-exhaustive regime
+    (20000, 384, 256, 15, 10, 64, 0),  # one leaf per tree
+    (8000, 768, 512, 8, 100, 32, 0),   # k = 100
+    (6000, 128, 300, 10, 10, 48, 1),   # SIFT-style integers: exact L2
+    (3000, 100, 40, 5, 7, 17, 0),      # d not a multiple of 4 -> generic kernels
+    (4000, 256, 12, 6, 10, 9, 0),      # leaves ~ k: backup walks with n - k
+]
+
+
+@pytest.mark.parametrize("n,d,M,T,k,B,kind", CASES)
+def test_search_bit_exact_with_injected_forest(za, n, d, M, T, k, B, kind):
+    X = zo.synth_rows(n, d, kind=kind)
+    Q = zo.synth_queries(B, d, n, kind=kind)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X)
+    ix.set_forest(f.arrays())
+    for name, m, om, omode in metrics(za):
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), name
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c]).all(), (name, b)
+            assert (keys[b, :c] == ok[b, :c]).all(), (name, b)
+            assert (ids[b, c:] == np.uint64(2**64 - 1)).all()
+    # single-query entry point
+    r = ix.search(Q[0], k, za.L2SquaredDistance())
+    oi, ok = f.search(Q[0], k, zo.L2SQ)
+    assert r == list(zip(oi.tolist(), ok.tolist()))
+
+
+@pytest.mark.parametrize("levels", [0, 1, 3, 100])
+def test_dense_levels_do_not_change_results(za, levels):
+    n, d, M, T, k = 6000, 96, 8, 5, 10
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(20, d, n)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X)
+    ix.set_forest(f.arrays())
+    ix.set_dense_levels(levels)
+    ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ)
+    assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()
+    st = ix.stats()
+    assert st["planes_total"] == f.arrays()["consts"].size
+    if levels == 0:
+        assert st["planes_dense"] == 0
+    if levels == 100:
+        assert st["planes_dense"] == st["planes_total"]
+
+
+# -------------------------------------------------------- lsh.rs:192-267, 411-429 (the build)
+@pytest.mark.parametrize("n,d,M,T", [(4000, 64, 5, 3), (20000, 128, 64, 4), (6000, 384, 100, 2), (3000, 768, 256, 2),
+                                     (1000, 30, 7, 2)])
+def test_gpu_build_equals_oracle_build(za, n, d, M, T):
+    X = zo.synth_rows(n, d)
+    f = zo.Forest.build(X, M, T, seed=77)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=77)
+    ids = ix.add(X)  # LSHIndex::add on an empty index = build_index
+    assert ids.tolist() == list(range(n))
+    assert not ix.is_empty() and len(ix) == n
+    g = ix.get_forest()
+    assert zo.canonical_forest(g, d) == zo.canonical_forest(f.arrays(), d)
+    # every id in exactly one leaf per tree; built leaves hold < M ids
+    assert g["leaf_ids"].size == n * T
+    leaves = g["plane"] < 0
+    assert (g["right"][leaves] < M).all()
+    for t in range(T):
+        assert sorted(g["leaf_ids"][t * n:(t + 1) * n].tolist()) == list(range(n))
+    # and searching the GPU-built forest gives the oracle's answers
+    Q = zo.synth_queries(16, d, n)
+    ids_, keys_, counts_ = ix.search_batch(Q, 10, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(Q, 10, zo.L2SQ)
+    assert (counts_ == oc).all() and (ids_ == oi).all() and (keys_ == ok).all()
+
+
+def test_synthetic_generators_bit_exact(za):
+    n, d = 3000, 384
+    ix = za.LSHIndex(d, za.LSHIndexOptions(64, 2))
+    ix.append_synthetic(n, seed=zo.SEED_ROWS, first_row=0, kind=0)
+    assert (ix.read_rows(0, n).view(np.uint32) == zo.synth_rows(n, d).view(np.uint32)).all()
+    ix2 = za.LSHIndex(128, za.LSHIndexOptions(64, 2))
+    ix2.append_synthetic(500, seed=5, first_row=1000, kind=1)
+    assert (ix2.read_rows(0, 500) == zo.synth_rows(500, 128, seed=5, row0=1000, kind=1)).all()
+    import torch
+    for kind, dd in ((0, 384), (1, 128)):
+        q = torch.empty((33, dd), dtype=torch.float32, device="cuda")
+        za.synth_queries_device(0, q.data_ptr(), 12345, 33, dd, b0=7, kind=kind)
+        want = zo.synth_queries(33, dd, 12345, b0=7, kind=kind)
+        assert (q.cpu().numpy().view(np.uint32) == want.view(np.uint32)).all()
+
+
+# ------------------------------------------------------------------------------ edge cases
+def test_edge_cases(za):
+    d = 16
+    ix = za.LSHIndex(d)
+    assert ix.is_empty() and ix.no_vectors() and ix.no_trees()
+    Q = zo.synth_queries(3, d, 10)
+    ids, keys, counts = ix.search_batch(Q, 5, za.L2SquaredDistance())  # empty index -> empty result
+    assert (counts == 0).all() and (ids == np.uint64(2**64 - 1)).all()
+    # fewer rows than max_node_size: every tree is one leaf; top_k > rows
+    X = zo.synth_rows(3, d)
+    ix.add(X)
+    f = zo.Forest.build(X, 5, 15)
+    ids, keys, counts = ix.search_batch(Q, 10, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(Q, 10, zo.L2SQ)
+    assert (counts == oc).all() and (counts == 3).all()
+    assert (ids[:, :3] == oi[:, :3]).all() and (keys[:, :3] == ok[:, :3]).all()
+    # duplicates of one vector: unsplittable node -> depth guard on both sides, same forest
+    Xd = np.repeat(zo.synth_rows(1, d), 40, axis=0)
+    ixd = za.LSHIndex(d, za.LSHIndexOptions(8, 2), seed=3)
+    ixd.add(Xd)
+    fd = zo.Forest.build(Xd, 8, 2, seed=3)
+    assert zo.canonical_forest(ixd.get_forest(), d) == zo.canonical_forest(fd.arrays(), d)
+    i2, k2, c2 = ixd.search_batch(Q, 10, za.L2SquaredDistance())
+    o2 = fd.search_batch(Q, 10, zo.L2SQ)
+    assert (c2 == o2[2]).all() and (i2 == o2[0]).all() and (k2 == o2[1]).all()
+    # limits and argument errors
+    with pytest.raises(za.ZhError):
+        ix.search_batch(Q, za.MAX_TOPK + 1, za.L2SquaredDistance())
+    ix.clear()
+    assert ix.is_empty()
+    # id_base shifts returned ids
+    ixb = za.LSHIndex(d, za.LSHIndexOptions(5, 3), id_base=1000)
+    assert ixb.add(zo.synth_rows(50, d)).tolist() == list(range(1000, 1050))
+    r = ixb.search(zo.synth_rows(50, d)[7], 1, za.L2SquaredDistance())
+    assert r[0][0] == 1007 and r[0][1] == 0
+
+
+def test_database_mirror(za):
+    """Database::insert_records / query_vectors (core.rs:245-254, 290-313)"""
+    d, n = 32, 500
+    X = zo.synth_rows(n, d)
+    db = za.Database(d, za.L2SquaredDistance(), za.LSHIndexOptions(16, 6))
+    assert db.query_vectors(X[:2], 3) == {}
+    db.insert_records(X, [f"doc{i}".encode() for i in range(n)])
+    res = db.query_vectors(X[[5, 77]], 3)
+    assert 5 in res[0] and res[0][5] == b"doc5" and 77 in res[1]
+    assert len(res[0]) == 3
+
+
+# ---------------------------------------------------------------- shard merge
+@pytest.mark.parametrize("S,k", [(2, 10), (4, 100), (8, 10), (8, 1024)])
+def test_shard_merge_device(za, S, k):
+    import torch
+    n, d, M, T, B = 4000, 64, 64, 5, 13
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    per = n // S
+    kk = min(k, 128)  # per-shard lists of kk valid entries inside k-wide slots
+    all_ids, all_keys, all_counts = [], [], []
+    for s in range(S):
+        Xs = X[s * per:(s + 1) * per]
+        ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=s * per, seed=100 + s)
+        ix.add(Xs)
+        i, kys, c = ix.search_batch(Q, kk, za.L2SquaredDistance())
+        # oracle of the shard: same forest seed, local ids + base
+        f = zo.Forest.build(Xs, M, T, seed=100 + s)
+        oi, ok, oc = f.search_batch(Q, kk, zo.L2SQ)
+        assert (c == oc).all()
+        for b in range(B):
+            assert (i[b, :oc[b]] == oi[b, :oc[b]] + np.uint64(s * per)).all() and (kys[b, :oc[b]] == ok[b, :oc[b]]).all()
+        pad_i = np.full((B, k), 2**64 - 1, np.uint64)
+        pad_k = np.full((B, k), 2**64 - 1, np.uint64)
+        pad_i[:, :kk], pad_k[:, :kk] = i, kys
+        all_ids.append(pad_i), all_keys.append(pad_k), all_counts.append(c)
+    ids = np.stack(all_ids)
+    keys = np.stack(all_keys)
+    counts = np.stack(all_counts)
+    want = zo.merge_topk(ids, keys, counts, k)
+    t_ids = torch.from_numpy(ids.view(np.int64)).cuda()
+    t_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    t_counts = torch.from_numpy(counts.view(np.int32)).cuda()
+    o_ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    o_keys = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    o_counts = torch.empty(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    za.merge_topk_device(0, S, B, k, t_ids.data_ptr(), t_keys.data_ptr(), t_counts.data_ptr(), o_ids.data_ptr(),
+                         o_keys.data_ptr(), o_counts.data_ptr())
+    gi = o_ids.cpu().numpy().view(np.uint64)
+    gk = o_keys.cpu().numpy().view(np.uint64)
+    gc = o_counts.cpu().numpy().view(np.uint32)
+    assert (gc == want[2]).all()
+    for b in range(B):
+        assert (gi[b, :gc[b]] == want[0][b, :gc[b]]).all() and (gk[b, :gc[b]] == want[1][b, :gc[b]]).all()
+
+
+def test_search_device_entry_point(za):
+    import torch
+    n, d, M, T, k, B = 10000, 384, 128, 15, 10, 40
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append_synthetic(n)
+    ix.build()
+    X = zo.synth_rows(n, d)
+    f = zo.Forest.build(X, M, T)
+    q = torch.empty((B, d), dtype=torch.float32, device="cuda")
+    za.synth_queries_device(0, q.data_ptr(), n, B, d)
+    ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    keys = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    counts = torch.empty(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ix.set_profiling(2)
+    m = za.CosineDistance(parity=True)
+    ix.search_batch_device(q.data_ptr(), B, k, m, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    oi, ok, oc = f.search_batch(zo.synth_queries(B, d, n), k, zo.COSINE, zo.PARITY)
+    assert (counts.cpu().numpy().view(np.uint32) == oc).all()
+    assert (ids.cpu().numpy().view(np.uint64) == oi).all() and (keys.cpu().numpy().view(np.uint64) == ok).all()
+    st = ix.stats()
+    assert st["timed_batches"] == 1 and st["ms_sweep"] > 0 and st["rows_scored"] >= st["rows_unique"] > 0
+    assert st["visits"] >= B * T

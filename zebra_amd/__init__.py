@@ -1,0 +1,16 @@
+"""zebra_amd -- MI355X (gfx950) implementation of Zebra's LSH bucket-scan + distance hot path.
+
+Host-side mirror of the reference crate's interface for this path, over the C ABI of
+include/zebra_hip.h:
+
+    reference (Rust)                                    here
+    Embedding<N>           src/lib.rs:15-46             numpy float32 rows of length N
+    DistanceUnit = u64     src/distance.rs:13           numpy uint64 keys
+    CosineDistance<N> ...  src/distance.rs:15-49,99-114 CosineDistance, L2SquaredDistance, L2Distance
+    LSHIndexOptions<N>     src/database/index/lsh.rs:122-139   LSHIndexOptions
+    LSHIndex<N>            src/database/index/lsh.rs:144-565   LSHIndex
+    Database<N,Met,Mod>    src/database/core.rs:45-313  Database (insert_records / query_vectors only)
+"""
+from ._ffi import COSINE, COSINE_CORRECTED, COSINE_PARITY, L2, L2SQ, MAX_TOPK, ZhError  # noqa: F401
+from .index import (CosineDistance, Database, L2Distance, L2SquaredDistance, LSHIndex,  # noqa: F401
+                    LSHIndexOptions, merge_topk_device, synth_queries_device)

@@ -1,0 +1,841 @@
+// zh_api.hip -- the C ABI of include/zebra_hip.h: index lifetime, device memory, forest build
+// orchestration and the per-batch search pipeline.  Host code only; kernels live in
+// zh_search.hip / zh_build.hip.  There is no CPU compute path in this file: every entry point
+// that produces distances, signs or neighbours launches gfx950 kernels.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "zh_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? ZH_ENOMEM : ZH_EHIP, "%s: %s (%s:%d)", #expr,          \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+    } while (0)
+
+extern "C" const char *zh_last_error(void) { return g_err.c_str(); }
+extern "C" const char *zh_version(void) { return "zebra-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// growable device buffer
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
+        if (bytes <= cap) return ZH_OK;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        ncap = (ncap + 255) & ~size_t(255);
+        void *np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap);
+        if (e != hipSuccess) {
+            ncap = (bytes + 255) & ~size_t(255);
+            e = hipMalloc(&np, ncap);
+        }
+        if (e != hipSuccess) return fail(ZH_ENOMEM, "hipMalloc(%zu bytes): %s", ncap, hipGetErrorString(e));
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { hipFree(np); return fail(ZH_EHIP, "grow copy: %s", hipGetErrorString(e)); }
+        }
+        if (p) hipFree(p);
+        p = np;
+        cap = ncap;
+        return ZH_OK;
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct zh_index {
+    zh_options opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    // stored vectors: n_rows x dim row-major f32 (Embedding<N>, lib.rs:18)
+    DevBuf X;
+    uint64_t n_rows = 0;
+
+    // forest
+    DevBuf node_plane, node_left, node_right, roots, planes, consts, leaf_ids;
+    uint32_t n_nodes = 0, n_planes = 0, n_trees = 0;
+    uint64_t n_leaf_ids = 0;
+    std::vector<int32_t> h_plane, h_left, h_right;
+    std::vector<uint32_t> h_roots;
+    std::vector<uint32_t> planes_below_level;  // [L] = planes whose level < L ; planes are stored level-major
+    uint32_t max_leaf_len = 0;
+
+    // per-batch workspace
+    DevBuf wQ, wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wVisitRowOff, wKeys,
+        wCandKeys, wCandIds, wOutIds, wOutKeys, wOutCounts;
+    ZhTotals *h_totals = nullptr;  // pinned
+
+    int dense_levels = -1;
+    int profiling = 0;
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+    zh_stats_t stats{};
+};
+
+static int set_device(const zh_index *ix) {
+    hipError_t e = hipSetDevice(ix->device);
+    if (e != hipSuccess) return fail(ZH_EHIP, "hipSetDevice(%d): %s", ix->device, hipGetErrorString(e));
+    return ZH_OK;
+}
+
+static ZhForestDev forest_dev(const zh_index *ix) {
+    ZhForestDev f;
+    f.node_plane = ix->node_plane.as<int32_t>();
+    f.node_left = ix->node_left.as<int32_t>();
+    f.node_right = ix->node_right.as<int32_t>();
+    f.roots = ix->roots.as<uint32_t>();
+    f.planes = ix->planes.as<float>();
+    f.consts = ix->consts.as<float>();
+    f.leaf_ids = ix->leaf_ids.as<uint32_t>();
+    f.n_nodes = ix->n_nodes;
+    f.n_planes = ix->n_planes;
+    f.n_trees = ix->n_trees;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" void zh_options_default(zh_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->max_node_size = 5;  // lsh.rs:134
+    o->num_trees = 15;     // lsh.rs:135
+    o->seed = 0x5EB2A003ull;
+    o->device = -1;
+}
+
+extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
+    if (!opt || !out) return fail(ZH_EINVAL, "zh_index_create: null argument");
+    if (opt->dim == 0) return fail(ZH_EINVAL, "zh_index_create: dim must be > 0");
+    if (opt->num_trees > 4096) return fail(ZH_ELIMIT, "zh_index_create: num_trees > 4096");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(ZH_EHIP, "no usable HIP device (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    zh_index *ix = new (std::nothrow) zh_index();
+    if (!ix) return fail(ZH_ENOMEM, "out of host memory");
+    ix->opt = *opt;
+    if (opt->device < 0) {
+        if (hipGetDevice(&ix->device) != hipSuccess) ix->device = 0;
+    } else
+        ix->device = opt->device;
+    if (ix->device >= ndev) { delete ix; return fail(ZH_EINVAL, "device %d out of range (%d devices)", opt->device, ndev); }
+    int rc = set_device(ix);
+    if (rc) { delete ix; return rc; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            delete ix;
+            return fail(ZH_EHIP, "device %d is %s; this library is built for gfx950 only", opt->device, prop.gcnArchName);
+        }
+    }
+    e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ix; return fail(ZH_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    e = hipHostMalloc((void **)&ix->h_totals, sizeof(ZhTotals), hipHostMallocDefault);
+    if (e != hipSuccess) { hipStreamDestroy(ix->stream); delete ix; return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    if (opt->reserve_rows) {
+        rc = ix->X.ensure((size_t)opt->reserve_rows * opt->dim * sizeof(float));
+        if (rc) { zh_index_destroy(ix); return rc; }
+    }
+    *out = ix;
+    return ZH_OK;
+}
+
+static void free_forest(zh_index *ix) {
+    ix->node_plane.release(); ix->node_left.release(); ix->node_right.release(); ix->roots.release();
+    ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
+    ix->n_nodes = ix->n_planes = ix->n_trees = 0;
+    ix->n_leaf_ids = 0;
+    ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
+    ix->planes_below_level.clear();
+    ix->max_leaf_len = 0;
+}
+
+extern "C" void zh_index_destroy(zh_index *ix) {
+    if (!ix) return;
+    hipSetDevice(ix->device);
+    if (ix->stream) hipStreamSynchronize(ix->stream);
+    free_forest(ix);
+    ix->X.release();
+    DevBuf *ws[] = {&ix->wQ, &ix->wQQ, &ix->wBits, &ix->wCounts, &ix->wInline, &ix->wRowBase, &ix->wCandBase,
+                    &ix->wVisitBase, &ix->wTotals, &ix->wVisits, &ix->wVisitRowOff, &ix->wKeys, &ix->wCandKeys,
+                    &ix->wCandIds, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
+    for (DevBuf *b : ws) b->release();
+    if (ix->ev_ok) for (auto &e : ix->ev) hipEventDestroy(e);
+    if (ix->h_totals) hipHostFree(ix->h_totals);
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+extern "C" int zh_index_clear(zh_index *ix) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    hipStreamSynchronize(ix->stream);
+    free_forest(ix);
+    ix->n_rows = 0;
+    return ZH_OK;
+}
+
+extern "C" uint64_t zh_index_count(const zh_index *ix) { return ix ? ix->n_rows : 0; }
+extern "C" uint32_t zh_index_num_trees(const zh_index *ix) { return ix ? ix->n_trees : 0; }
+extern "C" uint32_t zh_index_dim(const zh_index *ix) { return ix ? ix->opt.dim : 0; }
+extern "C" const float *zh_index_rows_device(const zh_index *ix) { return ix ? ix->X.as<float>() : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// rows
+// ------------------------------------------------------------------------------------------------
+static int grow_rows(zh_index *ix, size_t n_more) {
+    size_t need = (size_t)(ix->n_rows + n_more) * ix->opt.dim * sizeof(float);
+    if (ix->n_rows + n_more > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "more than 2^32-1 rows in one index (shard it)");
+    return ix->X.ensure(need, true, ix->stream);
+}
+
+extern "C" int zh_index_append(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
+    if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_append: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if ((rc = grow_rows(ix, n))) return rc;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(ix->X.as<float>() + (size_t)ix->n_rows * ix->opt.dim, rows,
+                              n * ix->opt.dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+    }
+    if (out_ids) for (size_t i = 0; i < n; i++) out_ids[i] = ix->opt.id_base + ix->n_rows + i;
+    ix->n_rows += n;
+    return ZH_OK;
+}
+
+extern "C" int zh_index_read_rows(zh_index *ix, uint64_t first, size_t n, float *out) {
+    if (!ix || (n && !out)) return fail(ZH_EINVAL, "zh_index_read_rows: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (first + n > ix->n_rows) return fail(ZH_EINVAL, "zh_index_read_rows: rows [%llu, %llu) out of range (%llu stored)",
+                                            (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)ix->n_rows);
+    if (n) HIPCHK(hipMemcpy(out, ix->X.as<float>() + (size_t)first * ix->opt.dim, n * ix->opt.dim * sizeof(float), hipMemcpyDeviceToHost));
+    return ZH_OK;
+}
+
+extern "C" int zh_index_append_device(zh_index *ix, const float *d_rows, size_t n) {
+    if (!ix || (!d_rows && n)) return fail(ZH_EINVAL, "zh_index_append_device: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if ((rc = grow_rows(ix, n))) return rc;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(ix->X.as<float>() + (size_t)ix->n_rows * ix->opt.dim, d_rows,
+                              n * ix->opt.dim * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+    }
+    ix->n_rows += n;
+    return ZH_OK;
+}
+
+extern "C" int zh_index_append_synthetic(zh_index *ix, size_t n, uint64_t seed, uint64_t first_row, int kind) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if ((rc = grow_rows(ix, n))) return rc;
+    HIPCHK(zh_launch_synth_rows(ix->X.as<float>() + (size_t)ix->n_rows * ix->opt.dim, n, ix->opt.dim, seed, first_row,
+                                kind, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->n_rows += n;
+    return ZH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forest upload (shared by set_forest and build): node arrays on the host, planes level-major
+// ------------------------------------------------------------------------------------------------
+static int upload_nodes(zh_index *ix) {
+    size_t nn = ix->h_plane.size();
+    int rc;
+    if ((rc = ix->node_plane.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
+    if ((rc = ix->node_left.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
+    if ((rc = ix->node_right.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
+    if ((rc = ix->roots.ensure(std::max<size_t>(ix->h_roots.size(), 1) * 4))) return rc;
+    if (nn) {
+        HIPCHK(hipMemcpyAsync(ix->node_plane.p, ix->h_plane.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(hipMemcpyAsync(ix->node_left.p, ix->h_left.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(hipMemcpyAsync(ix->node_right.p, ix->h_right.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
+    }
+    if (!ix->h_roots.empty())
+        HIPCHK(hipMemcpyAsync(ix->roots.p, ix->h_roots.data(), ix->h_roots.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->n_nodes = (uint32_t)nn;
+    ix->n_trees = (uint32_t)ix->h_roots.size();
+    ix->max_leaf_len = 0;
+    for (size_t i = 0; i < nn; i++)
+        if (ix->h_plane[i] < 0) ix->max_leaf_len = std::max(ix->max_leaf_len, (uint32_t)ix->h_right[i]);
+    return ZH_OK;
+}
+
+extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
+    if (!ix || !fv) return fail(ZH_EINVAL, "zh_index_set_forest: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    const uint32_t nn = fv->n_nodes, np = fv->n_planes, nt = fv->n_trees, d = ix->opt.dim;
+    if (nt && (!fv->roots || !fv->plane || !fv->left || !fv->right)) return fail(ZH_EINVAL, "set_forest: null arrays");
+    if (np && (!fv->planes || !fv->consts)) return fail(ZH_EINVAL, "set_forest: null plane arrays");
+    if (fv->n_leaf_ids && !fv->leaf_ids) return fail(ZH_EINVAL, "set_forest: null leaf_ids");
+    if (fv->n_leaf_ids > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "set_forest: more than 2^32-1 leaf entries");
+    // validate + level of every node (BFS per tree)
+    std::vector<int32_t> level(nn, -1);
+    std::vector<uint32_t> order;  // inner nodes in (level, tree, bfs) order
+    std::vector<std::vector<uint32_t>> by_level;
+    for (uint32_t t = 0; t < nt; t++) {
+        if (fv->roots[t] >= nn) return fail(ZH_EINVAL, "set_forest: root %u out of range", t);
+        std::vector<uint32_t> cur{fv->roots[t]}, nxt;
+        int32_t lv = 0;
+        while (!cur.empty()) {
+            if ((size_t)lv >= by_level.size()) by_level.resize(lv + 1);
+            for (uint32_t n : cur) {
+                if (level[n] >= 0) return fail(ZH_EINVAL, "set_forest: node %u reachable twice", n);
+                level[n] = lv;
+                if (fv->plane[n] >= 0) {
+                    if ((uint32_t)fv->plane[n] >= np) return fail(ZH_EINVAL, "set_forest: plane index out of range at node %u", n);
+                    if (fv->left[n] < 0 || (uint32_t)fv->left[n] >= nn || fv->right[n] < 0 || (uint32_t)fv->right[n] >= nn)
+                        return fail(ZH_EINVAL, "set_forest: child index out of range at node %u", n);
+                    by_level[lv].push_back(n);
+                    nxt.push_back((uint32_t)fv->left[n]);
+                    nxt.push_back((uint32_t)fv->right[n]);
+                } else {
+                    uint64_t off = (uint32_t)fv->left[n], len = (uint32_t)fv->right[n];
+                    if (fv->right[n] < 0 || off + len > fv->n_leaf_ids) return fail(ZH_EINVAL, "set_forest: leaf range out of bounds at node %u", n);
+                }
+            }
+            cur.swap(nxt);
+            nxt.clear();
+            lv++;
+            if (lv > 63) return fail(ZH_ELIMIT, "set_forest: tree deeper than 63 levels");
+        }
+    }
+    for (uint64_t i = 0; i < fv->n_leaf_ids; i++)
+        if (fv->leaf_ids[i] >= ix->n_rows) return fail(ZH_EINVAL, "set_forest: leaf id %u >= stored rows %llu", fv->leaf_ids[i], (unsigned long long)ix->n_rows);
+    // renumber planes level-major
+    std::vector<int32_t> new_of_old(np, -1);
+    std::vector<uint32_t> old_of_new;
+    std::vector<uint32_t> below{0};
+    for (auto &lvl : by_level) {
+        for (uint32_t n : lvl) {
+            uint32_t op = (uint32_t)fv->plane[n];
+            if (new_of_old[op] < 0) { new_of_old[op] = (int32_t)old_of_new.size(); old_of_new.push_back(op); }
+        }
+        below.push_back((uint32_t)old_of_new.size());
+    }
+    hipStreamSynchronize(ix->stream);
+    free_forest(ix);
+    ix->h_plane.assign(fv->plane, fv->plane + nn);
+    ix->h_left.assign(fv->left, fv->left + nn);
+    ix->h_right.assign(fv->right, fv->right + nn);
+    ix->h_roots.assign(fv->roots, fv->roots + nt);
+    for (uint32_t n = 0; n < nn; n++)
+        if (ix->h_plane[n] >= 0) ix->h_plane[n] = level[n] >= 0 ? new_of_old[ix->h_plane[n]] : 0;
+    const uint32_t np_used = (uint32_t)old_of_new.size();
+    std::vector<float> hp((size_t)std::max<uint32_t>(np_used, 1) * d), hc(std::max<uint32_t>(np_used, 1));
+    for (uint32_t i = 0; i < np_used; i++) {
+        memcpy(&hp[(size_t)i * d], fv->planes + (size_t)old_of_new[i] * d, d * sizeof(float));
+        hc[i] = fv->consts[old_of_new[i]];
+    }
+    if ((rc = ix->planes.ensure(hp.size() * 4))) return rc;
+    if ((rc = ix->consts.ensure(hc.size() * 4))) return rc;
+    if ((rc = ix->leaf_ids.ensure(std::max<uint64_t>(fv->n_leaf_ids, 1) * 4))) return rc;
+    HIPCHK(hipMemcpyAsync(ix->planes.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->consts.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    if (fv->n_leaf_ids)
+        HIPCHK(hipMemcpyAsync(ix->leaf_ids.p, fv->leaf_ids, fv->n_leaf_ids * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->n_planes = np_used;
+    ix->n_leaf_ids = fv->n_leaf_ids;
+    ix->planes_below_level = below;
+    return upload_nodes(ix);
+}
+
+extern "C" int zh_index_forest_sizes(zh_index *ix, zh_forest_sizes *out) {
+    if (!ix || !out) return fail(ZH_EINVAL, "null argument");
+    out->n_nodes = ix->n_nodes; out->n_planes = ix->n_planes; out->n_trees = ix->n_trees; out->n_leaf_ids = ix->n_leaf_ids;
+    return ZH_OK;
+}
+
+extern "C" int zh_index_get_forest(zh_index *ix, int32_t *plane, int32_t *left, int32_t *right, uint32_t *roots,
+                                   float *planes, float *consts, uint32_t *leaf_ids) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (plane) memcpy(plane, ix->h_plane.data(), ix->h_plane.size() * 4);
+    if (left) memcpy(left, ix->h_left.data(), ix->h_left.size() * 4);
+    if (right) memcpy(right, ix->h_right.data(), ix->h_right.size() * 4);
+    if (roots) memcpy(roots, ix->h_roots.data(), ix->h_roots.size() * 4);
+    if (planes && ix->n_planes) HIPCHK(hipMemcpy(planes, ix->planes.p, (size_t)ix->n_planes * ix->opt.dim * 4, hipMemcpyDeviceToHost));
+    if (consts && ix->n_planes) HIPCHK(hipMemcpy(consts, ix->consts.p, (size_t)ix->n_planes * 4, hipMemcpyDeviceToHost));
+    if (leaf_ids && ix->n_leaf_ids) HIPCHK(hipMemcpy(leaf_ids, ix->leaf_ids.p, ix->n_leaf_ids * 4, hipMemcpyDeviceToHost));
+    return ZH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GPU forest build (build_index, lsh.rs:411-429 -> build_a_tree lsh.rs:250-267), level-synchronous
+// ------------------------------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// two distinct rows uniform over the whole database (lsh.rs:197-201), keyed by (seed, tree, heap path)
+static void sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint64_t n_rows, uint64_t *i, uint64_t *j) {
+    uint64_t h = splitmix64(seed ^ splitmix64(0x7EE5ull + tree) ^ splitmix64(path * 0xC2B2AE3D27D4EB4Full));
+    uint64_t h1 = splitmix64(h), h2 = splitmix64(h1);
+    if (n_rows < 2) { *i = 0; *j = 0; return; }
+    *i = h1 % n_rows;
+    *j = h2 % (n_rows - 1);
+    if (*j >= *i) (*j)++;
+}
+
+struct ActiveNode {
+    uint32_t node, tree, len;
+    uint64_t seg_start, path;
+};
+
+static int build_forest_locked(zh_index *ix) {
+    const uint64_t N = ix->n_rows;
+    const uint32_t T = ix->opt.num_trees, M = ix->opt.max_node_size, d = ix->opt.dim;
+    int rc;
+    hipStreamSynchronize(ix->stream);
+    free_forest(ix);
+    if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
+    hipStream_t s = ix->stream;
+    const uint64_t total = (uint64_t)T * N;
+    DevBuf perm, tmp, flags, dNodes, dChunks, dChunkAbove, dChunkScan, dScanTmp, dNodeAbove;
+    struct Guard {
+        std::vector<DevBuf *> v;
+        ~Guard() { for (auto *b : v) b->release(); }
+    } guard;
+    guard.v = {&tmp, &flags, &dNodes, &dChunks, &dChunkAbove, &dChunkScan, &dScanTmp, &dNodeAbove};
+    if ((rc = perm.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
+    if (total) {
+        if ((rc = tmp.ensure(total * 4))) { perm.release(); return rc; }
+        if ((rc = flags.ensure(total))) { perm.release(); return rc; }
+        hipError_t e = zh_launch_iota_perm(perm.as<uint32_t>(), N, T, s);
+        if (e != hipSuccess) { perm.release(); return fail(ZH_EHIP, "iota_perm: %s", hipGetErrorString(e)); }
+    }
+    std::vector<ActiveNode> active, next;
+    ix->planes_below_level.assign(1, 0);
+    auto new_node = [&]() { ix->h_plane.push_back(-1); ix->h_left.push_back(0); ix->h_right.push_back(0); return (uint32_t)(ix->h_plane.size() - 1); };
+    auto make_leaf = [&](uint32_t node, uint64_t start, uint32_t len) {
+        ix->h_plane[node] = -1; ix->h_left[node] = (int32_t)(uint32_t)start; ix->h_right[node] = (int32_t)len;
+    };
+    for (uint32_t t = 0; t < T; t++) {
+        uint32_t n = new_node();
+        ix->h_roots.push_back(n);
+        if (N < M) make_leaf(n, (uint64_t)t * N, (uint32_t)N);  // lsh.rs:251-252 (depth 0 < ZH_MAX_DEPTH)
+        else active.push_back({n, t, (uint32_t)N, (uint64_t)t * N, 1});
+    }
+    uint32_t n_planes = 0;
+    std::vector<ZhBuildNode> hn;
+    std::vector<ZhBuildChunk> hc;
+    std::vector<uint32_t> h_above;
+    auto cleanup_fail = [&](int code) { perm.release(); free_forest(ix); return code; };
+    for (uint32_t depth = 0; !active.empty(); depth++) {
+        hn.clear(); hc.clear();
+        for (size_t i = 0; i < active.size(); i++) {
+            const ActiveNode &a = active[i];
+            ZhBuildNode bn;
+            bn.seg_start = a.seg_start; bn.len = a.len; bn.plane = n_planes + (uint32_t)i;
+            uint64_t si, sj;
+            sample_pair(ix->opt.seed, a.tree, a.path, N, &si, &sj);
+            bn.sample_a = N >= 1 ? si : ~0ull;   // lsh.rs:203-220: a missing sample decodes to the zero vector
+            bn.sample_b = N >= 2 ? sj : ~0ull;
+            bn.first_chunk = (uint32_t)hc.size();
+            bn.n_chunks = (a.len + 255) / 256;
+            for (uint32_t c = 0; c < bn.n_chunks; c++) {
+                ZhBuildChunk ch;
+                ch.node = (uint32_t)i; ch.pos = a.seg_start + (uint64_t)c * 256;
+                ch.count = std::min<uint32_t>(256, a.len - c * 256);
+                hc.push_back(ch);
+            }
+            hn.push_back(bn);
+        }
+        const uint32_t na = (uint32_t)hn.size(), nc = (uint32_t)hc.size();
+        if ((rc = ix->planes.ensure((size_t)(n_planes + na) * d * 4, true, s))) return cleanup_fail(rc);
+        if ((rc = ix->consts.ensure((size_t)(n_planes + na) * 4, true, s))) return cleanup_fail(rc);
+        if ((rc = dNodes.ensure(na * sizeof(ZhBuildNode)))) return cleanup_fail(rc);
+        if ((rc = dChunks.ensure(nc * sizeof(ZhBuildChunk)))) return cleanup_fail(rc);
+        if ((rc = dChunkAbove.ensure((size_t)nc * 4))) return cleanup_fail(rc);
+        if ((rc = dChunkScan.ensure((size_t)(nc + 1) * 4))) return cleanup_fail(rc);
+        if ((rc = dScanTmp.ensure(((size_t)nc / 1024 + 4) * 4))) return cleanup_fail(rc);
+        if ((rc = dNodeAbove.ensure((size_t)na * 4))) return cleanup_fail(rc);
+        hipError_t e = hipMemcpyAsync(dNodes.p, hn.data(), na * sizeof(ZhBuildNode), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dChunks.p, hc.data(), nc * sizeof(ZhBuildChunk), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = zh_launch_make_planes(ix->X.as<float>(), d, dNodes.as<ZhBuildNode>(), na, ix->planes.as<float>(), ix->consts.as<float>(), s);
+        if (e == hipSuccess) e = zh_launch_classify(ix->X.as<float>(), d, perm.as<uint32_t>(), dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, ix->planes.as<float>(), ix->consts.as<float>(), flags.as<uint8_t>(), dChunkAbove.as<uint32_t>(), s);
+        if (e == hipSuccess) e = zh_launch_scan_u32(dChunkAbove.as<uint32_t>(), dChunkScan.as<uint32_t>(), nc, dScanTmp.as<uint32_t>(), s);
+        if (e == hipSuccess) e = zh_launch_scatter(perm.as<uint32_t>(), tmp.as<uint32_t>(), dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, flags.as<uint8_t>(), dChunkScan.as<uint32_t>(), dNodeAbove.as<uint32_t>(), s);
+        h_above.resize(na);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_above.data(), dNodeAbove.p, (size_t)na * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return cleanup_fail(fail(ZH_EHIP, "forest build level %u: %s", depth, hipGetErrorString(e)));
+        next.clear();
+        for (size_t i = 0; i < active.size(); i++) {
+            const ActiveNode &a = active[i];
+            uint32_t nA = h_above[i], nB = a.len - nA;
+            uint32_t l = new_node(), r = new_node();
+            ix->h_plane[a.node] = (int32_t)(n_planes + i);
+            ix->h_left[a.node] = (int32_t)l;   // below  (lsh.rs:262)
+            ix->h_right[a.node] = (int32_t)r;  // above  (lsh.rs:263)
+            bool child_can_split = depth + 1 < ZH_MAX_DEPTH;
+            if (nB >= M && child_can_split) next.push_back({l, a.tree, nB, a.seg_start, 2 * a.path});
+            else make_leaf(l, a.seg_start, nB);
+            if (nA >= M && child_can_split) next.push_back({r, a.tree, nA, a.seg_start + nB, 2 * a.path + 1});
+            else make_leaf(r, a.seg_start + nB, nA);
+        }
+        n_planes += na;
+        ix->planes_below_level.push_back(n_planes);
+        active.swap(next);
+    }
+    if (n_planes == 0) {
+        if ((rc = ix->planes.ensure(4 * d))) return cleanup_fail(rc);
+        if ((rc = ix->consts.ensure(4))) return cleanup_fail(rc);
+    }
+    ix->n_planes = n_planes;
+    ix->leaf_ids = perm;  // perm is the concatenation of all leaves
+    perm.p = nullptr; perm.cap = 0;
+    ix->n_leaf_ids = total;
+    rc = upload_nodes(ix);
+    if (rc) free_forest(ix);
+    return rc;
+}
+
+extern "C" int zh_index_build(zh_index *ix) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    if (ix->opt.max_node_size == 0) return fail(ZH_EINVAL, "max_node_size must be >= 1");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    return build_forest_locked(ix);
+}
+
+extern "C" int zh_index_add(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    if (ix->n_trees != 0 && ix->n_rows != 0)
+        return fail(ZH_EUNSUPPORTED, "zh_index_add on an index that already has trees (incremental insert, lsh.rs:350-382) "
+                                     "is not implemented yet: append and rebuild with zh_index_append + zh_index_build");
+    int rc = zh_index_append(ix, rows, n, out_ids);
+    if (rc) return rc;
+    return zh_index_build(ix);  // lsh.rs:441-443: no trees -> build_index
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+extern "C" int zh_set_profiling(zh_index *ix, int level) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (level > 0 && !ix->ev_ok) {
+        for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
+        ix->ev_ok = true;
+    }
+    ix->profiling = level;
+    return ZH_OK;
+}
+extern "C" int zh_set_dense_levels(zh_index *ix, int levels) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    ix->dense_levels = levels;
+    return ZH_OK;
+}
+extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
+    if (!ix || !out) return fail(ZH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *out = ix->stats;
+    return ZH_OK;
+}
+extern "C" int zh_stats_reset(zh_index *ix) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    memset(&ix->stats, 0, sizeof ix->stats);
+    return ZH_OK;
+}
+
+// number of leading planes hashed densely for a batch of B queries asking for k neighbours
+static uint32_t choose_dense_planes(const zh_index *ix, size_t B, size_t k) {
+    const auto &below = ix->planes_below_level;
+    if (below.size() <= 1 || ix->n_planes == 0) return 0;
+    if (ix->dense_levels >= 0) return below[std::min<size_t>((size_t)ix->dense_levels, below.size() - 1)];
+    // 1-leaf regime (leaves comfortably >= k): a pair evaluates ~depth planes, cheap on demand, so only the
+    // top levels -- shared by every query -- go to the MFMA kernel.  Small leaves (the reference's defaults,
+    // max_node_size 5 < top_k): the walk wanders over most of the forest, hash everything densely.
+    const bool exhaustive = (size_t)ix->opt.max_node_size < 2 * k + 2;
+    const double budget = exhaustive ? 4e11 : 2e9;  // flops
+    const double per_plane = 2.0 * (double)B * ix->opt.dim;
+    uint32_t best = 0;
+    for (size_t L = 1; L < below.size(); L++)
+        if ((double)below[L] * per_plane <= budget) best = below[L];
+    return best;
+}
+
+static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
+                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    const uint32_t d = ix->opt.dim, T = ix->n_trees;
+    int rc;
+    if (B == 0) return ZH_OK;
+    if (k == 0 || ix->n_rows == 0 || T == 0) {  // core.rs:295-297: empty index -> no neighbours
+        HIPCHK(hipMemsetAsync(dOutCounts, 0, B * 4, s));
+        if (k) {
+            HIPCHK(hipMemsetAsync(dOutIds, 0xFF, B * k * 8, s));
+            HIPCHK(hipMemsetAsync(dOutKeys, 0xFF, B * k * 8, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        return ZH_OK;
+    }
+    const uint64_t pairs = (uint64_t)B * T;
+    if (pairs > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "batch * num_trees too large");
+    const bool prof = ix->profiling > 0 && ix->ev_ok;
+    const uint32_t P_dense = choose_dense_planes(ix, B, k);
+    const uint32_t wpq = (P_dense + 63) / 64 * 2;
+    if ((rc = ix->wQQ.ensure(B * 4))) return rc;
+    if ((rc = ix->wBits.ensure(std::max<size_t>((size_t)B * wpq * 4, 4)))) return rc;
+    if ((rc = ix->wCounts.ensure(pairs * sizeof(ZhPairCounts)))) return rc;
+    if ((rc = ix->wInline.ensure(pairs * ZH_INLINE_VISITS * sizeof(ZhVisit)))) return rc;
+    if ((rc = ix->wRowBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = ix->wCandBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = ix->wVisitBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = ix->wTotals.ensure(sizeof(ZhTotals)))) return rc;
+    ZhForestDev f = forest_dev(ix);
+    if (prof) HIPCHK(hipEventRecord(ix->ev[0], s));
+    if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, ix->wQQ.as<float>(), s));
+    if (P_dense)
+        HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, P_dense, d, ix->wBits.as<uint32_t>(), wpq, nullptr, s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev[1], s));
+    HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
+                                ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), s));
+    HIPCHK(zh_launch_pair_scan(ix->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, ix->wRowBase.as<uint64_t>(),
+                               ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wTotals.as<ZhTotals>(), s));
+    HIPCHK(hipMemcpyAsync(ix->h_totals, ix->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const ZhTotals tot = *ix->h_totals;
+    if (tot.visits > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "more than 2^31 leaf visits in one batch; use a smaller batch");
+    if ((rc = ix->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
+    if ((rc = ix->wVisitRowOff.ensure(std::max<uint64_t>(tot.visits, 1) * 8))) return rc;
+    if ((rc = ix->wKeys.ensure(std::max<uint64_t>(tot.rows, 1) * 8))) return rc;
+    if ((rc = ix->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
+    if ((rc = ix->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
+    HIPCHK(zh_launch_walk_emit(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
+                               ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), ix->wRowBase.as<uint64_t>(),
+                               ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wVisits.as<ZhVisit>(),
+                               ix->wVisitRowOff.as<uint64_t>(), s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev[2], s));
+    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, dQ, ix->wQQ.as<float>(), ix->wVisits.as<ZhVisit>(),
+                           ix->wVisitRowOff.as<uint64_t>(), tot.visits, f.leaf_ids, tot.rows, metric, mode,
+                           ix->wKeys.as<uint64_t>(), s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev[3], s));
+    HIPCHK(zh_launch_select(ix->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, ix->wKeys.as<uint64_t>(),
+                            ix->wCandKeys.as<uint64_t>(), ix->wCandIds.as<uint32_t>(), s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev[4], s));
+    HIPCHK(zh_launch_final(ix->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, ix->wCandKeys.as<uint64_t>(),
+                           ix->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev[5], s));
+    HIPCHK(hipStreamSynchronize(s));
+    zh_stats_t &st = ix->stats;
+    st.batch = B; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
+    st.planes_dense = P_dense; st.planes_total = ix->n_planes;
+    st.sweep_bytes = tot.rows * ((uint64_t)4 * d + 4 + 8);
+    if (prof) {
+        float ms[5];
+        for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]));
+        st.ms_hash += ms[0]; st.ms_walk += ms[1]; st.ms_sweep += ms[2]; st.ms_select += ms[3]; st.ms_final += ms[4];
+        st.ms_total += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+        st.timed_batches++;
+        st.sweep_rows_accum += tot.rows;
+    }
+    if (ix->profiling >= 2 && tot.visits) {  // R_unique: rows of the distinct leaves touched by the batch
+        std::vector<ZhVisit> hv(tot.visits);
+        HIPCHK(hipMemcpy(hv.data(), ix->wVisits.p, tot.visits * sizeof(ZhVisit), hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint32_t, uint32_t>> leaves(hv.size());
+        for (size_t i = 0; i < hv.size(); i++) leaves[i] = {hv[i].leaf_off, hv[i].len};
+        std::sort(leaves.begin(), leaves.end());
+        leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
+        uint64_t u = 0;
+        for (auto &l : leaves) u += l.second;
+        st.rows_unique = u;
+    }
+    return ZH_OK;
+}
+
+static int check_metric(int metric, int mode) {
+    if (metric != ZH_COSINE && metric != ZH_L2SQ && metric != ZH_L2) return fail(ZH_EINVAL, "unknown metric %d", metric);
+    if (mode != ZH_COSINE_PARITY && mode != ZH_COSINE_CORRECTED) return fail(ZH_EINVAL, "unknown cosine mode %d", mode);
+    return ZH_OK;
+}
+
+extern "C" int zh_search_batch_device(zh_index *ix, const float *d_q, size_t b, size_t k, int metric, int mode,
+                                      uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream) {
+    if (!ix || (b && (!d_q || !d_out_counts || (k && (!d_out_ids || !d_out_keys))))) return fail(ZH_EINVAL, "zh_search_batch_device: null argument");
+    if (k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k %zu > ZH_MAX_TOPK (%u)", k, ZH_MAX_TOPK);
+    int rc = check_metric(metric, mode);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if ((rc = set_device(ix))) return rc;
+    return search_locked(ix, d_q, b, k, metric, mode, d_out_ids, d_out_keys, d_out_counts,
+                         stream ? (hipStream_t)stream : ix->stream);
+}
+
+extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k, int metric, int mode,
+                               uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts) {
+    if (!ix || (b && (!q || !out_counts || (k && (!out_ids || !out_keys))))) return fail(ZH_EINVAL, "zh_search_batch: null argument");
+    if (k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k %zu > ZH_MAX_TOPK (%u)", k, ZH_MAX_TOPK);
+    int rc = check_metric(metric, mode);
+    if (rc) return rc;
+    if (b == 0) return ZH_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if ((rc = set_device(ix))) return rc;
+    hipStream_t s = ix->stream;
+    const uint32_t d = ix->opt.dim;
+    if ((rc = ix->wQ.ensure(b * d * 4))) return rc;
+    if ((rc = ix->wOutIds.ensure(std::max<size_t>(b * k, 1) * 8))) return rc;
+    if ((rc = ix->wOutKeys.ensure(std::max<size_t>(b * k, 1) * 8))) return rc;
+    if ((rc = ix->wOutCounts.ensure(b * 4))) return rc;
+    HIPCHK(hipMemcpyAsync(ix->wQ.p, q, b * d * 4, hipMemcpyHostToDevice, s));
+    rc = search_locked(ix, ix->wQ.as<float>(), b, k, metric, mode, ix->wOutIds.as<uint64_t>(),
+                       ix->wOutKeys.as<uint64_t>(), ix->wOutCounts.as<uint32_t>(), s);
+    if (rc) return rc;
+    if (k) {
+        HIPCHK(hipMemcpyAsync(out_ids, ix->wOutIds.p, b * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out_keys, ix->wOutKeys.p, b * k * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipMemcpyAsync(out_counts, ix->wOutCounts.p, b * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ZH_OK;
+}
+
+extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *out_bits, float *out_dots) {
+    if (!ix || (b && (!q || !out_bits))) return fail(ZH_EINVAL, "zh_hash_signs: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    const uint32_t P = ix->n_planes, d = ix->opt.dim;
+    if (!b || !P) return ZH_OK;
+    hipStream_t s = ix->stream;
+    const uint32_t wpq = (P + 63) / 64 * 2, words = (P + 31) / 32;
+    DevBuf dq, dbits, ddots;
+    struct G { DevBuf *a, *b, *c; ~G() { a->release(); b->release(); c->release(); } } g{&dq, &dbits, &ddots};
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(b, (size_t)(256u << 20) / ((size_t)P * 4 + 1)));
+    if ((rc = dq.ensure(chunk * d * 4))) return rc;
+    if ((rc = dbits.ensure(chunk * wpq * 4))) return rc;
+    if (out_dots && (rc = ddots.ensure(chunk * P * 4))) return rc;
+    std::vector<uint32_t> hb(chunk * wpq);
+    for (size_t b0 = 0; b0 < b; b0 += chunk) {
+        size_t nb = std::min(chunk, b - b0);
+        HIPCHK(hipMemcpyAsync(dq.p, q + b0 * d, nb * d * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(zh_launch_hash_dense(dq.as<float>(), (uint32_t)nb, ix->planes.as<float>(), ix->consts.as<float>(), P, d,
+                                    dbits.as<uint32_t>(), wpq, out_dots ? ddots.as<float>() : nullptr, s));
+        HIPCHK(hipMemcpyAsync(hb.data(), dbits.p, nb * wpq * 4, hipMemcpyDeviceToHost, s));
+        if (out_dots) HIPCHK(hipMemcpyAsync(out_dots + b0 * P, ddots.p, nb * P * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < nb; i++) {
+            memcpy(out_bits + (b0 + i) * words, &hb[i * wpq], words * 4);
+            if (P & 31) out_bits[(b0 + i) * words + words - 1] &= (1u << (P & 31)) - 1;
+        }
+    }
+    return ZH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone metric calls (src/distance.rs), multi-GPU merge, synthetic queries
+// ------------------------------------------------------------------------------------------------
+static int pick_device(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(ZH_EHIP, "no usable HIP device; this library has no CPU fallback");
+    if (device >= ndev) return fail(ZH_EINVAL, "device %d out of range", device);
+    if (device >= 0) { e = hipSetDevice(device); if (e != hipSuccess) return fail(ZH_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+    return ZH_OK;
+}
+
+extern "C" int zh_distance_batch(int metric, int mode, const float *a, const float *q, size_t n, size_t dim,
+                                 uint64_t *out_keys, int device) {
+    if ((n && (!a || !out_keys)) || !q || !dim) return fail(ZH_EINVAL, "zh_distance_batch: null argument");
+    if (n > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "zh_distance_batch: n > 2^32-1");
+    int rc = check_metric(metric, mode);
+    if (rc) return rc;
+    if ((rc = pick_device(device))) return rc;
+    if (!n) return ZH_OK;
+    DevBuf da, dq, dk;
+    struct G { DevBuf *a, *b, *c; ~G() { a->release(); b->release(); c->release(); } } g{&da, &dq, &dk};
+    if ((rc = da.ensure(n * dim * 4))) return rc;
+    if ((rc = dq.ensure(dim * 4))) return rc;
+    if ((rc = dk.ensure(n * 8))) return rc;
+    HIPCHK(hipMemcpy(da.p, a, n * dim * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dq.p, q, dim * 4, hipMemcpyHostToDevice));
+    HIPCHK(zh_launch_distance_rows(da.as<float>(), n, (uint32_t)dim, dq.as<float>(), metric, mode, dk.as<uint64_t>(), nullptr));
+    HIPCHK(hipMemcpy(out_keys, dk.p, n * 8, hipMemcpyDeviceToHost));
+    return ZH_OK;
+}
+
+extern "C" int zh_distance_pair(int metric, int mode, const float *a, const float *b, size_t dim, uint64_t *out_key, int device) {
+    return zh_distance_batch(metric, mode, a, b, 1, dim, out_key, device);
+}
+
+extern "C" int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_ids,
+                                    const uint64_t *d_keys, const uint32_t *d_counts, uint64_t *d_out_ids,
+                                    uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream) {
+    if (b && (!d_ids || !d_keys || !d_counts || !d_out_ids || !d_out_keys || !d_out_counts)) return fail(ZH_EINVAL, "zh_merge_topk_device: null argument");
+    if (k == 0 || k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k must be in 1..%u", ZH_MAX_TOPK);
+    if (n_shards == 0 || n_shards > 1024) return fail(ZH_EINVAL, "n_shards must be in 1..1024");
+    int rc = pick_device(device);
+    if (rc) return rc;
+    HIPCHK(zh_launch_merge(n_shards, (uint32_t)b, (uint32_t)k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return ZH_OK;
+}
+
+extern "C" int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,
+                                       uint64_t b0, size_t b, uint32_t dim, int kind, void *stream) {
+    if (b && !d_out) return fail(ZH_EINVAL, "null output");
+    if (!n_rows) return fail(ZH_EINVAL, "n_rows must be > 0");
+    int rc = pick_device(device);
+    if (rc) return rc;
+    HIPCHK(zh_launch_synth_queries(d_out, seed_rows, seed_q, n_rows, b0, b, dim, kind, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return ZH_OK;
+}

@@ -1,0 +1,290 @@
+// zh_build.hip -- gfx950 kernels of the insert path: level-synchronous forest build
+// (LSHIndex::build_hyperplane / build_a_tree, /root/reference/src/database/index/lsh.rs:192-267)
+// and the counter-based synthetic data generators used by the bench and the parity tests.
+//
+// Every node's id list is a contiguous segment of perm[tree]; a level splits all of its active
+// segments at once: make_planes (one hyperplane per node from two sampled rows) -> classify
+// (point_is_above for every member, the hash's sequential fma chain) -> stable partition
+// (below | above) by a scan over per-chunk counts.  Leaves end up as contiguous runs of perm,
+// which is then used directly as leaf_ids.
+#include "zh_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// synthetic data: Irwin-Hall(4) of four 16-bit fields of splitmix64 -- integer arithmetic plus one
+// exact int->float conversion and one f32 multiply, bit-identical to oracle zo_synth_rows.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t zh_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ int32_t synth_centered(uint64_t seed, uint64_t idx) {
+    uint64_t z = zh_splitmix64(seed ^ (idx * 0xD1342543DE82EF95ull));
+    uint32_t s = (uint32_t)(z & 0xFFFF) + (uint32_t)((z >> 16) & 0xFFFF) + (uint32_t)((z >> 32) & 0xFFFF) +
+                 (uint32_t)(z >> 48);
+    return (int32_t)s - 131070;
+}
+__device__ __forceinline__ float synth_value(uint64_t seed, uint64_t idx, int kind) {
+    int32_t t = synth_centered(seed, idx);
+    if (kind == 1) {
+        int32_t v = 30 + (t * 35) / 37837;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        return (float)v;
+    }
+    return (float)t * (1.0f / 37837.2f);
+}
+
+__global__ __launch_bounds__(256) void synth_rows_kernel(float *__restrict__ X, uint64_t n_elems, uint32_t d,
+                                                          uint64_t seed, uint64_t row0, int kind) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_elems; i += stride) X[i] = synth_value(seed, row0 * d + i, kind);
+}
+
+hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
+                                hipStream_t s) {
+    uint64_t n_elems = n * d;
+    if (!n_elems) return hipSuccess;
+    uint64_t blocks = (n_elems + 255) / 256;
+    if (blocks > 65536 * 8) blocks = 65536 * 8;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, n_elems, d, seed, row0, kind);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void synth_queries_kernel(float *__restrict__ out, uint64_t seed_rows,
+                                                             uint64_t seed_q, uint64_t n_rows, uint64_t b0,
+                                                             uint64_t b, uint32_t d, int kind) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * d) return;
+    uint64_t q = b0 + i / d;
+    uint32_t c = (uint32_t)(i % d);
+    uint64_t r = zh_splitmix64(seed_q ^ (q * 0xA24BAED4963EE407ull)) % n_rows;
+    float x = synth_value(seed_rows, r * d + c, kind);
+    float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, q * d + c) * (1.0f / 37837.2f);
+    out[i] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : __builtin_fmaf(0.3f, g, x);
+}
+
+hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,
+                                   uint64_t b, uint32_t d, int kind, hipStream_t s) {
+    uint64_t n = b * d;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(synth_queries_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dOut, seed_rows,
+                       seed_q, n_rows, b0, b, d, kind);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// build
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iota_perm_kernel(uint32_t *__restrict__ perm, uint64_t N, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) perm[i] = (uint32_t)(i % N);
+}
+hipError_t zh_launch_iota_perm(uint32_t *dPerm, uint64_t N, uint32_t T, hipStream_t s) {
+    uint64_t total = N * T;
+    if (!total) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 65536 * 8) blocks = 65536 * 8;
+    hipLaunchKernelGGL(iota_perm_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dPerm, N, total);
+    return hipGetLastError();
+}
+
+// lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 (sequential fma chain)
+__global__ __launch_bounds__(256) void make_planes_kernel(const float *__restrict__ X, uint32_t d,
+                                                           const ZhBuildNode *__restrict__ nodes,
+                                                           float *__restrict__ planes, float *__restrict__ consts) {
+    extern __shared__ float sm[];  // w[d], p[d]
+    float *w = sm, *p = sm + d;
+    const ZhBuildNode nd = nodes[blockIdx.x];
+    const float *a = nd.sample_a == ~0ull ? nullptr : X + (size_t)nd.sample_a * d;
+    const float *b = nd.sample_b == ~0ull ? nullptr : X + (size_t)nd.sample_b * d;
+    for (uint32_t k = threadIdx.x; k < d; k += blockDim.x) {
+        float av = a ? a[k] : 0.0f, bv = b ? b[k] : 0.0f;
+        float wk = bv - av;
+        w[k] = wk;
+        p[k] = (av + bv) / 2.0f;
+        planes[(size_t)nd.plane * d + k] = wk;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < d; k++) acc = __builtin_fmaf(w[k], p[k], acc);
+        consts[nd.plane] = -acc;
+    }
+}
+hipError_t zh_launch_make_planes(const float *dX, uint32_t d, const ZhBuildNode *dNodes, uint32_t n_nodes,
+                                 float *dPlanes, float *dConsts, hipStream_t s) {
+    if (!n_nodes) return hipSuccess;
+    hipLaunchKernelGGL(make_planes_kernel, dim3(n_nodes), dim3(256), 2 * d * sizeof(float), s, dX, d, dNodes,
+                       dPlanes, dConsts);
+    return hipGetLastError();
+}
+
+// classify one chunk (<= 256 consecutive members of one node): thread i owns member i and runs the
+// hash's sequential chain over its row.  The plane is block-uniform (served by broadcast loads).
+__global__ __launch_bounds__(256) void classify_kernel(const float *__restrict__ X, uint32_t d,
+                                                        const uint32_t *__restrict__ perm,
+                                                        const ZhBuildNode *__restrict__ nodes,
+                                                        const ZhBuildChunk *__restrict__ chunks,
+                                                        const float *__restrict__ planes,
+                                                        const float *__restrict__ consts,
+                                                        uint8_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ chunk_above) {
+    __shared__ uint32_t wsum[4];
+    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const uint32_t plane = nodes[ch.node].plane;
+    const float *__restrict__ w = planes + (size_t)plane * d;
+    const float c = consts[plane];
+    const uint32_t tid = threadIdx.x;
+    bool above = false;
+    if (tid < ch.count) {
+        uint32_t id = perm[ch.pos + tid];
+        const float *__restrict__ x = X + (size_t)id * d;
+        float acc = 0.0f;
+        if ((d & 3u) == 0) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(x);
+            const float4 *w4 = reinterpret_cast<const float4 *>(w);
+            for (uint32_t k = 0; k < d / 4; k++) {
+                float4 xv = x4[k], wv = w4[k];
+                acc = __builtin_fmaf(wv.x, xv.x, acc);
+                acc = __builtin_fmaf(wv.y, xv.y, acc);
+                acc = __builtin_fmaf(wv.z, xv.z, acc);
+                acc = __builtin_fmaf(wv.w, xv.w, acc);
+            }
+        } else {
+            for (uint32_t k = 0; k < d; k++) acc = __builtin_fmaf(w[k], x[k], acc);
+        }
+        above = ((double)acc + (double)c) >= 0.0;  // lsh.rs:40-42
+        flags[ch.pos + tid] = above ? 1 : 0;
+    }
+    unsigned long long m = __ballot(above);
+    if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (tid == 0) chunk_above[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+hipError_t zh_launch_classify(const float *dX, uint32_t d, const uint32_t *dPerm, const ZhBuildNode *dNodes,
+                              const ZhBuildChunk *dChunks, uint32_t n_chunks, const float *dPlanes,
+                              const float *dConsts, uint8_t *dFlags, uint32_t *dChunkAbove, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(classify_kernel, dim3(n_chunks), dim3(256), 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes,
+                       dConsts, dFlags, dChunkAbove);
+    return hipGetLastError();
+}
+
+// ---- exclusive scan of n u32 into n+1 entries (out[n] = total) ----------------------------------
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t *__restrict__ in, uint64_t n,
+                                                               uint32_t *__restrict__ sums) {
+    __shared__ uint32_t sm[256];
+    uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v = 0;
+    for (int j = 0; j < 4; j++)
+        if (base + j < n) v += in[base + j];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = sm[0];
+}
+// in-place exclusive scan of m values by one block
+__global__ __launch_bounds__(1024) void scan_single_kernel(uint32_t *__restrict__ a, uint64_t m) {
+    __shared__ uint32_t sm[1024];
+    const uint32_t tid = threadIdx.x;
+    uint64_t per = (m + 1023) / 1024, lo = tid * per, hi = lo + per < m ? lo + per : m;
+    uint32_t s = 0;
+    for (uint64_t i = lo; i < hi; i++) s += a[i];
+    sm[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t x = tid >= off ? sm[tid - off] : 0;
+        __syncthreads();
+        sm[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = sm[tid] - s;
+    for (uint64_t i = lo; i < hi; i++) { uint32_t v = a[i]; a[i] = run; run += v; }
+    if (tid == 1023) a[m] = sm[1023];
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ in, uint64_t n,
+                                                          const uint32_t *__restrict__ block_excl,
+                                                          uint32_t *__restrict__ out) {
+    __shared__ uint32_t sm[256];
+    uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t x = threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t run = block_excl[blockIdx.x] + sm[threadIdx.x] - s;
+    for (int j = 0; j < 4; j++)
+        if (base + j < n) { out[base + j] = run; run += v[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = block_excl[gridDim.x];
+}
+hipError_t zh_launch_scan_u32(const uint32_t *dIn, uint32_t *dOut, uint64_t n, uint32_t *dTmp, hipStream_t s) {
+    if (!n) return hipMemsetAsync(dOut, 0, sizeof(uint32_t), s);
+    uint32_t nb = (uint32_t)((n + 1023) / 1024);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, s, dIn, n, dTmp);
+    hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(1024), 0, s, dTmp, (uint64_t)nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, dIn, n, dTmp, dOut);
+    return hipGetLastError();
+}
+
+// stable partition of every active segment: below | above; perm_out receives the new order for the
+// positions of active segments only (copied back by copyback_kernel)
+__global__ __launch_bounds__(256) void scatter_kernel(const uint32_t *__restrict__ perm_in,
+                                                       uint32_t *__restrict__ perm_out,
+                                                       const ZhBuildNode *__restrict__ nodes,
+                                                       const ZhBuildChunk *__restrict__ chunks,
+                                                       const uint8_t *__restrict__ flags,
+                                                       const uint32_t *__restrict__ chunk_scan,
+                                                       uint32_t *__restrict__ node_above) {
+    __shared__ uint32_t sm[256];
+    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const ZhBuildNode nd = nodes[ch.node];
+    const uint32_t tid = threadIdx.x;
+    uint32_t f = 0, id = 0;
+    if (tid < ch.count) { f = flags[ch.pos + tid]; id = perm_in[ch.pos + tid]; }
+    sm[tid] = f;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t x = tid >= off ? sm[tid - off] : 0;
+        __syncthreads();
+        sm[tid] += x;
+        __syncthreads();
+    }
+    const uint32_t local_above = sm[tid] - f;  // exclusive
+    const uint32_t base_scan = chunk_scan[nd.first_chunk];
+    const uint32_t above_before = chunk_scan[blockIdx.x] - base_scan;
+    const uint32_t n_above = chunk_scan[nd.first_chunk + nd.n_chunks] - base_scan;
+    const uint32_t n_below = nd.len - n_above;
+    if (tid < ch.count) {
+        uint32_t pos_in_node = (uint32_t)(ch.pos - nd.seg_start) + tid;
+        uint32_t a_excl = above_before + local_above;
+        uint64_t dest = f ? nd.seg_start + n_below + a_excl : nd.seg_start + (pos_in_node - a_excl);
+        perm_out[dest] = id;
+    }
+    if (blockIdx.x == nd.first_chunk && tid == 0) node_above[ch.node] = n_above;
+}
+__global__ __launch_bounds__(256) void copyback_kernel(uint32_t *__restrict__ perm, const uint32_t *__restrict__ tmp,
+                                                        const ZhBuildChunk *__restrict__ chunks) {
+    const ZhBuildChunk ch = chunks[blockIdx.x];
+    if (threadIdx.x < ch.count) perm[ch.pos + threadIdx.x] = tmp[ch.pos + threadIdx.x];
+}
+hipError_t zh_launch_scatter(const uint32_t *dPermIn, uint32_t *dPermOut, const ZhBuildNode *dNodes,
+                             const ZhBuildChunk *dChunks, uint32_t n_chunks, const uint8_t *dFlags,
+                             const uint32_t *dChunkScan, uint32_t *dNodeAbove, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(scatter_kernel, dim3(n_chunks), dim3(256), 0, s, dPermIn, dPermOut, dNodes, dChunks, dFlags,
+                       dChunkScan, dNodeAbove);
+    hipLaunchKernelGGL(copyback_kernel, dim3(n_chunks), dim3(256), 0, s, const_cast<uint32_t *>(dPermIn), dPermOut,
+                       dChunks);
+    return hipGetLastError();
+}

@@ -1,0 +1,99 @@
+// zh_internal.h -- shared declarations between the kernel translation units and the C ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/zebra_hip.h"
+
+// ---- one leaf visit of the walk (tree_result, lsh.rs:290-348): score `len` rows of a leaf for
+// query `b`, keep the `take` smallest.  row_off / cand_off are the visit's slices of the key
+// scratch and of the candidate pool.
+struct ZhVisit {
+    uint32_t b;
+    uint32_t leaf_off;  // offset into leaf_ids
+    uint32_t len;
+    uint32_t take;      // min(n, len)
+    uint64_t row_off;
+    uint64_t cand_off;
+};
+
+// per (query, tree) pair counts produced by the walk's first pass, then their exclusive scans
+struct ZhPairCounts {
+    uint32_t visits, rows, takes, pad;
+};
+struct ZhTotals {
+    uint64_t visits, rows, takes, flags;
+};
+
+struct ZhForestDev {
+    const int32_t *node_plane, *node_left, *node_right;
+    const uint32_t *roots;
+    const float *planes, *consts;
+    const uint32_t *leaf_ids;
+    uint32_t n_nodes, n_planes, n_trees;
+};
+
+#define ZH_SORT_N 4096        // entries of the LDS sort buffer of the select / final kernels
+#define ZH_INLINE_VISITS 2    // visits a pair may record in the walk's first pass
+
+// ---- launchers (zh_search.hip) ---------------------------------------------------------------
+hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlanes, const float *dConsts,
+                                uint32_t P, uint32_t d, uint32_t *dBits, uint32_t words_per_q, float *dDots,
+                                hipStream_t s);
+hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, hipStream_t s);
+hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
+                                const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
+                                ZhVisit *dInline, hipStream_t s);
+// exclusive scans over the pairs; the three base arrays have n_pairs + 1 entries
+hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, uint64_t *dRowBase,
+                               uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, hipStream_t s);
+hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
+                               const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense,
+                               const ZhPairCounts *dCounts, const ZhVisit *dInline, const uint64_t *dRowBase,
+                               const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits,
+                               uint64_t *dVisitRowOff, hipStream_t s);
+hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhVisit *dVisits,
+                           const uint64_t *dVisitRowOff, uint64_t n_visits, const uint32_t *dLeafIds,
+                           uint64_t R_total, int metric, int mode, uint64_t *dKeys, hipStream_t s);
+hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
+                            const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s);
+hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,
+                           const uint32_t *dCandIds, uint64_t id_base, uint64_t *dOutIds, uint64_t *dOutKeys,
+                           uint32_t *dOutCounts, hipStream_t s);
+hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *dIds, const uint64_t *dKeys,
+                           const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
+                           hipStream_t s);
+// plain distance of n contiguous rows against one query (zh_distance_batch)
+hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
+                                   uint64_t *dKeys, hipStream_t s);
+
+// ---- launchers (zh_build.hip) ----------------------------------------------------------------
+struct ZhBuildNode {   // an active (to be split) node of the current level
+    uint64_t seg_start;  // global position in perm (tree * N + offset)
+    uint32_t len;
+    uint32_t plane;      // plane index this node's hyperplane is written to
+    uint64_t sample_a, sample_b;  // row numbers; UINT64_MAX = the all-zero default vector
+    uint32_t first_chunk, n_chunks;
+};
+struct ZhBuildChunk {
+    uint32_t node;       // index into the level's ZhBuildNode array
+    uint32_t count;      // <= 256
+    uint64_t pos;        // global position of the chunk's first row in perm
+};
+
+hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
+                                hipStream_t s);
+hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,
+                                   uint64_t b, uint32_t d, int kind, hipStream_t s);
+hipError_t zh_launch_iota_perm(uint32_t *dPerm, uint64_t N, uint32_t T, hipStream_t s);
+hipError_t zh_launch_make_planes(const float *dX, uint32_t d, const ZhBuildNode *dNodes, uint32_t n_nodes,
+                                 float *dPlanes, float *dConsts, hipStream_t s);
+hipError_t zh_launch_classify(const float *dX, uint32_t d, const uint32_t *dPerm, const ZhBuildNode *dNodes,
+                              const ZhBuildChunk *dChunks, uint32_t n_chunks, const float *dPlanes,
+                              const float *dConsts, uint8_t *dFlags, uint32_t *dChunkAbove, hipStream_t s);
+hipError_t zh_launch_scan_u32(const uint32_t *dIn, uint32_t *dOut /* n+1 */, uint64_t n, uint32_t *dTmp /* >= n/1024+2 */,
+                              hipStream_t s);
+hipError_t zh_launch_scatter(const uint32_t *dPermIn, uint32_t *dPermOut, const ZhBuildNode *dNodes,
+                             const ZhBuildChunk *dChunks, uint32_t n_chunks, const uint8_t *dFlags,
+                             const uint32_t *dChunkScan, uint32_t *dNodeAbove, hipStream_t s);

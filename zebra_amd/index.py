@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's metric / index / database interface for the hot path.
+
+Names, argument meaning and error behaviour follow the reference (file:line in each docstring);
+all arithmetic happens in libzebra_hip.so on the GPU."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, d=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if d is not None and (a.ndim != 2 or a.shape[1] != d):
+        raise ValueError(f"expected an (n, {d}) float32 array, got {a.shape}")
+    return a
+
+
+# ---------------------------------------------------------------------------- src/distance.rs
+class _Metric:
+    """space::Metric<Embedding<N>> with Unit = u64 (src/distance.rs:19-21)."""
+    metric = None
+    mode = _ffi.COSINE_PARITY
+
+    def __init__(self, device=-1):
+        self.device = device
+
+    def distance(self, a, b):
+        """Metric::distance(a, b) -> DistanceUnit: the f64 bit pattern as u64."""
+        a, b = _f32(a).ravel(), _f32(b).ravel()
+        if a.size != b.size:
+            raise ValueError("vectors differ in length")
+        out = C.c_uint64()
+        check(lib().zh_distance_pair(self.metric, self.mode, _p(a), _p(b), a.size, C.byref(out), self.device))
+        return int(out.value)
+
+    def distance_batch(self, rows, query):
+        rows, query = _f32(rows), _f32(query).ravel()
+        out = np.empty(rows.shape[0], np.uint64)
+        check(lib().zh_distance_batch(self.metric, self.mode, _p(rows), _p(query), rows.shape[0], rows.shape[1],
+                                      _p(out), self.device))
+        return out
+
+
+class CosineDistance(_Metric):
+    """src/distance.rs:15-32.  `parity=True` (default) keeps the reference's literal key
+    bits(1.0 - simsimd_cosine) = bits of the SIMILARITY; `parity=False` keys on the distance."""
+    metric = _ffi.COSINE
+
+    def __init__(self, parity=True, device=-1):
+        super().__init__(device)
+        self.mode = _ffi.COSINE_PARITY if parity else _ffi.COSINE_CORRECTED
+
+
+class L2SquaredDistance(_Metric):
+    """src/distance.rs:34-49"""
+    metric = _ffi.L2SQ
+
+
+class L2Distance(_Metric):
+    """src/distance.rs:99-114"""
+    metric = _ffi.L2
+
+
+# ------------------------------------------------------------------- src/database/index/lsh.rs
+@dataclass
+class LSHIndexOptions:
+    """lsh.rs:122-139; defaults max_node_size = 5, num_trees = 15."""
+    max_node_size: int = 5
+    num_trees: int = 15
+
+
+class LSHIndex:
+    """LSHIndex<N> (lsh.rs:144-565) for the hot path: new / add / search / is_empty / no_vectors /
+    no_trees / clear, plus search_batch (the loop of core.rs:299-303 as one call)."""
+
+    def __init__(self, dim, options=None, seed=0x5EB2A003, device=-1, id_base=0, reserve_rows=0):
+        options = options or LSHIndexOptions()
+        o = _ffi.Options()
+        lib().zh_options_default(C.byref(o))
+        o.dim, o.max_node_size, o.num_trees = dim, options.max_node_size, options.num_trees
+        o.seed, o.device, o.id_base, o.reserve_rows = seed, device, id_base, reserve_rows
+        self._h = C.c_void_p()
+        check(lib().zh_index_create(C.byref(o), C.byref(self._h)))
+        self.dim, self.options, self.id_base = dim, options, id_base
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zh_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # lsh.rs:389-409
+    def no_vectors(self):
+        return lib().zh_index_count(self._h) == 0
+
+    def no_trees(self):
+        return lib().zh_index_num_trees(self._h) == 0
+
+    def is_empty(self):
+        return self.no_vectors() or self.no_trees()
+
+    def __len__(self):
+        return int(lib().zh_index_count(self._h))
+
+    def add(self, embeddings):
+        """lsh.rs:440-466: returns the ids of the added vectors (dense row ids, not Uuids)."""
+        e = _f32(embeddings, self.dim)
+        ids = np.empty(e.shape[0], np.uint64)
+        check(lib().zh_index_add(self._h, _p(e), e.shape[0], _p(ids)))
+        return ids
+
+    def append(self, embeddings):
+        e = _f32(embeddings, self.dim)
+        ids = np.empty(e.shape[0], np.uint64)
+        check(lib().zh_index_append(self._h, _p(e), e.shape[0], _p(ids)))
+        return ids
+
+    def append_synthetic(self, n, seed=0x5EB2A001, first_row=0, kind=0):
+        check(lib().zh_index_append_synthetic(self._h, n, seed, first_row, kind))
+
+    def build(self):
+        check(lib().zh_index_build(self._h))
+
+    def clear(self):
+        check(lib().zh_index_clear(self._h))
+
+    def set_forest(self, arrays):
+        a = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        keep = [a["plane"].astype(np.int32), a["left"].astype(np.int32), a["right"].astype(np.int32),
+                a["roots"].astype(np.uint32), _f32(a["planes"]).reshape(-1, self.dim), _f32(a["consts"]),
+                a["leaf_ids"].astype(np.uint32)]
+        fv = _ffi.ForestView(keep[0].size, keep[5].size, keep[3].size, keep[6].size, *[_p(x).value for x in keep])
+        check(lib().zh_index_set_forest(self._h, C.byref(fv)))
+
+    def get_forest(self):
+        s = _ffi.ForestSizes()
+        check(lib().zh_index_forest_sizes(self._h, C.byref(s)))
+        out = dict(plane=np.empty(s.n_nodes, np.int32), left=np.empty(s.n_nodes, np.int32),
+                   right=np.empty(s.n_nodes, np.int32), roots=np.empty(s.n_trees, np.uint32),
+                   planes=np.empty((s.n_planes, self.dim), np.float32), consts=np.empty(s.n_planes, np.float32),
+                   leaf_ids=np.empty(s.n_leaf_ids, np.uint32))
+        check(lib().zh_index_get_forest(self._h, *[_p(out[k]) for k in
+                                                  ("plane", "left", "right", "roots", "planes", "consts", "leaf_ids")]))
+        return out
+
+    def hash_signs(self, queries, dots=False):
+        """point_is_above (lsh.rs:39-43) of every plane for every query -> bool array [b, n_planes]."""
+        q = _f32(queries, self.dim)
+        s = _ffi.ForestSizes()
+        check(lib().zh_index_forest_sizes(self._h, C.byref(s)))
+        words = (s.n_planes + 31) // 32
+        bits = np.zeros((q.shape[0], max(words, 1)), np.uint32)
+        dd = np.zeros((q.shape[0], s.n_planes), np.float32) if dots else None
+        check(lib().zh_hash_signs(self._h, _p(q), q.shape[0], _p(bits), _p(dd) if dots else None))
+        signs = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :s.n_planes].astype(bool)
+        return (signs, dd) if dots else signs
+
+    def search_batch(self, queries, top_k, metric):
+        """LSHIndex::search for every query: (ids [b,k] u64, keys [b,k] u64, counts [b] u32);
+        entries past counts[i] are 2^64-1."""
+        q = _f32(queries, self.dim)
+        b = q.shape[0]
+        ids = np.empty((b, top_k), np.uint64)
+        keys = np.empty((b, top_k), np.uint64)
+        counts = np.zeros(b, np.uint32)
+        check(lib().zh_search_batch(self._h, _p(q), b, top_k, metric.metric, metric.mode, _p(ids), _p(keys), _p(counts)))
+        return ids, keys, counts
+
+    def search(self, query, top_k, metric):
+        """lsh.rs:544-565 -> list of (id, distance key), ascending."""
+        ids, keys, counts = self.search_batch(_f32(query).reshape(1, -1), top_k, metric)
+        n = int(counts[0])
+        return list(zip(ids[0, :n].tolist(), keys[0, :n].tolist()))
+
+    def search_batch_device(self, d_q_ptr, b, top_k, metric, d_ids_ptr, d_keys_ptr, d_counts_ptr, stream=None):
+        """Queries and results already in device memory (raw pointers, e.g. torch .data_ptr())."""
+        check(lib().zh_search_batch_device(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode, d_ids_ptr,
+                                           d_keys_ptr, d_counts_ptr, stream))
+
+    def read_rows(self, first, n):
+        """KeyValue::embedding (lsh.rs:107-119) for a run of rows."""
+        out = np.empty((n, self.dim), np.float32)
+        check(lib().zh_index_read_rows(self._h, first, n, _p(out)))
+        return out
+
+    def rows_device_ptr(self):
+        return lib().zh_index_rows_device(self._h)
+
+    def set_profiling(self, level):
+        check(lib().zh_set_profiling(self._h, level))
+
+    def set_dense_levels(self, levels):
+        check(lib().zh_set_dense_levels(self._h, levels))
+
+    def stats(self, reset=False):
+        s = _ffi.Stats()
+        check(lib().zh_stats(self._h, C.byref(s)))
+        if reset:
+            check(lib().zh_stats_reset(self._h))
+        return s.as_dict()
+
+
+def merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, stream=None):
+    check(lib().zh_merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys,
+                                     d_out_counts, stream))
+
+
+def synth_queries_device(device, d_out, n_rows, b, dim, b0=0, seed_rows=0x5EB2A001, seed_q=0x5EB2A002, kind=0, stream=None):
+    check(lib().zh_synth_queries_device(device, d_out, seed_rows, seed_q, n_rows, b0, b, dim, kind, stream))
+
+
+# ------------------------------------------------------------------------ src/database/core.rs
+class Database:
+    """Database<N, Met, Mod> restricted to the two calls on the hot path: insert_records
+    (core.rs:245-254) and query_vectors (core.rs:290-313).  Documents are kept in memory (the lz4
+    files and the embedding model are out of scope)."""
+
+    def __init__(self, dim, metric, index_options=None, **index_kwargs):
+        self.metric = metric
+        self.index = LSHIndex(dim, index_options, **index_kwargs)  # pub field `index`, core.rs:62
+        self._documents = {}
+
+    def insert_records(self, embeddings, documents):
+        ids = self.index.add(embeddings)
+        for i, doc in zip(ids.tolist(), documents):
+            self._documents[i] = doc
+
+    def query_vectors(self, vectors, number_of_results):
+        """-> {query index: {id: document}} ; order and distances are dropped as in core.rs:304-305."""
+        if self.index.no_vectors():
+            return {}
+        ids, _, counts = self.index.search_batch(vectors, number_of_results, self.metric)
+        return {b: {int(i): self._documents.get(int(i)) for i in ids[b, :counts[b]]} for b in range(ids.shape[0])}
