@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the LSH bucket-scan + distance hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of B synthetic queries through zh_search_batch_device (hash -> walk -> sweep ->
+select -> final), plus, for N > 1, the RCCL all-gather of every rank's top-k and the merge kernel.
+Queries and stored vectors are resident in HBM before the timed region starts.
+
+Workloads (BASELINE.json `configs`; index options from BASELINE.md s3):
+  N = 1  -> cfg3: 10M x 768 f32, L2 top-100, batch 1024, max_node_size 4096, num_trees 15.  The metric's own
+            config (cfg4, 100M x 768) is 307 GB and does not fit one 288 GB GPU, so the largest single-GPU
+            config is used, as the bench contract prescribes.
+  N > 1  -> cfg4: 100M x 768 f32 cosine top-10, batch 1024, rows sharded N ways (global ids), one forest per
+            shard, queries replicated, per-shard max_node_size = 32768 / N (4096 at N = 8 as in BASELINE.md),
+            so that the number of rows scored per query -- the work of a batch -- is the same at every N
+            ("strong" scaling of a fixed probe budget); all-gather + merge per batch.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED_ROWS, SEED_Q, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
+
+WORKLOADS = {
+    # name: rows (total), dim, metric, k, batch, max_node_size (total budget), trees, kind
+    "cfg2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, batch=256, M=1024, T=15, kind=0,
+                 desc="1M x 384-d cosine top-10, query batch=256, LSH index on 1 MI355X"),
+    "cfg3": dict(rows=10_000_000, dim=768, metric="l2", k=100, batch=1024, M=4096, T=15, kind=0,
+                 desc="10M x 768-d L2 top-100, query batch=1024, 1 MI355X (HBM-bound candidate sweep)"),
+    "cfg4": dict(rows=100_000_000, dim=768, metric="cosine", k=10, batch=1024, M=32768, T=15, kind=0,
+                 desc="100M x 768-d cosine top-10, batch=1024, vectors sharded across GPUs + RCCL top-k merge"),
+    "cfg5": dict(rows=1_000_000_000, dim=128, metric="l2", k=10, batch=4096, M=65536, T=15, kind=1,
+                 desc="1B x 128-d SIFT-style L2 top-10, batch=4096, 8 GPUs"),
+    "tiny": dict(rows=200_000, dim=768, metric="l2", k=100, batch=256, M=1024, T=15, kind=0,
+                 desc="200k x 768-d L2 top-100 (debug)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, help="override: " + ",".join(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=None, help="override total rows (debug)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--recall-queries", type=int, default=64)
+    ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
+    return ap.parse_args()
+
+
+def make_metric(za, name, parity=True):
+    return {"cosine": za.CosineDistance(parity=parity), "l2": za.L2Distance(), "l2sq": za.L2SquaredDistance()}[name]
+
+
+def exact_topk(torch, X, q, k, metric, chunk=1 << 20):
+    """brute-force top-k of the true metric (cosine distance / L2) with torch matmul, for recall"""
+    n = X.shape[0]
+    best_v = torch.full((q.shape[0], k), float("inf"), device=q.device)
+    best_i = torch.zeros((q.shape[0], k), dtype=torch.int64, device=q.device)
+    qn = (q * q).sum(1)
+    for s in range(0, n, chunk):
+        xs = X[s:s + chunk]
+        dots = q @ xs.T
+        xn = (xs * xs).sum(1)
+        if metric == "cosine":
+            dist = 1.0 - dots / torch.sqrt(qn[:, None] * xn[None, :]).clamp_min(1e-30)
+        else:
+            dist = qn[:, None] + xn[None, :] - 2.0 * dots
+        v, i = torch.topk(dist, min(k, xs.shape[0]), dim=1, largest=False)
+        cv = torch.cat([best_v, v], 1)
+        ci = torch.cat([best_i, i + s], 1)
+        o = torch.topk(cv, k, dim=1, largest=False)
+        best_v, best_i = o.values, torch.gather(ci, 1, o.indices)
+    return best_i
+
+
+def cpu_baseline(wl, M_shard, seconds, za, torch, device):
+    """The oracle (a CPU *port* of the reference algorithm: the Rust crate cannot be built here) timed on
+    this box's host cores, on a bounded sample: the same dim / metric / k / max_node_size / num_trees, a
+    smaller stored set (so it fits host RAM and builds quickly) and as many 16-query batches as fit the time
+    budget.  In the one-leaf-per-tree regime the rows scored per query (~0.68 * M * T) do not depend on the
+    number of stored rows, so the per-query cost is representative."""
+    from oracle import zebra_oracle as zo
+    d, T, k = wl["dim"], wl["T"], wl["k"]
+    n_cpu = int(min(wl["rows_local"], max(8 * M_shard, 262144)))
+    X = zo.synth_rows(n_cpu, d, kind=wl["kind"])
+    # forest of the sample: built by the HIP path (bit-identical to the oracle's build, tests/test_gpu_parity.py)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX, device=device)
+    ix.append(X)
+    ix.build()
+    f = zo.Forest.from_arrays(X, M_shard, ix.get_forest())
+    ix.close()
+    om = {"cosine": zo.COSINE, "l2": zo.L2, "l2sq": zo.L2SQ}[wl["metric"]]
+    cores = zo.num_threads()
+    bq, done, t0, b0 = 16 * max(1, cores // 8), 0, time.perf_counter(), 0
+    f.search_batch(zo.synth_queries(cores, d, n_cpu, kind=wl["kind"]), k, om, zo.PARITY, nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    rows = 0
+    while True:
+        Q = zo.synth_queries(bq, d, n_cpu, b0=b0, kind=wl["kind"])
+        _, _, _, st = f.search_batch(Q, k, om, zo.PARITY, nthreads=cores, stats=True)
+        rows += st.rows_scored
+        done += bq
+        b0 += bq
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 4096:
+            break
+    return {"value": done / el, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{done} queries against {n_cpu} x {d} stored rows (same metric, k={k}, max_node_size={M_shard}, "
+                      f"num_trees={T}; {rows / done:.0f} rows scored per query), {el:.1f} s on {cores} OpenMP threads"}
+
+
+def main():
+    args = parse()
+    import torch
+    import zebra_amd as za
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    name = args.workload or ("cfg3" if world == 1 else "cfg4")
+    wl = dict(WORKLOADS[name])
+    if args.rows:
+        wl["rows"] = args.rows
+    S = world
+    rows_local = wl["rows"] // S
+    wl["rows_local"] = rows_local
+    M_shard = max(wl["M"] // S, 2 * wl["k"] + 2) if S > 1 else wl["M"]
+    d, T, k, B = wl["dim"], wl["T"], wl["k"], wl["batch"]
+    metric = make_metric(za, wl["metric"], parity=True)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- setup (untimed): synthetic rows on the device, GPU forest build -------------------------------
+    t_setup = time.perf_counter()
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=local_rank,
+                     id_base=rank * rows_local, reserve_rows=rows_local)
+    ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=rank * rows_local, kind=wl["kind"])
+    t_fill = time.perf_counter() - t_setup
+    ix.build()
+    t_build = time.perf_counter() - t_setup - t_fill
+    n_total = rows_local * S
+
+    n_batches = args.steps + args.warmup
+    queries = []
+    for i in range(n_batches):
+        q = torch.empty((B, d), dtype=torch.float32, device=dev)
+        za.synth_queries_device(local_rank, q.data_ptr(), n_total, B, d, b0=i * B, seed_rows=SEED_ROWS, seed_q=SEED_Q,
+                                kind=wl["kind"])
+        queries.append(q)
+    ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+    keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    if S > 1:
+        g_ids = torch.empty((S, B, k), dtype=torch.int64, device=dev)
+        g_keys = torch.empty((S, B, k), dtype=torch.int64, device=dev)
+        g_counts = torch.empty((S, B), dtype=torch.int32, device=dev)
+        m_ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+        m_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+        m_counts = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def step(q):
+        ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
+        if S > 1:  # the one exchange step of the path: every rank's top-k to every rank, then merge
+            dist.all_gather_into_tensor(g_ids, ids)
+            dist.all_gather_into_tensor(g_keys, keys)
+            dist.all_gather_into_tensor(g_counts, counts)
+            za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
+                                 m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
+
+    def barrier():
+        if S > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(queries[i])
+    ix.set_profiling(1)  # hipEvents around every stage, on the stream the kernels run on
+    ix.stats(reset=True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(queries[args.warmup + i])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if S > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ix.stats()
+
+    # ---- untimed: R_unique of the timed batches, recall, sanity of the last result ---------------------
+    ix.set_profiling(2)
+    uniq = tot = 0
+    for i in range(min(args.steps, 4)):
+        ix.stats(reset=True)
+        ix.search_batch_device(queries[args.warmup + i].data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(),
+                               counts.data_ptr(), stream)
+        s2 = ix.stats()
+        uniq += s2["rows_unique"]
+        tot += s2["rows_scored"]
+    uniq_frac = uniq / max(tot, 1)
+    ix.set_profiling(0)
+
+    rows_per_launch = st["sweep_rows_accum"] / max(st["timed_batches"], 1)
+    sweep_ms = st["ms_sweep"] / max(st["timed_batches"], 1)
+    # algorithmic bytes of one sweep launch (DESIGN.md "Kernels"): every distinct stored row crosses HBM once
+    # (4*d bytes), every scored row reads a 4-byte leaf id and writes an 8-byte key, plus the query batch
+    bytes_alg = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B
+    bytes_nosharing = (4.0 * d + 12.0) * rows_per_launch
+    achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+
+    # roofline.traffic: HBM bytes per sweep launch from the rocprofv3 PMC passes of THIS command (separate
+    # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), summarised under profiles/ by
+    # profiles/summarize.py; bench.py cannot collect counters on itself, so it quotes the committed summary.
+    traffic, traffic_src = None, None
+    import glob
+    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
+    kname = "sweep_kernel<%d, %s>" % (d, "true" if wl["metric"] == "cosine" else "false")
+    if cands and name == "cfg3" and S == 1 and not args.rows:
+        try:
+            pm = json.load(open(cands[-1]))
+            traffic = pm[kname]["hbm_bytes_per_launch"]
+            traffic_src = os.path.relpath(cands[-1], ROOT)
+        except Exception:
+            traffic = None
+
+    recall = recall_parity = planted = None
+    if not args.no_recall and args.recall_queries > 0:
+        nq = min(args.recall_queries, B)
+        q = queries[-1][:nq]
+        got_parity = None
+        rec_metric = metric if wl["metric"] != "cosine" else make_metric(za, "cosine", parity=False)
+        r_ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+        r_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+        r_counts = torch.empty(B, dtype=torch.int32, device=dev)
+
+        def run(m):
+            ix.search_batch_device(queries[-1].data_ptr(), B, k, m, r_ids.data_ptr(), r_keys.data_ptr(),
+                                   r_counts.data_ptr(), stream)
+            out = r_ids.clone()
+            if S > 1:
+                dist.all_gather_into_tensor(g_ids, r_ids)
+                dist.all_gather_into_tensor(g_keys, r_keys)
+                dist.all_gather_into_tensor(g_counts, r_counts)
+                za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
+                                     m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
+                out = m_ids.clone()
+            return out[:nq]
+
+        got = run(rec_metric)
+        if wl["metric"] == "cosine":
+            got_parity = run(metric)
+        # exact neighbours over the whole (sharded) set: local exact top-k, gathered, merged by distance
+        Xt = _wrap_rows(torch, ix, rows_local, d, dev)
+        true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + rank * rows_local
+        if S > 1:
+            # re-rank the union of the shards' exact top-k by true distance
+            all_true = [torch.empty_like(true_local) for _ in range(S)]
+            dist.all_gather(all_true, true_local)
+            cand = torch.cat(all_true, 1)
+            dl = _true_dist(torch, Xt, q, cand - rank * rows_local, rows_local, wl["metric"])
+            dist.all_reduce(dl, op=dist.ReduceOp.MIN)
+            true_ids = torch.gather(cand, 1, torch.topk(dl, k, dim=1, largest=False).indices)
+        else:
+            true_ids = true_local
+
+        def rec(g):
+            hit = 0
+            gt, tt = g.cpu().numpy(), true_ids.cpu().numpy()
+            for b in range(nq):
+                hit += len(set(gt[b].tolist()) & set(tt[b].tolist()))
+            return hit / (nq * k)
+
+        # the planted neighbour (query = stored row + 0.3 * noise): is it among the returned ids?
+        from zebra_amd import _ffi as _f  # noqa: F401
+        pl = np.array([_planted_row(SEED_Q, (n_batches - 1) * B + b, n_total) for b in range(nq)], dtype=np.int64)
+        planted = float((got.cpu().numpy() == pl[:, None]).any(1).mean())
+        recall = rec(got)
+        recall_parity = rec(got_parity) if got_parity is not None else recall
+
+    cpu = None
+    if rank == 0 and S == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(wl, M_shard, args.cpu_seconds, za, torch, local_rank)
+
+    if rank == 0:
+        qps = B * args.steps / elapsed
+        out = {
+            "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": S, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {wl['desc']}", "rows_total": n_total, "rows_per_gpu": rows_local,
+                       "dim": d, "metric": wl["metric"] + ("(parity key)" if wl["metric"] == "cosine" else ""),
+                       "top_k": k, "batch": B, "max_node_size": M_shard, "num_trees": T,
+                       "parallelism": f"rows sharded x{S}, queries replicated, all-gather top-k merge" if S > 1 else "1 GPU"},
+            f"recall_at_{k}": recall, f"recall_at_{k}_reference_key": recall_parity, "planted_neighbour_hit_rate": planted,
+            "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
+                         "bytes_per_launch": bytes_alg, "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0},
+            "cpu_baseline": cpu,
+            "stage_ms": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
+            "setup_s": {"fill": t_fill, "build": t_build},
+        }
+        print(json.dumps(out))
+    if S > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _planted_row(seed_q, b, n_rows):
+    """row the synthetic query b was planted next to (same formula as the device generator)"""
+    M64 = (1 << 64) - 1
+
+    def sm(z):
+        z = (z + 0x9E3779B97F4A7C15) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+    return sm(seed_q ^ ((b * 0xA24BAED4963EE407) & M64)) % n_rows
+
+
+def _wrap_rows(torch, ix, n, d, dev):
+    """torch view of the library-owned stored rows (device pointer -> tensor, no copy)"""
+    class _Ext:
+        pass
+    e = _Ext()
+    e.__cuda_array_interface__ = {"shape": (n, d), "typestr": "<f4", "data": (ix.rows_device_ptr(), False), "version": 3,
+                                  "strides": None}
+    return torch.as_tensor(e, device=dev)
+
+
+def _true_dist(torch, X, q, local_ids, n_local, metric):
+    """true distance of candidate ids that live on this shard (inf elsewhere)"""
+    valid = (local_ids >= 0) & (local_ids < n_local)
+    idx = local_ids.clamp(0, n_local - 1)
+    rows = X[idx.reshape(-1)].reshape(idx.shape[0], idx.shape[1], -1)
+    if metric == "cosine":
+        dots = (rows * q[:, None, :]).sum(2)
+        dv = 1.0 - dots / torch.sqrt((rows * rows).sum(2) * (q * q).sum(1)[:, None]).clamp_min(1e-30)
+    else:
+        dv = ((rows - q[:, None, :]) ** 2).sum(2)
+    return torch.where(valid, dv, torch.full_like(dv, float("inf")))
+
+
+if __name__ == "__main__":
+    main()
