@@ -325,6 +325,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
+                         "rows_loaded_per_launch": st["swept_rows_accum"] / max(st["timed_batches"], 1),
                          "bytes_per_launch": bytes_alg, "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0},
             "cpu_baseline": cpu,
             "stage_ms": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},

@@ -105,15 +105,17 @@ typedef struct zh_stats_t {
     uint64_t visits;           /* leaf visits (bucket probes) */
     uint64_t rows_scored;      /* R_total: stored rows whose distance was computed */
     uint64_t rows_unique;      /* R_unique: rows of the distinct leaves touched (0 unless stats level >= 2) */
+    uint64_t rows_swept;       /* rows the sweep kernel actually loaded: queries that probe the same leaf share them */
     uint64_t candidates;       /* ids handed to the final top-k (before de-duplication) */
     uint64_t planes_dense;     /* hyperplanes hashed by the dense MFMA kernel, per query */
     uint64_t planes_total;     /* hyperplanes in the forest */
-    uint64_t sweep_bytes;      /* algorithmic bytes of the sweep: 4*dim*rows_scored + 4*rows_scored + 8*rows_scored */
+    uint64_t sweep_bytes;      /* bytes the sweep moves: (4*dim + 4) * rows_swept + 8 * rows_scored */
     /* accumulated since zh_stats_reset, in milliseconds, measured with hipEvents on the stream the
      * kernels run on (only when profiling is enabled with zh_set_profiling) */
     double ms_hash, ms_walk, ms_sweep, ms_select, ms_final, ms_total;
     uint64_t timed_batches;
     uint64_t sweep_rows_accum;  /* rows_scored summed over the timed batches */
+    uint64_t swept_rows_accum;  /* rows_swept summed over the timed batches */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

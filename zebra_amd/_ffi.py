@@ -37,11 +37,11 @@ class ForestSizes(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("batch", C.c_uint64), ("visits", C.c_uint64), ("rows_scored", C.c_uint64),
-                ("rows_unique", C.c_uint64), ("candidates", C.c_uint64), ("planes_dense", C.c_uint64),
+                ("rows_unique", C.c_uint64), ("rows_swept", C.c_uint64), ("candidates", C.c_uint64), ("planes_dense", C.c_uint64),
                 ("planes_total", C.c_uint64), ("sweep_bytes", C.c_uint64),
                 ("ms_hash", C.c_double), ("ms_walk", C.c_double), ("ms_sweep", C.c_double),
                 ("ms_select", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
-                ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64)]
+                ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64), ("swept_rows_accum", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -94,8 +94,8 @@ struct zh_index {
     uint32_t max_leaf_len = 0;
 
     // per-batch workspace
-    DevBuf wQ, wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wVisitRowOff, wKeys,
-        wCandKeys, wCandIds, wOutIds, wOutKeys, wOutCounts;
+    DevBuf wQ, wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys,
+        wCandIds, wOutIds, wOutKeys, wOutCounts, wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff;
     ZhTotals *h_totals = nullptr;  // pinned
 
     int dense_levels = -1;
@@ -193,8 +193,9 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     free_forest(ix);
     ix->X.release();
     DevBuf *ws[] = {&ix->wQ, &ix->wQQ, &ix->wBits, &ix->wCounts, &ix->wInline, &ix->wRowBase, &ix->wCandBase,
-                    &ix->wVisitBase, &ix->wTotals, &ix->wVisits, &ix->wVisitRowOff, &ix->wKeys, &ix->wCandKeys,
-                    &ix->wCandIds, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
+                    &ix->wVisitBase, &ix->wTotals, &ix->wVisits, &ix->wKeys, &ix->wCandKeys, &ix->wCandIds,
+                    &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts, &ix->wLeafCount, &ix->wLeafFill, &ix->wGroupBase,
+                    &ix->wGroupRowBase, &ix->wGroups, &ix->wGroupRowOff};
     for (DevBuf *b : ws) b->release();
     if (ix->ev_ok) for (auto &e : ix->ev) hipEventDestroy(e);
     if (ix->h_totals) hipHostFree(ix->h_totals);
@@ -641,6 +642,13 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
     if ((rc = ix->wCandBase.ensure((pairs + 1) * 8))) return rc;
     if ((rc = ix->wVisitBase.ensure((pairs + 1) * 8))) return rc;
     if ((rc = ix->wTotals.ensure(sizeof(ZhTotals)))) return rc;
+    const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
+    if ((rc = ix->wLeafCount.ensure(nn * 4))) return rc;
+    if ((rc = ix->wLeafFill.ensure(nn * 4))) return rc;
+    if ((rc = ix->wGroupBase.ensure(nn * 4))) return rc;
+    if ((rc = ix->wGroupRowBase.ensure(nn * 8))) return rc;
+    HIPCHK(hipMemsetAsync(ix->wLeafCount.p, 0, nn * 4, s));
+    HIPCHK(hipMemsetAsync(ix->wLeafFill.p, 0, nn * 4, s));
     ZhForestDev f = forest_dev(ix);
     if (prof) HIPCHK(hipEventRecord(ix->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, ix->wQQ.as<float>(), s));
@@ -648,7 +656,9 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
         HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, P_dense, d, ix->wBits.as<uint32_t>(), wpq, nullptr, s));
     if (prof) HIPCHK(hipEventRecord(ix->ev[1], s));
     HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
-                                ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), s));
+                                ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), ix->wLeafCount.as<uint32_t>(), s));
+    HIPCHK(zh_launch_leaf_scan(f, ix->wLeafCount.as<uint32_t>(), ix->wGroupBase.as<uint32_t>(),
+                               ix->wGroupRowBase.as<uint64_t>(), ix->wTotals.as<ZhTotals>(), s));
     HIPCHK(zh_launch_pair_scan(ix->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, ix->wRowBase.as<uint64_t>(),
                                ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wTotals.as<ZhTotals>(), s));
     HIPCHK(hipMemcpyAsync(ix->h_totals, ix->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
@@ -656,17 +666,19 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
     const ZhTotals tot = *ix->h_totals;
     if (tot.visits > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "more than 2^31 leaf visits in one batch; use a smaller batch");
     if ((rc = ix->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
-    if ((rc = ix->wVisitRowOff.ensure(std::max<uint64_t>(tot.visits, 1) * 8))) return rc;
+    if ((rc = ix->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
+    if ((rc = ix->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;
     if ((rc = ix->wKeys.ensure(std::max<uint64_t>(tot.rows, 1) * 8))) return rc;
     if ((rc = ix->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
     if ((rc = ix->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
     HIPCHK(zh_launch_walk_emit(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
                                ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), ix->wRowBase.as<uint64_t>(),
                                ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wVisits.as<ZhVisit>(),
-                               ix->wVisitRowOff.as<uint64_t>(), s));
+                               ix->wLeafCount.as<uint32_t>(), ix->wLeafFill.as<uint32_t>(), ix->wGroupBase.as<uint32_t>(),
+                               ix->wGroupRowBase.as<uint64_t>(), ix->wGroups.as<ZhGroup>(), ix->wGroupRowOff.as<uint64_t>(), s));
     if (prof) HIPCHK(hipEventRecord(ix->ev[2], s));
-    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, dQ, ix->wQQ.as<float>(), ix->wVisits.as<ZhVisit>(),
-                           ix->wVisitRowOff.as<uint64_t>(), tot.visits, f.leaf_ids, tot.rows, metric, mode,
+    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, dQ, ix->wQQ.as<float>(), ix->wGroups.as<ZhGroup>(),
+                           ix->wGroupRowOff.as<uint64_t>(), tot.groups, f.leaf_ids, tot.group_rows, metric, mode,
                            ix->wKeys.as<uint64_t>(), s));
     if (prof) HIPCHK(hipEventRecord(ix->ev[3], s));
     HIPCHK(zh_launch_select(ix->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, ix->wKeys.as<uint64_t>(),
@@ -679,7 +691,8 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
     zh_stats_t &st = ix->stats;
     st.batch = B; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
     st.planes_dense = P_dense; st.planes_total = ix->n_planes;
-    st.sweep_bytes = tot.rows * ((uint64_t)4 * d + 4 + 8);
+    st.rows_swept = tot.group_rows;
+    st.sweep_bytes = tot.group_rows * ((uint64_t)4 * d + 4) + tot.rows * 8;
     if (prof) {
         float ms[5];
         for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]));
@@ -687,6 +700,7 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
         st.ms_total += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
         st.timed_batches++;
         st.sweep_rows_accum += tot.rows;
+        st.swept_rows_accum += tot.group_rows;
     }
     if (ix->profiling >= 2 && tot.visits) {  // R_unique: rows of the distinct leaves touched by the batch
         std::vector<ZhVisit> hv(tot.visits);

@@ -16,6 +16,17 @@ struct ZhVisit {
     uint32_t take;      // min(n, len)
     uint64_t row_off;
     uint64_t cand_off;
+    uint32_t node;      // the leaf's node index
+    uint32_t pad;
+};
+
+// Visits of one leaf by different queries of the batch are swept together, ZH_GROUP at a time:
+// the leaf's rows cross HBM once per group instead of once per query.
+#define ZH_GROUP 2
+struct ZhGroup {
+    uint32_t leaf_off, len, gsize, pad;
+    uint32_t b[ZH_GROUP];
+    uint64_t key_off[ZH_GROUP];  // the member visits' row_off (slice of the key scratch)
 };
 
 // per (query, tree) pair counts produced by the walk's first pass, then their exclusive scans
@@ -24,6 +35,7 @@ struct ZhPairCounts {
 };
 struct ZhTotals {
     uint64_t visits, rows, takes, flags;
+    uint64_t groups, group_rows;  // filled by the leaf scan
 };
 
 struct ZhForestDev {
@@ -35,7 +47,7 @@ struct ZhForestDev {
 };
 
 #define ZH_SORT_N 4096        // entries of the LDS sort buffer of the select / final kernels
-#define ZH_INLINE_VISITS 2    // visits a pair may record in the walk's first pass
+#define ZH_INLINE_VISITS 8    // visits a pair may record in the walk's first pass
 
 // ---- launchers (zh_search.hip) ---------------------------------------------------------------
 hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlanes, const float *dConsts,
@@ -44,7 +56,10 @@ hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlane
 hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, hipStream_t s);
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                 const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
-                                ZhVisit *dInline, hipStream_t s);
+                                ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s);
+// per leaf node: visits -> groups; exclusive scans of groups and of groups * len over the nodes
+hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
+                               uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s);
 // exclusive scans over the pairs; the three base arrays have n_pairs + 1 entries
 hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, uint64_t *dRowBase,
                                uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, hipStream_t s);
@@ -52,10 +67,11 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense,
                                const ZhPairCounts *dCounts, const ZhVisit *dInline, const uint64_t *dRowBase,
                                const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits,
-                               uint64_t *dVisitRowOff, hipStream_t s);
-hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhVisit *dVisits,
-                           const uint64_t *dVisitRowOff, uint64_t n_visits, const uint32_t *dLeafIds,
-                           uint64_t R_total, int metric, int mode, uint64_t *dKeys, hipStream_t s);
+                               const uint32_t *dLeafCount, uint32_t *dLeafFill, const uint32_t *dGroupBase,
+                               const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s);
+hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
+                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
+                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s);
 hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
                             const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s);
 hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,

@@ -201,7 +201,21 @@ __device__ __forceinline__ bool plane_above_on_demand(const float *__restrict__ 
     if ((d & 3u) == 0) {
         const float4 *w4 = reinterpret_cast<const float4 *>(w);
         const float4 *q4 = reinterpret_cast<const float4 *>(q);
-        for (uint32_t k = 0; k < d / 4; k++) {
+        const uint32_t n4 = d / 4;
+        uint32_t k = 0;
+        for (; k + 8 <= n4; k += 8) {  // 16 independent 16-B loads in flight, then the ordered chain
+            float4 a[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = w4[k + u]; x[u] = q4[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc = __builtin_fmaf(a[u].x, x[u].x, acc);
+                acc = __builtin_fmaf(a[u].y, x[u].y, acc);
+                acc = __builtin_fmaf(a[u].z, x[u].z, acc);
+                acc = __builtin_fmaf(a[u].w, x[u].w, acc);
+            }
+        }
+        for (; k < n4; k++) {
             float4 a = w4[k], x = q4[k];
             acc = __builtin_fmaf(a.x, x.x, acc);
             acc = __builtin_fmaf(a.y, x.y, acc);
@@ -216,6 +230,25 @@ __device__ __forceinline__ bool plane_above_on_demand(const float *__restrict__ 
 
 #define WALK_STACK 64
 
+// emit pass: the s-th visit of a leaf joins group s / ZH_GROUP of that leaf as member s % ZH_GROUP
+__device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__restrict__ leafCount,
+                                           uint32_t *__restrict__ leafFill, const uint32_t *__restrict__ groupBase,
+                                           const uint64_t *__restrict__ groupRowBase, ZhGroup *__restrict__ groups,
+                                           uint64_t *__restrict__ groupRowOff) {
+    const uint32_t s = atomicAdd(&leafFill[v.node], 1u);
+    const uint32_t c = leafCount[v.node];
+    const uint32_t gl = s / ZH_GROUP, slot = s % ZH_GROUP;
+    const uint32_t g = groupBase[v.node] + gl;
+    const uint32_t rest = c - gl * ZH_GROUP;
+    ZhGroup *G = groups + g;
+    G->b[slot] = v.b;
+    G->key_off[slot] = v.row_off;
+    if (slot == 0) {
+        G->leaf_off = v.leaf_off; G->len = v.len; G->gsize = rest < ZH_GROUP ? rest : ZH_GROUP; G->pad = 0;
+        groupRowOff[g] = groupRowBase[v.node] + (uint64_t)gl * v.len;
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__restrict__ Q, uint32_t B, uint32_t d,
                                                    int32_t n, const uint32_t *__restrict__ bits, uint32_t wpq,
@@ -223,7 +256,11 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    ZhVisit *__restrict__ inl, const uint64_t *__restrict__ rowBase,
                                                    const uint64_t *__restrict__ candBase,
                                                    const uint64_t *__restrict__ visitBase,
-                                                   ZhVisit *__restrict__ visits, uint64_t *__restrict__ visitRowOff) {
+                                                   ZhVisit *__restrict__ visits, uint32_t *__restrict__ leafCount,
+                                                   uint32_t *__restrict__ leafFill,
+                                                   const uint32_t *__restrict__ groupBase,
+                                                   const uint64_t *__restrict__ groupRowBase,
+                                                   ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff) {
     const uint32_t T = f.n_trees;
     const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= (uint64_t)B * T) return;
@@ -237,7 +274,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 v.row_off += rb;
                 v.cand_off += cb;
                 visits[vb + i] = v;
-                visitRowOff[vb + i] = v.row_off;
+                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
             }
             return;
         }
@@ -266,14 +303,17 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
         if (take > 0) {
             ZhVisit v;
-            v.b = b; v.leaf_off = off; v.len = len; v.take = take;
+            v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
             if (EMIT) {
                 v.row_off = rb + nrows; v.cand_off = cb + ntakes;
                 visits[vb + nv] = v;
-                visitRowOff[vb + nv] = v.row_off;
-            } else if (nv < ZH_INLINE_VISITS) {
-                v.row_off = nrows; v.cand_off = ntakes;
-                inl[pair * ZH_INLINE_VISITS + nv] = v;
+                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+            } else {
+                atomicAdd(&leafCount[cur], 1u);
+                if (nv < ZH_INLINE_VISITS) {
+                    v.row_off = nrows; v.cand_off = ntakes;
+                    inl[pair * ZH_INLINE_VISITS + nv] = v;
+                }
             }
             nv++; nrows += len; ntakes += take;
         }
@@ -298,23 +338,66 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
 
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                 const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
-                                ZhVisit *dInline, hipStream_t s) {
+                                ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
     hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
-                       words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr, dLeafCount, nullptr,
+                       nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError();
 }
 hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense,
                                const ZhPairCounts *dCounts, const ZhVisit *dInline, const uint64_t *dRowBase,
                                const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits,
-                               uint64_t *dVisitRowOff, hipStream_t s) {
+                               const uint32_t *dLeafCount, uint32_t *dLeafFill, const uint32_t *dGroupBase,
+                               const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
     hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
                        words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts), const_cast<ZhVisit *>(dInline),
-                       dRowBase, dCandBase, dVisitBase, dVisits, dVisitRowOff);
+                       dRowBase, dCandBase, dVisitBase, dVisits, const_cast<uint32_t *>(dLeafCount), dLeafFill,
+                       dGroupBase, dGroupRowBase, dGroups, dGroupRowOff);
+    return hipGetLastError();
+}
+
+// leaf scan: one block; node i with c visits forms ceil(c / ZH_GROUP) groups of len(i) rows each
+__global__ __launch_bounds__(1024) void leaf_scan_kernel(ZhForestDev f, const uint32_t *__restrict__ leafCount,
+                                                          uint32_t *__restrict__ groupBase,
+                                                          uint64_t *__restrict__ groupRowBase,
+                                                          ZhTotals *__restrict__ totals) {
+    __shared__ uint64_t sg[1024], sr[1024];
+    const uint32_t tid = threadIdx.x, n = f.n_nodes;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint64_t g = 0, r = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t c = leafCount[i];
+        if (c) { uint32_t ng = (c + ZH_GROUP - 1) / ZH_GROUP; g += ng; r += (uint64_t)ng * (uint32_t)f.node_right[i]; }
+    }
+    sg[tid] = g; sr[tid] = r;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint64_t ag = 0, ar = 0;
+        if (tid >= off) { ag = sg[tid - off]; ar = sr[tid - off]; }
+        __syncthreads();
+        sg[tid] += ag; sr[tid] += ar;
+        __syncthreads();
+    }
+    uint64_t bg = sg[tid] - g, br = sr[tid] - r;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t c = leafCount[i];
+        if (c) {
+            groupBase[i] = (uint32_t)bg; groupRowBase[i] = br;
+            uint32_t ng = (c + ZH_GROUP - 1) / ZH_GROUP;
+            bg += ng; br += (uint64_t)ng * (uint32_t)f.node_right[i];
+        }
+    }
+    if (tid == 1023) { totals->groups = sg[1023]; totals->group_rows = sr[1023]; }
+}
+hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
+                               uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s) {
+    hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, s, f, dLeafCount, dGroupBase, dGroupRowBase, dTotals);
     return hipGetLastError();
 }
 
@@ -407,98 +490,163 @@ __device__ __forceinline__ void row_sums(const float4 *v, const float4 *q, uint3
 
 #define SWEEP_RG 4
 
+// one row against the (up to ZH_GROUP) queries of its group; a2 (the stored row's norm) is shared
+template <int D, bool COSINE>
+__device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q)[RowVec<D>::NV], uint32_t gsize,
+                                               uint32_t lane, float *s0, float &s1) {
+    constexpr int NV = RowVec<D>::NV;
+    if (COSINE) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+            if (act) {
+                c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
+                c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
+            }
+        }
+        s1 = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
+    } else
+        s1 = 0.0f;
+#pragma unroll
+    for (int m = 0; m < ZH_GROUP; m++) {
+        if ((uint32_t)m < gsize) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+                if (act) {
+                    if (COSINE) {
+                        a.x = __builtin_fmaf(v[j].x, q[m][j].x, a.x); a.y = __builtin_fmaf(v[j].y, q[m][j].y, a.y);
+                        a.z = __builtin_fmaf(v[j].z, q[m][j].z, a.z); a.w = __builtin_fmaf(v[j].w, q[m][j].w, a.w);
+                    } else {
+                        float dx = v[j].x - q[m][j].x, dy = v[j].y - q[m][j].y, dz = v[j].z - q[m][j].z,
+                              dw = v[j].w - q[m][j].w;
+                        a.x = __builtin_fmaf(dx, dx, a.x); a.y = __builtin_fmaf(dy, dy, a.y);
+                        a.z = __builtin_fmaf(dz, dz, a.z); a.w = __builtin_fmaf(dw, dw, a.w);
+                    }
+                }
+            }
+            s0[m] = wave_sum_canonical((a.x + a.y) + (a.z + a.w));
+        }
+    }
+}
+
 // D > 0: compile-time dimension (multiple of 4); D == 0: runtime d, any value (slow path)
 template <int D, bool COSINE>
 __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X, uint32_t d,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
-                                                     const ZhVisit *__restrict__ visits,
-                                                     const uint64_t *__restrict__ visitRowOff, uint64_t n_visits,
-                                                     const uint32_t *__restrict__ leaf_ids, uint64_t R_total,
+                                                     const ZhGroup *__restrict__ groups,
+                                                     const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                                     const uint32_t *__restrict__ leaf_ids, uint64_t R_grouped,
                                                      int metric, int mode, uint64_t *__restrict__ keys) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t r0 = wave * 64;
-    if (r0 >= R_total) return;
-    const uint32_t cnt = (uint32_t)(R_total - r0 < 64 ? R_total - r0 : 64);
-    // lane i -> (query, stored row) of flat row r0 + i
-    uint32_t my_b = 0, my_id = 0;
+    if (r0 >= R_grouped) return;
+    const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+    // lane i -> (group, stored row) of flat row r0 + i
+    uint32_t my_g, my_id, my_within;
     {
         uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
-        uint64_t lo = 0, hi = n_visits;  // last visit with row_off <= r
+        uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
         while (hi - lo > 1) {
             uint64_t mid = (lo + hi) >> 1;
-            if (visitRowOff[mid] <= r) lo = mid; else hi = mid;
+            if (groupRowOff[mid] <= r) lo = mid; else hi = mid;
         }
-        ZhVisit v = visits[lo];
-        uint32_t within = (uint32_t)(r - v.row_off);
-        my_b = v.b;
-        my_id = leaf_ids ? leaf_ids[(size_t)v.leaf_off + within] : v.leaf_off + within;
+        my_g = (uint32_t)lo;
+        my_within = (uint32_t)(r - groupRowOff[lo]);
+        uint32_t lo_off = groups[lo].leaf_off;
+        my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
     }
-    float mine0 = 0.f, mine1 = 0.f, mine_qq = 0.f;
+    float mine0[ZH_GROUP], mine1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < ZH_GROUP; m++) mine0[m] = 0.f;
     if (D > 0) {
-        constexpr int NV = RowVec<(D > 0 ? D : 4)>::NV;
-        float4 q[NV];
-        uint32_t cur_b = 0xFFFFFFFFu;
-        float cur_qq = 0.f;
+        constexpr int DD = (D > 0 ? D : 4);
+        constexpr int NV = RowVec<DD>::NV;
+        float4 q[ZH_GROUP][NV];
+        uint32_t cur_g = 0xFFFFFFFFu, gsize = 0;
         for (uint32_t i0 = 0; i0 < cnt; i0 += SWEEP_RG) {
             float4 v[SWEEP_RG][NV];
 #pragma unroll
             for (int r = 0; r < SWEEP_RG; r++) {
                 uint32_t i = i0 + r < cnt ? i0 + r : cnt - 1;
                 uint32_t id = __builtin_amdgcn_readlane(my_id, i);
-                load_row<(D > 0 ? D : 4)>(X + (size_t)id * D, lane, v[r]);
+                load_row<DD>(X + (size_t)id * DD, lane, v[r]);
             }
 #pragma unroll
             for (int r = 0; r < SWEEP_RG; r++) {
                 uint32_t i = i0 + r;
                 if (i < cnt) {
-                    uint32_t bq = __builtin_amdgcn_readlane(my_b, i);
-                    if (bq != cur_b) {
-                        cur_b = bq;
-                        load_row<(D > 0 ? D : 4)>(Q + (size_t)bq * D, lane, q);
-                        if (COSINE) cur_qq = QQ[bq];
+                    uint32_t g = __builtin_amdgcn_readlane(my_g, i);
+                    if (g != cur_g) {
+                        cur_g = g;
+                        gsize = groups[g].gsize;
+#pragma unroll
+                        for (int m = 0; m < ZH_GROUP; m++)
+                            if ((uint32_t)m < gsize) load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[m]);
                     }
-                    float s0, s1;
-                    row_sums<(D > 0 ? D : 4), COSINE>(v[r], q, lane, s0, s1);
-                    if (lane == i) { mine0 = s0; mine1 = s1; mine_qq = cur_qq; }
+                    float s0[ZH_GROUP], s1;
+                    row_sums_group<DD, COSINE>(v[r], q, gsize, lane, s0, s1);
+                    if (lane == i) {
+#pragma unroll
+                        for (int m = 0; m < ZH_GROUP; m++) mine0[m] = s0[m];
+                        mine1 = s1;
+                    }
                 }
             }
         }
     } else {
         for (uint32_t i = 0; i < cnt; i++) {
             uint32_t id = __builtin_amdgcn_readlane(my_id, i);
-            uint32_t bq = __builtin_amdgcn_readlane(my_b, i);
-            float ab, a2, l2;
-            lane_sums_generic(X + (size_t)id * d, Q + (size_t)bq * d, d, lane, COSINE, ab, a2, l2);
-            if (lane == i) { mine0 = COSINE ? ab : l2; mine1 = a2; mine_qq = COSINE ? QQ[bq] : 0.f; }
+            uint32_t g = __builtin_amdgcn_readlane(my_g, i);
+            uint32_t gsize = groups[g].gsize;
+            for (uint32_t m = 0; m < gsize; m++) {
+                float ab, a2, l2;
+                lane_sums_generic(X + (size_t)id * d, Q + (size_t)groups[g].b[m] * d, d, lane, COSINE, ab, a2, l2);
+                if (lane == i) {
+#pragma unroll
+                    for (int mm = 0; mm < ZH_GROUP; mm++)
+                        if ((uint32_t)mm == m) mine0[mm] = COSINE ? ab : l2;
+                    mine1 = a2;
+                }
+            }
         }
     }
-    if (lane < cnt) keys[r0 + lane] = COSINE ? key_cosine(mine0, mine1, mine_qq, mode) : key_l2(mine0, metric);
+    if (lane < cnt) {
+        const ZhGroup G = groups[my_g];
+#pragma unroll
+        for (int m = 0; m < ZH_GROUP; m++)
+            if ((uint32_t)m < G.gsize)
+                keys[G.key_off[m] + my_within] =
+                    COSINE ? key_cosine(mine0[m], mine1, QQ[G.b[m]], mode) : key_l2(mine0[m], metric);
+    }
 }
 
 template <int D>
 static hipError_t launch_sweep_d(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
-                                 const ZhVisit *dVisits, const uint64_t *dVisitRowOff, uint64_t n_visits,
-                                 const uint32_t *dLeafIds, uint64_t R_total, int metric, int mode, uint64_t *dKeys,
+                                 const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int mode, uint64_t *dKeys,
                                  hipStream_t s) {
-    uint64_t waves = (R_total + 63) / 64;
+    uint64_t waves = (R_grouped + 63) / 64;
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (metric == ZH_COSINE)
-        hipLaunchKernelGGL((sweep_kernel<D, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dVisits,
-                           dVisitRowOff, n_visits, dLeafIds, R_total, metric, mode, dKeys);
+        hipLaunchKernelGGL((sweep_kernel<D, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dGroups,
+                           dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys);
     else
-        hipLaunchKernelGGL((sweep_kernel<D, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dVisits,
-                           dVisitRowOff, n_visits, dLeafIds, R_total, metric, mode, dKeys);
+        hipLaunchKernelGGL((sweep_kernel<D, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dGroups,
+                           dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys);
     return hipGetLastError();
 }
 
-hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhVisit *dVisits,
-                           const uint64_t *dVisitRowOff, uint64_t n_visits, const uint32_t *dLeafIds,
-                           uint64_t R_total, int metric, int mode, uint64_t *dKeys, hipStream_t s) {
-    if (R_total == 0 || n_visits == 0) return hipSuccess;
+hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
+                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
+                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s) {
+    if (R_grouped == 0 || n_groups == 0) return hipSuccess;
 #define ZH_SWEEP_CASE(DD) \
-    case DD: return launch_sweep_d<DD>(dX, d, dQ, dQQ, dVisits, dVisitRowOff, n_visits, dLeafIds, R_total, metric, mode, dKeys, s)
+    case DD: return launch_sweep_d<DD>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys, s)
     switch (d) {
         ZH_SWEEP_CASE(64);
         ZH_SWEEP_CASE(128);
@@ -508,31 +656,32 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
         ZH_SWEEP_CASE(768);
         ZH_SWEEP_CASE(1024);
         ZH_SWEEP_CASE(1536);
-    default: return launch_sweep_d<0>(dX, d, dQ, dQQ, dVisits, dVisitRowOff, n_visits, dLeafIds, R_total, metric, mode, dKeys, s);
+    default: return launch_sweep_d<0>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys, s);
     }
 #undef ZH_SWEEP_CASE
 }
 
-// n contiguous rows against one query: a single synthetic visit, ids = row numbers
-__global__ void one_visit_kernel(ZhVisit *v, uint64_t *rowoff, uint64_t n) {
-    v->b = 0; v->leaf_off = 0; v->len = (uint32_t)n; v->take = 0; v->row_off = 0; v->cand_off = 0;
+// n contiguous rows against one query: a single synthetic group, ids = row numbers
+__global__ void one_group_kernel(ZhGroup *g, uint64_t *rowoff, uint64_t n) {
+    g->leaf_off = 0; g->len = (uint32_t)n; g->gsize = 1; g->pad = 0;
+    for (int m = 0; m < ZH_GROUP; m++) { g->b[m] = 0; g->key_off[m] = 0; }
     rowoff[0] = 0;
 }
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
                                    uint64_t *dKeys, hipStream_t s) {
     if (!n) return hipSuccess;
-    ZhVisit *dv = nullptr;
+    ZhGroup *dg = nullptr;
     uint64_t *dro = nullptr;
     float *dqq = nullptr;
     hipError_t e;
-    if ((e = hipMalloc(&dv, sizeof(ZhVisit))) != hipSuccess) return e;
-    if ((e = hipMalloc(&dro, 8)) != hipSuccess) { hipFree(dv); return e; }
-    if ((e = hipMalloc(&dqq, 4)) != hipSuccess) { hipFree(dv); hipFree(dro); return e; }
-    hipLaunchKernelGGL(one_visit_kernel, dim3(1), dim3(1), 0, s, dv, dro, n);
+    if ((e = hipMalloc(&dg, sizeof(ZhGroup))) != hipSuccess) return e;
+    if ((e = hipMalloc(&dro, 8)) != hipSuccess) { hipFree(dg); return e; }
+    if ((e = hipMalloc(&dqq, 4)) != hipSuccess) { hipFree(dg); hipFree(dro); return e; }
+    hipLaunchKernelGGL(one_group_kernel, dim3(1), dim3(1), 0, s, dg, dro, n);
     e = zh_launch_qnorm(dq, 1, d, dqq, s);
-    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dv, dro, 1, nullptr, n, metric, mode, dKeys, s);
+    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dg, dro, 1, nullptr, n, metric, mode, dKeys, s);
     hipError_t e2 = hipStreamSynchronize(s);
-    hipFree(dv); hipFree(dro); hipFree(dqq);
+    hipFree(dg); hipFree(dro); hipFree(dqq);
     return e != hipSuccess ? e : e2;
 }
 
@@ -565,24 +714,18 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-// per visit: the `take` smallest (key, id) of the leaf (lsh.rs:317-323); take == len copies all
-__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits,
-                                                      const uint32_t *__restrict__ leaf_ids,
-                                                      const uint64_t *__restrict__ keys,
-                                                      uint64_t *__restrict__ cand_keys,
-                                                      uint32_t *__restrict__ cand_ids) {
-    __shared__ uint64_t sk[ZH_SORT_N];
-    __shared__ uint32_t si[ZH_SORT_N];
-    const ZhVisit v = visits[blockIdx.x];
+// per visit: the `take` smallest (key, id) of the leaf (lsh.rs:317-323); take == len copies all.
+// The candidates of a query are sorted again by the final kernel, so a visit's slice of the pool
+// need not be ordered: select = partition.  Fast path (leaf fits the LDS buffer): histogram
+// refinement of the unsigned key range, 8 bits per round, until the bucket that holds the take-th
+// key is small; everything below it is emitted as is, the bucket itself is sorted by (key, id).
+// Slow path (leaf longer than the buffer, or a large group of equal keys): streaming bitonic sort.
+#define SEL_SMALL 512
+
+__device__ __forceinline__ void select_slow(const ZhVisit &v, const uint32_t *__restrict__ leaf_ids,
+                                            const uint64_t *__restrict__ keys, uint64_t *__restrict__ cand_keys,
+                                            uint32_t *__restrict__ cand_ids, uint64_t *sk, uint32_t *si) {
     const uint32_t tid = threadIdx.x;
-    if (v.take == 0) return;
-    if (v.take >= v.len) {
-        for (uint32_t i = tid; i < v.len; i += 256) {
-            cand_keys[v.cand_off + i] = keys[v.row_off + i];
-            cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
-        }
-        return;
-    }
     uint32_t have = 0, pos = 0;
     while (pos < v.len) {
         uint32_t m = ZH_SORT_N - have;
@@ -600,6 +743,122 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
     for (uint32_t i = tid; i < have; i += 256) {
         cand_keys[v.cand_off + i] = sk[i];
         cand_ids[v.cand_off + i] = si[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits,
+                                                      const uint32_t *__restrict__ leaf_ids,
+                                                      const uint64_t *__restrict__ keys,
+                                                      uint64_t *__restrict__ cand_keys,
+                                                      uint32_t *__restrict__ cand_ids) {
+    __shared__ uint64_t sk[ZH_SORT_N];
+    __shared__ __attribute__((aligned(16))) uint32_t si[ZH_SORT_N];  // slow path ids; fast path: small-sort buffers + histogram
+    __shared__ uint32_t s_u32[8];
+    const ZhVisit v = visits[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (v.take == 0) return;
+    if (v.take >= v.len) {
+        for (uint32_t i = tid; i < v.len; i += 256) {
+            cand_keys[v.cand_off + i] = keys[v.row_off + i];
+            cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
+        }
+        return;
+    }
+    if (v.len > ZH_SORT_N) { select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si); return; }
+    // fast-path carve-up of si[]: tk (SEL_SMALL u64) | ti (SEL_SMALL u32) | hist (256 u32) | wmin/wmax
+    uint64_t *tk = reinterpret_cast<uint64_t *>(si);
+    uint32_t *ti = si + 2 * SEL_SMALL;
+    uint32_t *hist = si + 3 * SEL_SMALL;
+    uint64_t *wred = reinterpret_cast<uint64_t *>(si + 3 * SEL_SMALL + 256);  // 8 u64
+    uint64_t kmin = ~0ull, kmax = 0;
+    for (uint32_t i = tid; i < v.len; i += 256) {
+        uint64_t k = keys[v.row_off + i];
+        sk[i] = k;
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        uint64_t a = __shfl_xor(kmin, m), b = __shfl_xor(kmax, m);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { wred[wv] = kmin; wred[4 + wv] = kmax; }
+    __syncthreads();
+    uint64_t lo = wred[0], hi = wred[4];
+    for (int w = 1; w < 4; w++) { lo = wred[w] < lo ? wred[w] : lo; hi = wred[4 + w] > hi ? wred[4 + w] : hi; }
+    uint32_t need = v.take;   // how many to take from [lo, hi]; every key < lo is already taken
+    uint32_t inb = v.len;     // keys inside [lo, hi]
+    bool take_all_bucket = false;
+    while (inb > SEL_SMALL && inb != need) {
+        uint64_t range = hi - lo;
+        if (range == 0) break;  // > SEL_SMALL equal keys: slow path below
+        int sh = 64 - __clzll((long long)range) - 8;
+        if (sh < 0) sh = 0;
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < v.len; i += 256) {
+            uint64_t k = sk[i];
+            if (k >= lo && k <= hi) atomicAdd(&hist[(uint32_t)((k - lo) >> sh)], 1u);
+        }
+        __syncthreads();
+        if (wv == 0) {  // find the bucket holding the need-th key
+            uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            uint32_t ssum = h0 + h1 + h2 + h3, inc = ssum;
+            for (int m = 1; m < 64; m <<= 1) {
+                uint32_t t = __shfl_up(inc, m);
+                if ((int)lane >= m) inc += t;
+            }
+            uint32_t exc = inc - ssum;
+            bool mine = exc < need && need <= inc;
+            if (mine) {
+                uint32_t c = exc, j = 4 * lane, hb = h0;
+                if (need > c + h0) { c += h0; j++; hb = h1;
+                    if (need > c + h1) { c += h1; j++; hb = h2;
+                        if (need > c + h2) { c += h2; j++; hb = h3; } } }
+                s_u32[0] = j; s_u32[1] = c; s_u32[2] = hb;
+            }
+        }
+        __syncthreads();
+        uint32_t j = s_u32[0], before = s_u32[1];
+        inb = s_u32[2];
+        need -= before;
+        uint64_t nlo = lo + ((uint64_t)j << sh);
+        uint64_t nhi = nlo + ((1ull << sh) - 1);
+        if (nhi < nlo) nhi = hi;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    if (inb > SEL_SMALL && inb != need) { __syncthreads(); select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si); return; }
+    take_all_bucket = (inb == need);
+    // emit: keys < lo (and the whole bucket when it is taken whole) straight to the pool; otherwise the
+    // bucket's members go to the small sort buffer
+    __syncthreads();
+    if (tid == 0) { s_u32[3] = 0; s_u32[4] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < v.len; i += 256) {
+        uint64_t k = sk[i];
+        bool below = k < lo || (take_all_bucket && k <= hi);
+        bool inside = !take_all_bucket && k >= lo && k <= hi;
+        if (below) {
+            uint32_t o = atomicAdd(&s_u32[3], 1u);
+            cand_keys[v.cand_off + o] = k;
+            cand_ids[v.cand_off + o] = leaf_ids[(size_t)v.leaf_off + i];
+        } else if (inside) {
+            uint32_t o = atomicAdd(&s_u32[4], 1u);
+            if (o < SEL_SMALL) { tk[o] = k; ti[o] = leaf_ids[(size_t)v.leaf_off + i]; }
+        }
+    }
+    __syncthreads();
+    if (!take_all_bucket && need > 0) {
+        uint32_t nb = s_u32[4] < SEL_SMALL ? s_u32[4] : SEL_SMALL, base = s_u32[3];
+        uint32_t np2 = next_pow2(nb);
+        for (uint32_t i = nb + tid; i < np2; i += 256) { tk[i] = ~0ull; ti[i] = ~0u; }
+        block_bitonic_sort<uint32_t>(tk, ti, np2);
+        for (uint32_t i = tid; i < need && i < nb; i += 256) {
+            cand_keys[v.cand_off + base + i] = tk[i];
+            cand_ids[v.cand_off + base + i] = ti[i];
+        }
     }
 }
 
