@@ -128,6 +128,7 @@ def main():
     args = parse()
     import torch
     import zebra_amd as za
+    from zebra_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,9 +150,9 @@ def main():
     if args.rows:
         wl["rows"] = args.rows
     S = world
-    rows_local = wl["rows"] // S
+    first_row, rows_local = sharding.shard_rows(wl["rows"], S, rank)
     wl["rows_local"] = rows_local
-    M_shard = max(wl["M"] // S, 2 * wl["k"] + 2) if S > 1 else wl["M"]
+    M_shard = sharding.per_shard_max_node_size(wl["M"], S, wl["k"]) if S > 1 else wl["M"]
     d, T, k, B = wl["dim"], wl["T"], wl["k"], wl["batch"]
     metric = make_metric(za, wl["metric"], parity=True)
     stream = torch.cuda.current_stream().cuda_stream
@@ -159,12 +160,12 @@ def main():
     # ---- setup (untimed): synthetic rows on the device, GPU forest build -------------------------------
     t_setup = time.perf_counter()
     ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=local_rank,
-                     id_base=rank * rows_local, reserve_rows=rows_local)
-    ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=rank * rows_local, kind=wl["kind"])
+                     id_base=first_row, reserve_rows=rows_local)
+    ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=first_row, kind=wl["kind"])
     t_fill = time.perf_counter() - t_setup
     ix.build()
     t_build = time.perf_counter() - t_setup - t_fill
-    n_total = rows_local * S
+    n_total = wl["rows"]
 
     n_batches = args.steps + args.warmup
     queries = []
@@ -187,9 +188,7 @@ def main():
     def step(q):
         ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
         if S > 1:  # the one exchange step of the path: every rank's top-k to every rank, then merge
-            dist.all_gather_into_tensor(g_ids, ids)
-            dist.all_gather_into_tensor(g_keys, keys)
-            dist.all_gather_into_tensor(g_counts, counts)
+            sharding.all_gather_topk(dist, ids, keys, counts, g_ids, g_keys, g_counts)
             za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
                                  m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
 
@@ -268,9 +267,7 @@ def main():
                                    r_counts.data_ptr(), stream)
             out = r_ids.clone()
             if S > 1:
-                dist.all_gather_into_tensor(g_ids, r_ids)
-                dist.all_gather_into_tensor(g_keys, r_keys)
-                dist.all_gather_into_tensor(g_counts, r_counts)
+                sharding.all_gather_topk(dist, r_ids, r_keys, r_counts, g_ids, g_keys, g_counts)
                 za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
                                      m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
                 out = m_ids.clone()
@@ -281,13 +278,13 @@ def main():
             got_parity = run(metric)
         # exact neighbours over the whole (sharded) set: local exact top-k, gathered, merged by distance
         Xt = _wrap_rows(torch, ix, rows_local, d, dev)
-        true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + rank * rows_local
+        true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + first_row
         if S > 1:
             # re-rank the union of the shards' exact top-k by true distance
             all_true = [torch.empty_like(true_local) for _ in range(S)]
             dist.all_gather(all_true, true_local)
             cand = torch.cat(all_true, 1)
-            dl = _true_dist(torch, Xt, q, cand - rank * rows_local, rows_local, wl["metric"])
+            dl = _true_dist(torch, Xt, q, cand - first_row, rows_local, wl["metric"])
             dist.all_reduce(dl, op=dist.ReduceOp.MIN)
             true_ids = torch.gather(cand, 1, torch.topk(dl, k, dim=1, largest=False).indices)
         else:

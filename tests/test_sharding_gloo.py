@@ -1,0 +1,95 @@
+"""The N > 1 path on CPU: two processes over the gloo backend run the same sharding / all-gather
+plumbing bench.py uses (zebra_amd/sharding.py).  No GPU here, so each rank's shard engine is the
+oracle (the checker standing in for zh_search_batch_device); what is under test is the host logic:
+row ranges, id_base, the rank-major [S,B,k] layout of the exchange, and that merging the gathered
+per-shard top-k equals the S-shard oracle run in one process (SURVEY s8e 'parity definition')."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import zebra_oracle as zo
+from zebra_amd import sharding
+
+N, D, M, T, K, B = 6001, 32, 64, 5, 10, 9
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_search(rank, world):
+    first, n = sharding.shard_rows(N, world, rank)
+    X = zo.synth_rows(n, D, row0=first)
+    f = zo.Forest.build(X, sharding.per_shard_max_node_size(M * world, world, K), T, seed=zo.SEED_INDEX + rank)
+    Q = zo.synth_queries(B, D, N)
+    ids, keys, counts = f.search_batch(Q, K, zo.L2SQ)
+    ids = np.where(np.arange(K)[None, :] < counts[:, None], ids + np.uint64(first), np.uint64(2**64 - 1))
+    keys = np.where(np.arange(K)[None, :] < counts[:, None], keys, np.uint64(2**64 - 1))
+    return ids, keys, counts
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids, keys, counts = _shard_search(rank, world)
+    t_ids = torch.from_numpy(ids.view(np.int64).copy())
+    t_keys = torch.from_numpy(keys.view(np.int64).copy())
+    t_counts = torch.from_numpy(counts.view(np.int32).copy())
+    g_ids = torch.empty((world, B, K), dtype=torch.int64)
+    g_keys = torch.empty((world, B, K), dtype=torch.int64)
+    g_counts = torch.empty((world, B), dtype=torch.int32)
+    sharding.all_gather_topk(dist, t_ids, t_keys, t_counts, g_ids, g_keys, g_counts)
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    np.savez(os.path.join(out, f"r{rank}.npz"), ids=g_ids.numpy().view(np.uint64), keys=g_keys.numpy().view(np.uint64),
+             counts=g_counts.numpy().view(np.uint32), tmax=t.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allgather_merge(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    # every rank holds the same gathered tensors, rank-major
+    for k in ("ids", "keys", "counts"):
+        assert (got[0][k] == got[1][k]).all()
+    assert got[0]["tmax"][0] == 2.0 and got[1]["tmax"][0] == 2.0
+    ref = [_shard_search(r, world) for r in range(world)]
+    for r in range(world):
+        assert (got[0]["ids"][r] == ref[r][0]).all() and (got[0]["keys"][r] == ref[r][1]).all()
+        assert (got[0]["counts"][r] == ref[r][2]).all()
+    merged = zo.merge_topk(got[0]["ids"], got[0]["keys"], got[0]["counts"], K)
+    # parity definition at S > 1: top-k of the union of the shards' candidate lists
+    Q = zo.synth_queries(B, D, N)
+    Xall = zo.synth_rows(N, D)
+    for b in range(B):
+        pool = sorted((int(ref[r][1][b, i]), int(ref[r][0][b, i])) for r in range(world) for i in range(ref[r][2][b]))[:K]
+        assert [(int(merged[1][b, i]), int(merged[0][b, i])) for i in range(merged[2][b])] == pool
+        # global ids really are rows of the unsharded set
+        for i in range(merged[2][b]):
+            gid = int(merged[0][b, i])
+            assert zo.distance(zo.L2SQ, 0, Xall[gid], Q[b]) == int(merged[1][b, i])
+
+
+def test_shard_arithmetic():
+    for total, world in ((100_000_000, 8), (10, 3), (7, 8), (1_000_000_000, 8)):
+        spans = [sharding.shard_rows(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(n for _, n in spans) == total
+        for (a, n), (b, _) in zip(spans, spans[1:]):
+            assert a + n == b
+    assert sharding.per_shard_max_node_size(32768, 8, 10) == 4096  # cfg4 per-shard 4096 / 15
+    assert sharding.per_shard_max_node_size(32768, 1, 10) == 32768
+    assert sharding.per_shard_max_node_size(64, 8, 100) == 202
