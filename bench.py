@@ -304,6 +304,16 @@ def main():
         recall = rec(got)
         recall_parity = rec(got_parity) if got_parity is not None else recall
 
+    # PCIe-inclusive rate through the host-buffer entry point (zh_search_batch): reported beside, never as, `value`
+    host_qps = None
+    if S == 1:
+        qh = [queries[args.warmup + i % max(args.steps, 1)].cpu().numpy() for i in range(3)]
+        ix.search_batch(qh[0], k, metric)
+        th = time.perf_counter()
+        for q_ in qh:
+            ix.search_batch(q_, k, metric)
+        host_qps = 3 * B / (time.perf_counter() - th)
+
     cpu = None
     if rank == 0 and S == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(wl, M_shard, args.cpu_seconds, za, torch, local_rank)
@@ -324,7 +334,7 @@ def main():
                          "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
                          "rows_loaded_per_launch": st["swept_rows_accum"] / max(st["timed_batches"], 1),
                          "bytes_per_launch": bytes_alg, "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "host_buffers_qps": host_qps,
             "stage_ms": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
             "setup_s": {"fill": t_fill, "build": t_build},
         }
