@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="debug: all ranks on cuda:0, exchange over gloo through host copies (RCCL needs one device per rank)")
     ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
     return ap.parse_args()
 
@@ -137,13 +139,18 @@ def main():
         if world == 1 and args.gpus > 1:
             print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
             sys.exit(2)
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.debug_single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     name = args.workload or ("cfg3" if world == 1 else "cfg4")
     wl = dict(WORKLOADS[name])
@@ -185,10 +192,21 @@ def main():
         m_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
         m_counts = torch.empty(B, dtype=torch.int32, device=dev)
 
+    def gather(a, b_, c):
+        if args.debug_single_device:  # gloo: through the host
+            ha, hb, hc = a.cpu(), b_.cpu(), c.cpu()
+            ga, gb, gc = torch.empty(g_ids.shape, dtype=a.dtype), torch.empty(g_keys.shape, dtype=a.dtype), \
+                torch.empty(g_counts.shape, dtype=c.dtype)
+            sharding.all_gather_topk(dist, ha, hb, hc, ga, gb, gc)
+            g_ids.copy_(ga), g_keys.copy_(gb), g_counts.copy_(gc)
+            torch.cuda.synchronize()
+        else:
+            sharding.all_gather_topk(dist, a, b_, c, g_ids, g_keys, g_counts)
+
     def step(q):
         ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
         if S > 1:  # the one exchange step of the path: every rank's top-k to every rank, then merge
-            sharding.all_gather_topk(dist, ids, keys, counts, g_ids, g_keys, g_counts)
+            gather(ids, keys, counts)
             za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
                                  m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
 
@@ -211,7 +229,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if S > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_single_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ix.stats()
@@ -267,7 +285,7 @@ def main():
                                    r_counts.data_ptr(), stream)
             out = r_ids.clone()
             if S > 1:
-                sharding.all_gather_topk(dist, r_ids, r_keys, r_counts, g_ids, g_keys, g_counts)
+                gather(r_ids, r_keys, r_counts)
                 za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
                                      m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
                 out = m_ids.clone()
@@ -281,11 +299,13 @@ def main():
         true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + first_row
         if S > 1:
             # re-rank the union of the shards' exact top-k by true distance
-            all_true = [torch.empty_like(true_local) for _ in range(S)]
-            dist.all_gather(all_true, true_local)
-            cand = torch.cat(all_true, 1)
-            dl = _true_dist(torch, Xt, q, cand - first_row, rows_local, wl["metric"])
+            xdev = "cpu" if args.debug_single_device else dev
+            all_true = [torch.empty_like(true_local, device=xdev) for _ in range(S)]
+            dist.all_gather(all_true, true_local.to(xdev))
+            cand = torch.cat(all_true, 1).to(dev)
+            dl = _true_dist(torch, Xt, q, cand - first_row, rows_local, wl["metric"]).to(xdev)
             dist.all_reduce(dl, op=dist.ReduceOp.MIN)
+            dl = dl.to(dev)
             true_ids = torch.gather(cand, 1, torch.topk(dl, k, dim=1, largest=False).indices)
         else:
             true_ids = true_local

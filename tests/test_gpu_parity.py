@@ -82,6 +82,8 @@ CASES = [
     (6000, 128, 300, 10, 10, 48, 1),   # SIFT-style integers: exact L2
     (3000, 100, 40, 5, 7, 17, 0),      # d not a multiple of 4 -> generic kernels
     (4000, 256, 12, 6, 10, 9, 0),      # leaves ~ k: backup walks with n - k
+    (30000, 64, 9000, 3, 100, 16, 0),  # leaves longer than the select kernel's LDS buffer
+    (20000, 32, 20001, 2, 10, 8, 0),   # one 20000-row leaf per tree
 ]
 
 
@@ -106,6 +108,27 @@ def test_search_bit_exact_with_injected_forest(za, n, d, M, T, k, B, kind):
     r = ix.search(Q[0], k, za.L2SquaredDistance())
     oi, ok = f.search(Q[0], k, zo.L2SQ)
     assert r == list(zip(oi.tolist(), ok.tolist()))
+
+
+def test_ties_across_the_cut(za):
+    """hundreds of equal keys straddling top_k: ids must come out in ascending order (tie-break on id)"""
+    d = 16
+    base = zo.synth_rows(40, d)
+    X = np.concatenate([base[:20], np.repeat(base[20:21], 1500, axis=0), base[21:], np.repeat(base[5:6], 700, axis=0)])
+    n = X.shape[0]
+    Q = np.stack([base[20], base[5], base[3]])
+    for M in (4000, 64):
+        f = zo.Forest.build(X, M, 3, seed=8)
+        ix = za.LSHIndex(d, za.LSHIndexOptions(M, 3), seed=8)
+        ix.add(X)
+        assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+        for k in (10, 100, 1000):
+            for name, m, om, omode in metrics(za):
+                ids, keys, counts = ix.search_batch(Q, k, m)
+                oi, ok, oc = f.search_batch(Q, k, om, omode)
+                assert (counts == oc).all(), (M, k, name)
+                for b in range(3):
+                    assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all(), (M, k, name, b)
 
 
 @pytest.mark.parametrize("levels", [0, 1, 3, 100])

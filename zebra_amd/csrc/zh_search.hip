@@ -13,6 +13,8 @@
 //   distance sums : element e -> accumulator (e mod 256) [lane = (e mod 256)/4, component e mod 4],
 //                   ascending e, fma; per lane ((x+y)+(z+w)); wave xor-butterfly 1,2,4,8,16,32
 //   ordering      : unsigned (key, id)
+#include <cstdlib>
+
 #include "zh_internal.h"
 
 #define WAVE 64
@@ -454,14 +456,23 @@ struct RowVec {
     static constexpr int NV = NJ + (REM4 ? 1 : 0);
 };
 
-template <int D>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld16(const float4 *p) {
+    if (NT) {  // streamed once: non-temporal hint (global_load_dwordx4 ... nt)
+        f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return *p;
+}
+template <int D, bool NT = false>
 __device__ __forceinline__ void load_row(const float *__restrict__ row, uint32_t lane, float4 *v) {
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
 #pragma unroll
-    for (int j = 0; j < RowVec<D>::NJ; j++) v[j] = r4[lane + 64 * j];
+    for (int j = 0; j < RowVec<D>::NJ; j++) v[j] = ld16<NT>(r4 + lane + 64 * j);
     if (RowVec<D>::REM4) {
         v[RowVec<D>::NJ] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < (uint32_t)RowVec<D>::REM4) v[RowVec<D>::NJ] = r4[lane + 64 * RowVec<D>::NJ];
+        if (lane < (uint32_t)RowVec<D>::REM4) v[RowVec<D>::NJ] = ld16<NT>(r4 + lane + 64 * RowVec<D>::NJ);
     }
 }
 
@@ -487,8 +498,6 @@ __device__ __forceinline__ void row_sums(const float4 *v, const float4 *q, uint3
     s0 = wave_sum_canonical((a.x + a.y) + (a.z + a.w));
     s1 = COSINE ? wave_sum_canonical((c.x + c.y) + (c.z + c.w)) : 0.0f;
 }
-
-#define SWEEP_RG 4
 
 // one row against the (up to ZH_GROUP) queries of its group; a2 (the stored row's norm) is shared
 template <int D, bool COSINE>
@@ -533,7 +542,7 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
 }
 
 // D > 0: compile-time dimension (multiple of 4); D == 0: runtime d, any value (slow path)
-template <int D, bool COSINE>
+template <int D, bool COSINE, int SWEEP_RG = 4, bool NT = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X, uint32_t d,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
             for (int r = 0; r < SWEEP_RG; r++) {
                 uint32_t i = i0 + r < cnt ? i0 + r : cnt - 1;
                 uint32_t id = __builtin_amdgcn_readlane(my_id, i);
-                load_row<DD>(X + (size_t)id * DD, lane, v[r]);
+                load_row<DD, NT>(X + (size_t)id * DD, lane, v[r]);
             }
 #pragma unroll
             for (int r = 0; r < SWEEP_RG; r++) {
@@ -632,12 +641,17 @@ static hipError_t launch_sweep_d(const float *dX, uint32_t d, const float *dQ, c
     uint64_t waves = (R_grouped + 63) / 64;
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (metric == ZH_COSINE)
-        hipLaunchKernelGGL((sweep_kernel<D, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dGroups,
-                           dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys);
-    else
-        hipLaunchKernelGGL((sweep_kernel<D, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ, dGroups,
-                           dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys);
+#define ZH_SW_LAUNCH(COS, RG, NTV)                                                                              \
+    hipLaunchKernelGGL((sweep_kernel<D, COS, RG, NTV>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,   \
+                       dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys)
+    // rows are streamed once per batch: non-temporal loads (+1.3 % measured, profiles/); ZH_SWEEP_VARIANT=1
+    // switches them off for A/B runs.  Rows in flight (2/4/8) made no measurable difference: 4.
+    static const int variant = [] { const char *e = getenv("ZH_SWEEP_VARIANT"); return e ? atoi(e) : 0; }();
+    const bool cosv = metric == ZH_COSINE;
+    if (variant == 1) { if (cosv) ZH_SW_LAUNCH(true, 4, false); else ZH_SW_LAUNCH(false, 4, false); }
+    else if (cosv) ZH_SW_LAUNCH(true, 4, true);
+    else ZH_SW_LAUNCH(false, 4, true);
+#undef ZH_SW_LAUNCH
     return hipGetLastError();
 }
 
@@ -746,34 +760,25 @@ __device__ __forceinline__ void select_slow(const ZhVisit &v, const uint32_t *__
     }
 }
 
-__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits,
-                                                      const uint32_t *__restrict__ leaf_ids,
-                                                      const uint64_t *__restrict__ keys,
-                                                      uint64_t *__restrict__ cand_keys,
-                                                      uint32_t *__restrict__ cand_ids) {
-    __shared__ uint64_t sk[ZH_SORT_N];
-    __shared__ __attribute__((aligned(16))) uint32_t si[ZH_SORT_N];  // slow path ids; fast path: small-sort buffers + histogram
-    __shared__ uint32_t s_u32[8];
-    const ZhVisit v = visits[blockIdx.x];
+// KEY(i): the visit's i-th key, from the LDS copy when the leaf fits it, else straight from the
+// (L2 / Infinity-Cache resident) key scratch -- a few 8-B passes against the 4*d bytes the sweep read
+template <bool IN_LDS>
+__device__ __forceinline__ void select_fast(const ZhVisit &v, const uint32_t *__restrict__ leaf_ids,
+                                            const uint64_t *__restrict__ gkeys, uint64_t *__restrict__ cand_keys,
+                                            uint32_t *__restrict__ cand_ids, uint64_t *sk, uint32_t *si,
+                                            uint32_t *s_u32, bool &need_slow) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (v.take == 0) return;
-    if (v.take >= v.len) {
-        for (uint32_t i = tid; i < v.len; i += 256) {
-            cand_keys[v.cand_off + i] = keys[v.row_off + i];
-            cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
-        }
-        return;
-    }
-    if (v.len > ZH_SORT_N) { select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si); return; }
-    // fast-path carve-up of si[]: tk (SEL_SMALL u64) | ti (SEL_SMALL u32) | hist (256 u32) | wmin/wmax
+    // carve-up of si[]: tk (SEL_SMALL u64) | ti (SEL_SMALL u32) | hist (256 u32) | wmin/wmax (8 u64)
     uint64_t *tk = reinterpret_cast<uint64_t *>(si);
     uint32_t *ti = si + 2 * SEL_SMALL;
     uint32_t *hist = si + 3 * SEL_SMALL;
-    uint64_t *wred = reinterpret_cast<uint64_t *>(si + 3 * SEL_SMALL + 256);  // 8 u64
+    uint64_t *wred = reinterpret_cast<uint64_t *>(si + 3 * SEL_SMALL + 256);
+    const uint64_t *kp = gkeys + v.row_off;
+#define SEL_KEY(i) (IN_LDS ? sk[i] : kp[i])
     uint64_t kmin = ~0ull, kmax = 0;
     for (uint32_t i = tid; i < v.len; i += 256) {
-        uint64_t k = keys[v.row_off + i];
-        sk[i] = k;
+        uint64_t k = kp[i];
+        if (IN_LDS) sk[i] = k;
         kmin = k < kmin ? k : kmin;
         kmax = k > kmax ? k : kmax;
     }
@@ -788,17 +793,16 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
     for (int w = 1; w < 4; w++) { lo = wred[w] < lo ? wred[w] : lo; hi = wred[4 + w] > hi ? wred[4 + w] : hi; }
     uint32_t need = v.take;   // how many to take from [lo, hi]; every key < lo is already taken
     uint32_t inb = v.len;     // keys inside [lo, hi]
-    bool take_all_bucket = false;
     while (inb > SEL_SMALL && inb != need) {
         uint64_t range = hi - lo;
-        if (range == 0) break;  // > SEL_SMALL equal keys: slow path below
+        if (range == 0) break;  // > SEL_SMALL equal keys: slow path
         int sh = 64 - __clzll((long long)range) - 8;
         if (sh < 0) sh = 0;
         __syncthreads();
         hist[tid] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < v.len; i += 256) {
-            uint64_t k = sk[i];
+            uint64_t k = SEL_KEY(i);
             if (k >= lo && k <= hi) atomicAdd(&hist[(uint32_t)((k - lo) >> sh)], 1u);
         }
         __syncthreads();
@@ -829,15 +833,15 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
         lo = nlo;
         hi = nhi < hi ? nhi : hi;
     }
-    if (inb > SEL_SMALL && inb != need) { __syncthreads(); select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si); return; }
-    take_all_bucket = (inb == need);
+    if (inb > SEL_SMALL && inb != need) { need_slow = true; return; }
+    const bool take_all_bucket = (inb == need);
     // emit: keys < lo (and the whole bucket when it is taken whole) straight to the pool; otherwise the
     // bucket's members go to the small sort buffer
     __syncthreads();
     if (tid == 0) { s_u32[3] = 0; s_u32[4] = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < v.len; i += 256) {
-        uint64_t k = sk[i];
+        uint64_t k = SEL_KEY(i);
         bool below = k < lo || (take_all_bucket && k <= hi);
         bool inside = !take_all_bucket && k >= lo && k <= hi;
         if (below) {
@@ -859,6 +863,34 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
             cand_keys[v.cand_off + base + i] = tk[i];
             cand_ids[v.cand_off + base + i] = ti[i];
         }
+    }
+#undef SEL_KEY
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits,
+                                                      const uint32_t *__restrict__ leaf_ids,
+                                                      const uint64_t *__restrict__ keys,
+                                                      uint64_t *__restrict__ cand_keys,
+                                                      uint32_t *__restrict__ cand_ids) {
+    __shared__ uint64_t sk[ZH_SORT_N];
+    __shared__ __attribute__((aligned(16))) uint32_t si[ZH_SORT_N];  // slow path ids; fast path: small-sort buffers + histogram
+    __shared__ uint32_t s_u32[8];
+    const ZhVisit v = visits[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (v.take == 0) return;
+    if (v.take >= v.len) {
+        for (uint32_t i = tid; i < v.len; i += 256) {
+            cand_keys[v.cand_off + i] = keys[v.row_off + i];
+            cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
+        }
+        return;
+    }
+    bool need_slow = false;
+    if (v.len <= ZH_SORT_N) select_fast<true>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
+    else select_fast<false>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
+    if (need_slow) {  // a large group of equal keys straddles the cut: order it by id the slow way
+        __syncthreads();
+        select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si);
     }
 }
 
