@@ -127,8 +127,9 @@ ZH_API int zh_index_clear(zh_index *idx); /* drops vectors AND trees (what lsh.r
 /* ---- insert --------------------------------------------------------------------------------- */
 /* LSHIndex::add: rows is n x dim row-major host memory.  If the index has no trees the forest is
  * built over everything stored so far plus these rows (build_index); otherwise the rows descend
- * the existing trees and split full leaves (insert, lsh.rs:350-382).  out_row_ids (may be NULL)
- * receives id_base + row for each new row. */
+ * the existing trees and split full leaves (insert, lsh.rs:350-382) -- as the sequential execution
+ * "one row after another, each into every tree" of the reference's racy par_iter (lsh.rs:445-462).
+ * out_row_ids (may be NULL) receives id_base + row for each new row. */
 ZH_API int zh_index_add(zh_index *idx, const float *rows, size_t n, uint64_t *out_row_ids);
 /* staged loading for large shards: append without building, then zh_index_build once */
 ZH_API int zh_index_append(zh_index *idx, const float *rows, size_t n, uint64_t *out_row_ids);

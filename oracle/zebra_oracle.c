@@ -291,8 +291,11 @@ ZO_EXPORT void zo_make_hyperplane(const float *a, const float *b, uint32_t d, fl
 }
 
 static int32_t build_node(zo_forest *f, const float *X, uint32_t tree, uint64_t path, int depth, uint32_t *ids,
-                          uint32_t n, uint32_t *scratch) {
-    uint32_t me = new_node(f);
+                          uint32_t n, uint32_t *scratch);
+
+/* (re)build the subtree of an existing node index `me` over ids (build_a_tree, lsh.rs:250-267) */
+static int32_t build_node_into(zo_forest *f, uint32_t me, const float *X, uint32_t tree, uint64_t path, int depth,
+                               uint32_t *ids, uint32_t n, uint32_t *scratch) {
     f->depth[me] = (uint8_t)depth;
     if (n < f->M || depth >= ZO_MAX_DEPTH) { /* lsh.rs:251-252 */
         f->plane[me] = -1;
@@ -338,6 +341,49 @@ static int32_t build_node(zo_forest *f, const float *X, uint32_t tree, uint64_t 
     f->left[me] = l;
     f->right[me] = r;
     return (int32_t)me;
+}
+
+static int32_t build_node(zo_forest *f, const float *X, uint32_t tree, uint64_t path, int depth, uint32_t *ids,
+                          uint32_t n, uint32_t *scratch) {
+    return build_node_into(f, new_node(f), X, tree, path, depth, ids, n, scratch);
+}
+
+/* lsh.rs:350-382 insert: descend by point_is_above; a leaf takes the id while len + 1 <= M, else the node is
+ * rebuilt by build_a_tree over (leaf ids + id), sampling its hyperplanes from the database as it is NOW */
+static void insert_one(zo_forest *f, const float *X, uint32_t tree, uint32_t id) {
+    uint32_t node = f->roots[tree];
+    uint64_t path = 1;
+    int depth = 0;
+    const float *x = X + (size_t)id * f->d;
+    while (f->plane[node] >= 0) {
+        int32_t p = f->plane[node];
+        int above = zo_point_is_above(f->planes + (size_t)p * f->d, f->consts[p], x, f->d);
+        node = (uint32_t)(above ? f->right[node] : f->left[node]);
+        path = 2 * path + (above ? 1 : 0);
+        depth++;
+    }
+    uint32_t off = (uint32_t)f->left[node], len = (uint32_t)f->right[node];
+    uint32_t *ids = malloc((len + 1) * sizeof(uint32_t));
+    memcpy(ids, f->leaf_ids + off, len * sizeof(uint32_t));
+    ids[len] = id;
+    if (len + 1 > f->M) { /* lsh.rs:368-377 */
+        uint32_t *scratch = malloc((size_t)(len + 1) * 2 * sizeof(uint32_t));
+        build_node_into(f, node, X, tree, path, depth, ids, len + 1, scratch);
+        free(scratch);
+    } else { /* lsh.rs:369: push */
+        f->left[node] = (int32_t)push_leaf(f, ids, len + 1);
+        f->right[node] = (int32_t)(len + 1);
+    }
+    free(ids);
+}
+
+/* lsh.rs:445-462, as ONE admissible sequential execution of its racy par_iter: rows n_prev .. n_prev+n_new-1
+ * of X are added one after another, each into every tree, the database growing by one row each time */
+ZO_EXPORT void zo_forest_insert(zo_forest *f, const float *X, uint64_t n_prev, uint64_t n_new) {
+    for (uint64_t r = 0; r < n_new; r++) {
+        f->n_rows = n_prev + r + 1;
+        for (uint32_t t = 0; t < f->T; t++) insert_one(f, X, t, (uint32_t)(n_prev + r));
+    }
 }
 
 /* lsh.rs:411-429 build_index: T independent trees over all ids */

@@ -56,6 +56,7 @@ def lib():
         L.zo_forest_build.restype = vp
         L.zo_forest_from_arrays.argtypes = [u64, u32, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.zo_forest_from_arrays.restype = vp
+        L.zo_forest_insert.argtypes = [vp, vp, u64, u64]
         L.zo_forest_free.argtypes = [vp]
         L.zo_forest_sizes.argtypes = [vp, vp, vp, vp]
         L.zo_forest_export.argtypes = [vp] * 8
@@ -171,6 +172,13 @@ class Forest:
         h = lib().zo_forest_from_arrays(n, d, M, roots.size, plane.size, _p(plane), _p(left), _p(right), _p(roots),
                                         consts.size, _p(planes), _p(consts), leaf_ids.size, _p(leaf_ids))
         return cls(h, X, n, d, M, roots.size)
+
+    def insert(self, X_all, n_prev):
+        """LSHIndex::add on an index that already has trees (lsh.rs:445-462): X_all = old rows + new rows"""
+        X_all = _f32(X_all)
+        lib().zo_forest_insert(self._h, _p(X_all), n_prev, X_all.shape[0] - n_prev)
+        self.X = X_all
+        self.n_rows = X_all.shape[0]
 
     def __del__(self):
         if getattr(self, "_h", None):

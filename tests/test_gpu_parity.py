@@ -177,6 +177,59 @@ def test_gpu_build_equals_oracle_build(za, n, d, M, T):
     assert (counts_ == oc).all() and (ids_ == oi).all() and (keys_ == ok).all()
 
 
+# ------------------------------------------------- lsh.rs:350-382, 445-462 (incremental insert)
+@pytest.mark.parametrize("d,M,T,steps", [
+    (16, 8, 4, [100, 1, 299]),        # single row, then a burst that splits the same leaves several times
+    (128, 64, 5, [2000, 500, 37]),
+    (32, 5, 15, [300, 300]),          # reference defaults
+    (16, 8, 2, [3, 27, 100]),         # roots are leaves at first (fewer rows than max_node_size)
+    (768, 300, 3, [1500, 900]),
+])
+def test_incremental_add_equals_oracle_insert(za, d, M, T, steps):
+    total = sum(steps)
+    X = zo.synth_rows(total, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=31)
+    n = steps[0]
+    assert ix.add(X[:n]).tolist() == list(range(n))
+    f = zo.Forest.build(X[:n], M, T, seed=31)
+    for more in steps[1:]:
+        ids = ix.add(X[n:n + more])  # trees exist -> insert path
+        assert ids.tolist() == list(range(n, n + more))
+        f.insert(X[:n + more], n)
+        n += more
+        g = ix.get_forest()
+        assert zo.canonical_forest(g, d) == zo.canonical_forest(f.arrays(), d)
+        leaves = g["plane"] < 0
+        assert (g["right"][leaves] <= M).all()
+    assert len(ix) == total
+    Q = zo.synth_queries(12, d, total)
+    for name, m, om, omode in metrics(za):
+        i_, k_, c_ = ix.search_batch(Q, 10, m)
+        oi, ok, oc = f.search_batch(Q, 10, om, omode)
+        assert (c_ == oc).all() and (i_ == oi).all() and (k_ == ok).all(), name
+    # every inserted row is found at distance 0
+    r = ix.search(X[total - 1], 1, za.L2SquaredDistance())
+    assert r[0] == (total - 1, 0)
+
+
+def test_incremental_add_of_duplicates_and_compaction(za):
+    d, M = 8, 6
+    base = zo.synth_rows(50, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, 2), seed=2)
+    ix.add(base)
+    f = zo.Forest.build(base, M, 2, seed=2)
+    X = base
+    for r in range(12):  # many small adds of the same vector: unsplittable leaves, relocation garbage, compaction
+        X = np.concatenate([X, np.repeat(base[7:8], 9, axis=0)])
+        ix.add(X[-9:])
+        f.insert(X, X.shape[0] - 9)
+        assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+    assert ix.get_forest()["leaf_ids"].size <= 2 * 2 * X.shape[0] + 1024
+    i_, k_, c_ = ix.search_batch(base[:4], 20, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(base[:4], 20, zo.L2SQ)
+    assert (c_ == oc).all() and (i_ == oi).all() and (k_ == ok).all()
+
+
 def test_synthetic_generators_bit_exact(za):
     n, d = 3000, 384
     ix = za.LSHIndex(d, za.LSHIndexOptions(64, 2))

@@ -285,3 +285,52 @@ def test_synthetic_generator_moments():
     assert (S == np.round(S)).all() and S.min() >= 0 and S.max() <= 255
     # any row can be regenerated anywhere
     assert (zo.synth_rows(5, 64, row0=100) == X[100:105]).all()
+
+
+def test_incremental_insert_rules():
+    """lsh.rs:350-382: a leaf takes ids while len + 1 <= max_node_size (so it may reach M, one more than a
+    built leaf), the next id rebuilds the node; every id stays in exactly one leaf per tree; searching finds
+    the inserted rows."""
+    d, M, T = 16, 8, 4
+    X = zo.synth_rows(400, d)
+    f = zo.Forest.build(X[:100], M, T, seed=21)
+    f.insert(X[:101], 100)
+    a = f.arrays()
+    for t in range(T):  # the new id is in exactly one leaf of every tree
+        n, stack, found = int(a["roots"][t]), [], 0
+        stack = [n]
+        while stack:
+            n = stack.pop()
+            if a["plane"][n] < 0:
+                ids = a["leaf_ids"][a["left"][n]:a["left"][n] + a["right"][n]]
+                found += int((ids == 100).sum())
+                assert a["right"][n] <= M
+            else:
+                stack += [int(a["left"][n]), int(a["right"][n])]
+        assert found == 1
+    f.insert(X, 101)
+    a = f.arrays()
+    seen = []
+    n, stack = 0, [int(a["roots"][0])]
+    while stack:
+        n = stack.pop()
+        if a["plane"][n] < 0:
+            seen += a["leaf_ids"][a["left"][n]:a["left"][n] + a["right"][n]].tolist()
+            assert a["right"][n] <= M
+        else:
+            p = a["plane"][n]
+            stack += [int(a["left"][n]), int(a["right"][n])]
+    assert sorted(seen) == list(range(400))
+    for i in (0, 100, 250, 399):
+        ids, keys = f.search(X[i], 3, zo.L2SQ)
+        assert ids[0] == i and keys[0] == 0
+    # inserting into a forest whose roots are leaves (fewer rows than M at build time)
+    g = zo.Forest.build(X[:3], M, 2, seed=5)
+    g.insert(X[:30], 3)
+    ids, _ = g.search(X[17], 1, zo.L2SQ)
+    assert ids[0] == 17
+    # deterministic
+    h = zo.Forest.build(X[:100], M, T, seed=21)
+    h.insert(X[:101], 100)
+    h.insert(X, 101)
+    assert zo.canonical_forest(h.arrays(), d) == zo.canonical_forest(f.arrays(), d)

@@ -91,6 +91,7 @@ struct zh_index {
     std::vector<int32_t> h_plane, h_left, h_right;
     std::vector<uint32_t> h_roots;
     std::vector<uint32_t> planes_below_level;  // [L] = planes whose level < L ; planes are stored level-major
+    std::vector<uint32_t> h_leaf_ids;          // host mirror of leaf_ids, materialised by the first incremental add
     uint32_t max_leaf_len = 0;
 
     // per-batch workspace
@@ -183,6 +184,7 @@ static void free_forest(zh_index *ix) {
     ix->n_leaf_ids = 0;
     ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
     ix->planes_below_level.clear();
+    ix->h_leaf_ids.clear();
     ix->max_leaf_len = 0;
 }
 
@@ -432,60 +434,46 @@ static void sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint64_t n_
     if (*j >= *i) (*j)++;
 }
 
-struct ActiveNode {
-    uint32_t node, tree, len;
-    uint64_t seg_start, path;
+struct ActiveNode {   // a node whose id list (a segment of a perm array) is to be split
+    uint32_t node, tree, len, depth;
+    uint64_t seg_start, path, n_sample;  // n_sample: size of the database the two sample rows are drawn from
 };
 
-static int build_forest_locked(zh_index *ix) {
-    const uint64_t N = ix->n_rows;
-    const uint32_t T = ix->opt.num_trees, M = ix->opt.max_node_size, d = ix->opt.dim;
-    int rc;
-    hipStreamSynchronize(ix->stream);
-    free_forest(ix);
-    if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
+// Split every active node, level after level, until all descendants are leaves (build_a_tree,
+// lsh.rs:250-267).  d_perm holds the id lists as segments; leaves become runs of d_perm and get
+// offset leaf_base + position.  New planes are appended to ix->planes from index n_planes on.
+static int grow_segments(zh_index *ix, uint32_t *d_perm, uint64_t perm_len, std::vector<ActiveNode> active,
+                         uint64_t leaf_base, uint32_t &n_planes, bool record_levels) {
+    const uint32_t M = ix->opt.max_node_size, d = ix->opt.dim;
     hipStream_t s = ix->stream;
-    const uint64_t total = (uint64_t)T * N;
-    DevBuf perm, tmp, flags, dNodes, dChunks, dChunkAbove, dChunkScan, dScanTmp, dNodeAbove;
+    int rc;
+    DevBuf tmp, flags, dNodes, dChunks, dChunkAbove, dChunkScan, dScanTmp, dNodeAbove;
     struct Guard {
         std::vector<DevBuf *> v;
         ~Guard() { for (auto *b : v) b->release(); }
     } guard;
     guard.v = {&tmp, &flags, &dNodes, &dChunks, &dChunkAbove, &dChunkScan, &dScanTmp, &dNodeAbove};
-    if ((rc = perm.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
-    if (total) {
-        if ((rc = tmp.ensure(total * 4))) { perm.release(); return rc; }
-        if ((rc = flags.ensure(total))) { perm.release(); return rc; }
-        hipError_t e = zh_launch_iota_perm(perm.as<uint32_t>(), N, T, s);
-        if (e != hipSuccess) { perm.release(); return fail(ZH_EHIP, "iota_perm: %s", hipGetErrorString(e)); }
-    }
-    std::vector<ActiveNode> active, next;
-    ix->planes_below_level.assign(1, 0);
+    if (active.empty()) return ZH_OK;
+    if ((rc = tmp.ensure(std::max<uint64_t>(perm_len, 1) * 4))) return rc;
+    if ((rc = flags.ensure(std::max<uint64_t>(perm_len, 1)))) return rc;
     auto new_node = [&]() { ix->h_plane.push_back(-1); ix->h_left.push_back(0); ix->h_right.push_back(0); return (uint32_t)(ix->h_plane.size() - 1); };
     auto make_leaf = [&](uint32_t node, uint64_t start, uint32_t len) {
-        ix->h_plane[node] = -1; ix->h_left[node] = (int32_t)(uint32_t)start; ix->h_right[node] = (int32_t)len;
+        ix->h_plane[node] = -1; ix->h_left[node] = (int32_t)(uint32_t)(leaf_base + start); ix->h_right[node] = (int32_t)len;
     };
-    for (uint32_t t = 0; t < T; t++) {
-        uint32_t n = new_node();
-        ix->h_roots.push_back(n);
-        if (N < M) make_leaf(n, (uint64_t)t * N, (uint32_t)N);  // lsh.rs:251-252 (depth 0 < ZH_MAX_DEPTH)
-        else active.push_back({n, t, (uint32_t)N, (uint64_t)t * N, 1});
-    }
-    uint32_t n_planes = 0;
+    std::vector<ActiveNode> next;
     std::vector<ZhBuildNode> hn;
     std::vector<ZhBuildChunk> hc;
     std::vector<uint32_t> h_above;
-    auto cleanup_fail = [&](int code) { perm.release(); free_forest(ix); return code; };
-    for (uint32_t depth = 0; !active.empty(); depth++) {
+    for (uint32_t round = 0; !active.empty(); round++) {
         hn.clear(); hc.clear();
         for (size_t i = 0; i < active.size(); i++) {
             const ActiveNode &a = active[i];
             ZhBuildNode bn;
             bn.seg_start = a.seg_start; bn.len = a.len; bn.plane = n_planes + (uint32_t)i;
             uint64_t si, sj;
-            sample_pair(ix->opt.seed, a.tree, a.path, N, &si, &sj);
-            bn.sample_a = N >= 1 ? si : ~0ull;   // lsh.rs:203-220: a missing sample decodes to the zero vector
-            bn.sample_b = N >= 2 ? sj : ~0ull;
+            sample_pair(ix->opt.seed, a.tree, a.path, a.n_sample, &si, &sj);
+            bn.sample_a = a.n_sample >= 1 ? si : ~0ull;   // lsh.rs:203-220: a missing sample decodes to the zero vector
+            bn.sample_b = a.n_sample >= 2 ? sj : ~0ull;
             bn.first_chunk = (uint32_t)hc.size();
             bn.n_chunks = (a.len + 255) / 256;
             for (uint32_t c = 0; c < bn.n_chunks; c++) {
@@ -497,24 +485,25 @@ static int build_forest_locked(zh_index *ix) {
             hn.push_back(bn);
         }
         const uint32_t na = (uint32_t)hn.size(), nc = (uint32_t)hc.size();
-        if ((rc = ix->planes.ensure((size_t)(n_planes + na) * d * 4, true, s))) return cleanup_fail(rc);
-        if ((rc = ix->consts.ensure((size_t)(n_planes + na) * 4, true, s))) return cleanup_fail(rc);
-        if ((rc = dNodes.ensure(na * sizeof(ZhBuildNode)))) return cleanup_fail(rc);
-        if ((rc = dChunks.ensure(nc * sizeof(ZhBuildChunk)))) return cleanup_fail(rc);
-        if ((rc = dChunkAbove.ensure((size_t)nc * 4))) return cleanup_fail(rc);
-        if ((rc = dChunkScan.ensure((size_t)(nc + 1) * 4))) return cleanup_fail(rc);
-        if ((rc = dScanTmp.ensure(((size_t)nc / 1024 + 4) * 4))) return cleanup_fail(rc);
-        if ((rc = dNodeAbove.ensure((size_t)na * 4))) return cleanup_fail(rc);
+        if ((rc = ix->planes.ensure((size_t)(n_planes + na) * d * 4, true, s))) return rc;
+        if ((rc = ix->consts.ensure((size_t)(n_planes + na) * 4, true, s))) return rc;
+        if ((rc = dNodes.ensure(na * sizeof(ZhBuildNode)))) return rc;
+        if ((rc = dChunks.ensure(std::max<uint32_t>(nc, 1) * sizeof(ZhBuildChunk)))) return rc;
+        if ((rc = dChunkAbove.ensure((size_t)std::max<uint32_t>(nc, 1) * 4))) return rc;
+        if ((rc = dChunkScan.ensure((size_t)(nc + 1) * 4))) return rc;
+        if ((rc = dScanTmp.ensure(((size_t)nc / 1024 + 4) * 4))) return rc;
+        if ((rc = dNodeAbove.ensure((size_t)na * 4))) return rc;
         hipError_t e = hipMemcpyAsync(dNodes.p, hn.data(), na * sizeof(ZhBuildNode), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(dChunks.p, hc.data(), nc * sizeof(ZhBuildChunk), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && nc) e = hipMemcpyAsync(dChunks.p, hc.data(), nc * sizeof(ZhBuildChunk), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(dNodeAbove.p, 0, (size_t)na * 4, s);
         if (e == hipSuccess) e = zh_launch_make_planes(ix->X.as<float>(), d, dNodes.as<ZhBuildNode>(), na, ix->planes.as<float>(), ix->consts.as<float>(), s);
-        if (e == hipSuccess) e = zh_launch_classify(ix->X.as<float>(), d, perm.as<uint32_t>(), dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, ix->planes.as<float>(), ix->consts.as<float>(), flags.as<uint8_t>(), dChunkAbove.as<uint32_t>(), s);
+        if (e == hipSuccess) e = zh_launch_classify(ix->X.as<float>(), d, d_perm, dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, ix->planes.as<float>(), ix->consts.as<float>(), flags.as<uint8_t>(), dChunkAbove.as<uint32_t>(), s);
         if (e == hipSuccess) e = zh_launch_scan_u32(dChunkAbove.as<uint32_t>(), dChunkScan.as<uint32_t>(), nc, dScanTmp.as<uint32_t>(), s);
-        if (e == hipSuccess) e = zh_launch_scatter(perm.as<uint32_t>(), tmp.as<uint32_t>(), dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, flags.as<uint8_t>(), dChunkScan.as<uint32_t>(), dNodeAbove.as<uint32_t>(), s);
+        if (e == hipSuccess) e = zh_launch_scatter(d_perm, tmp.as<uint32_t>(), dNodes.as<ZhBuildNode>(), dChunks.as<ZhBuildChunk>(), nc, flags.as<uint8_t>(), dChunkScan.as<uint32_t>(), dNodeAbove.as<uint32_t>(), s);
         h_above.resize(na);
         if (e == hipSuccess) e = hipMemcpyAsync(h_above.data(), dNodeAbove.p, (size_t)na * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return cleanup_fail(fail(ZH_EHIP, "forest build level %u: %s", depth, hipGetErrorString(e)));
+        if (e != hipSuccess) return fail(ZH_EHIP, "forest build round %u: %s", round, hipGetErrorString(e));
         next.clear();
         for (size_t i = 0; i < active.size(); i++) {
             const ActiveNode &a = active[i];
@@ -523,19 +512,47 @@ static int build_forest_locked(zh_index *ix) {
             ix->h_plane[a.node] = (int32_t)(n_planes + i);
             ix->h_left[a.node] = (int32_t)l;   // below  (lsh.rs:262)
             ix->h_right[a.node] = (int32_t)r;  // above  (lsh.rs:263)
-            bool child_can_split = depth + 1 < ZH_MAX_DEPTH;
-            if (nB >= M && child_can_split) next.push_back({l, a.tree, nB, a.seg_start, 2 * a.path});
+            bool child_can_split = a.depth + 1 < ZH_MAX_DEPTH;
+            if (nB >= M && child_can_split) next.push_back({l, a.tree, nB, a.depth + 1, a.seg_start, 2 * a.path, a.n_sample});
             else make_leaf(l, a.seg_start, nB);
-            if (nA >= M && child_can_split) next.push_back({r, a.tree, nA, a.seg_start + nB, 2 * a.path + 1});
+            if (nA >= M && child_can_split) next.push_back({r, a.tree, nA, a.depth + 1, a.seg_start + nB, 2 * a.path + 1, a.n_sample});
             else make_leaf(r, a.seg_start + nB, nA);
         }
         n_planes += na;
-        ix->planes_below_level.push_back(n_planes);
+        if (record_levels) ix->planes_below_level.push_back(n_planes);
         active.swap(next);
     }
+    return ZH_OK;
+}
+
+static int build_forest_locked(zh_index *ix) {
+    const uint64_t N = ix->n_rows;
+    const uint32_t T = ix->opt.num_trees, M = ix->opt.max_node_size;
+    int rc;
+    hipStreamSynchronize(ix->stream);
+    free_forest(ix);
+    if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
+    const uint64_t total = (uint64_t)T * N;
+    DevBuf perm;
+    if ((rc = perm.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
+    if (total) {
+        hipError_t e = zh_launch_iota_perm(perm.as<uint32_t>(), N, T, ix->stream);
+        if (e != hipSuccess) { perm.release(); return fail(ZH_EHIP, "iota_perm: %s", hipGetErrorString(e)); }
+    }
+    std::vector<ActiveNode> active;
+    ix->planes_below_level.assign(1, 0);
+    for (uint32_t t = 0; t < T; t++) {
+        ix->h_plane.push_back(-1); ix->h_left.push_back(0); ix->h_right.push_back(0);
+        uint32_t n = (uint32_t)(ix->h_plane.size() - 1);
+        ix->h_roots.push_back(n);
+        if (N < M) { ix->h_left[n] = (int32_t)(uint32_t)((uint64_t)t * N); ix->h_right[n] = (int32_t)N; }  // lsh.rs:251-252
+        else active.push_back({n, t, (uint32_t)N, 0, (uint64_t)t * N, 1, N});
+    }
+    uint32_t n_planes = 0;
+    rc = grow_segments(ix, perm.as<uint32_t>(), total, active, 0, n_planes, true);
+    if (rc) { perm.release(); free_forest(ix); return rc; }
     if (n_planes == 0) {
-        if ((rc = ix->planes.ensure(4 * d))) return cleanup_fail(rc);
-        if ((rc = ix->consts.ensure(4))) return cleanup_fail(rc);
+        if ((rc = ix->planes.ensure(4 * (size_t)ix->opt.dim)) || (rc = ix->consts.ensure(4))) { perm.release(); free_forest(ix); return rc; }
     }
     ix->n_planes = n_planes;
     ix->leaf_ids = perm;  // perm is the concatenation of all leaves
@@ -544,6 +561,103 @@ static int build_forest_locked(zh_index *ix) {
     rc = upload_nodes(ix);
     if (rc) free_forest(ix);
     return rc;
+}
+
+// LSHIndex::add on an index that already has trees (lsh.rs:445-462) for rows [n_prev, n_prev + n_new), as the
+// sequential execution "one row after another, each into every tree".  A leaf's fate depends only on its own
+// arrivals in id order, so the rows are processed in rounds: descend all pending (row, tree) pairs on the GPU,
+// append to leaves with room, split the leaves that overflow (GPU classification through grow_segments) and
+// send the arrivals that came after a split down the new subtree in the next round.
+static int insert_rows_locked(zh_index *ix, uint64_t n_prev, uint64_t n_new) {
+    const uint32_t T = ix->n_trees, M = ix->opt.max_node_size, d = ix->opt.dim;
+    hipStream_t s = ix->stream;
+    int rc;
+    if (!n_new) return ZH_OK;
+    if (ix->h_leaf_ids.size() != ix->n_leaf_ids) {  // host mirror of the leaf lists (bookkeeping only)
+        ix->h_leaf_ids.resize(ix->n_leaf_ids);
+        if (ix->n_leaf_ids) HIPCHK(hipMemcpy(ix->h_leaf_ids.data(), ix->leaf_ids.p, ix->n_leaf_ids * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<ZhDescend> pending;
+    pending.reserve(n_new * T);
+    for (uint64_t r = 0; r < n_new; r++)
+        for (uint32_t t = 0; t < T; t++) pending.push_back({(uint32_t)(n_prev + r), ix->h_roots[t], 0, t, 1});
+    DevBuf dItems, dTemp;
+    struct G { DevBuf *a, *b; ~G() { a->release(); b->release(); } } g{&dItems, &dTemp};
+    uint32_t n_planes = ix->n_planes;
+    while (!pending.empty()) {
+        if (pending.size() > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "too many rows in one add call");
+        if ((rc = dItems.ensure(pending.size() * sizeof(ZhDescend)))) return rc;
+        HIPCHK(hipMemcpyAsync(dItems.p, pending.data(), pending.size() * sizeof(ZhDescend), hipMemcpyHostToDevice, s));
+        HIPCHK(zh_launch_descend(forest_dev(ix), ix->X.as<float>(), d, dItems.as<ZhDescend>(), (uint32_t)pending.size(), s));
+        HIPCHK(hipMemcpyAsync(pending.data(), dItems.p, pending.size() * sizeof(ZhDescend), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::sort(pending.begin(), pending.end(), [](const ZhDescend &a, const ZhDescend &b) {
+            return a.node != b.node ? a.node < b.node : a.row < b.row;
+        });
+        std::vector<ZhDescend> next;
+        std::vector<ActiveNode> splits;
+        std::vector<uint32_t> temp;  // id lists of the nodes to split, one segment each
+        const size_t old_leaf_size = ix->h_leaf_ids.size();
+        for (size_t i = 0; i < pending.size();) {
+            size_t j = i;
+            while (j < pending.size() && pending[j].node == pending[i].node) j++;
+            const ZhDescend &first = pending[i];
+            const uint32_t node = first.node;
+            const uint32_t off = (uint32_t)ix->h_left[node], len = (uint32_t)ix->h_right[node];
+            std::vector<uint32_t> cur(ix->h_leaf_ids.begin() + off, ix->h_leaf_ids.begin() + off + len);
+            size_t a = i;
+            const bool can_split = first.depth < ZH_MAX_DEPTH;
+            while (a < j && (cur.size() + 1 <= M || !can_split)) cur.push_back(pending[a++].row);  // lsh.rs:368-369
+            if (a == j) {  // the leaf just grew: relocate its run to the end of leaf_ids
+                ix->h_left[node] = (int32_t)(uint32_t)ix->h_leaf_ids.size();
+                ix->h_right[node] = (int32_t)cur.size();
+                ix->h_leaf_ids.insert(ix->h_leaf_ids.end(), cur.begin(), cur.end());
+            } else {       // lsh.rs:370-377: this arrival overflows the leaf -> build_a_tree(leaf ids + id)
+                cur.push_back(pending[a].row);
+                splits.push_back({node, first.tree, (uint32_t)cur.size(), first.depth, (uint64_t)temp.size(), first.path,
+                                  (uint64_t)pending[a].row + 1});
+                temp.insert(temp.end(), cur.begin(), cur.end());
+                for (size_t r = a + 1; r < j; r++) next.push_back(pending[r]);  // they arrive after the split
+            }
+            i = j;
+        }
+        if (ix->h_leaf_ids.size() + temp.size() > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "leaf storage exceeds 2^32-1 entries; rebuild the index");
+        if (!splits.empty()) {
+            if ((rc = dTemp.ensure(temp.size() * 4))) return rc;
+            HIPCHK(hipMemcpyAsync(dTemp.p, temp.data(), temp.size() * 4, hipMemcpyHostToDevice, s));
+            const uint64_t leaf_base = ix->h_leaf_ids.size();
+            if ((rc = grow_segments(ix, dTemp.as<uint32_t>(), temp.size(), splits, leaf_base, n_planes, false))) return rc;
+            HIPCHK(hipMemcpy(temp.data(), dTemp.p, temp.size() * 4, hipMemcpyDeviceToHost));
+            ix->h_leaf_ids.insert(ix->h_leaf_ids.end(), temp.begin(), temp.end());
+        }
+        // mirror -> device (appended tail only), nodes -> device
+        if (ix->h_leaf_ids.size() > old_leaf_size) {
+            if ((rc = ix->leaf_ids.ensure(ix->h_leaf_ids.size() * 4, true, s))) return rc;
+            HIPCHK(hipMemcpyAsync(ix->leaf_ids.as<uint32_t>() + old_leaf_size, ix->h_leaf_ids.data() + old_leaf_size,
+                                  (ix->h_leaf_ids.size() - old_leaf_size) * 4, hipMemcpyHostToDevice, s));
+        }
+        ix->n_leaf_ids = ix->h_leaf_ids.size();
+        ix->n_planes = n_planes;
+        if ((rc = upload_nodes(ix))) return rc;
+        pending.swap(next);
+    }
+    // compaction: relocated runs leave dead entries behind; rewrite the lists when they dominate
+    const uint64_t live = (uint64_t)T * ix->n_rows;
+    if (ix->h_leaf_ids.size() > 2 * live + 1024) {
+        std::vector<uint32_t> compact;
+        compact.reserve(live);
+        for (size_t n = 0; n < ix->h_plane.size(); n++)
+            if (ix->h_plane[n] < 0) {
+                uint32_t off = (uint32_t)ix->h_left[n], len = (uint32_t)ix->h_right[n];
+                ix->h_left[n] = (int32_t)(uint32_t)compact.size();
+                compact.insert(compact.end(), ix->h_leaf_ids.begin() + off, ix->h_leaf_ids.begin() + off + len);
+            }
+        ix->h_leaf_ids.swap(compact);
+        ix->n_leaf_ids = ix->h_leaf_ids.size();
+        if (ix->n_leaf_ids) HIPCHK(hipMemcpyAsync(ix->leaf_ids.p, ix->h_leaf_ids.data(), ix->n_leaf_ids * 4, hipMemcpyHostToDevice, s));
+        if ((rc = upload_nodes(ix))) return rc;
+    }
+    return ZH_OK;
 }
 
 extern "C" int zh_index_build(zh_index *ix) {
@@ -557,12 +671,15 @@ extern "C" int zh_index_build(zh_index *ix) {
 
 extern "C" int zh_index_add(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    if (ix->n_trees != 0 && ix->n_rows != 0)
-        return fail(ZH_EUNSUPPORTED, "zh_index_add on an index that already has trees (incremental insert, lsh.rs:350-382) "
-                                     "is not implemented yet: append and rebuild with zh_index_append + zh_index_build");
+    if (ix->opt.max_node_size == 0) return fail(ZH_EINVAL, "max_node_size must be >= 1");
+    const bool had_trees = ix->n_trees != 0;  // lsh.rs:441: no_trees() decides between build_index and insert
+    const uint64_t n_prev = ix->n_rows;
     int rc = zh_index_append(ix, rows, n, out_ids);
     if (rc) return rc;
-    return zh_index_build(ix);  // lsh.rs:441-443: no trees -> build_index
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if ((rc = set_device(ix))) return rc;
+    if (!had_trees) return build_forest_locked(ix);  // lsh.rs:441-443
+    return insert_rows_locked(ix, n_prev, n);        // lsh.rs:445-462
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -288,3 +288,27 @@ hipError_t zh_launch_scatter(const uint32_t *dPermIn, uint32_t *dPermOut, const 
                        dChunks);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// incremental insert: one lane per (new row, tree) descends from its current node to a leaf
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void descend_kernel(ZhForestDev f, const float *__restrict__ X, uint32_t d,
+                                                      ZhDescend *__restrict__ items, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ZhDescend it = items[i];
+    const float *x = X + (size_t)it.row * d;
+    int32_t p;
+    while ((p = f.node_plane[it.node]) >= 0) {
+        bool above = zh_plane_above(f.planes + (size_t)p * d, f.consts[p], x, d);
+        it.node = (uint32_t)(above ? f.node_right[it.node] : f.node_left[it.node]);
+        it.path = 2 * it.path + (above ? 1 : 0);
+        it.depth++;
+    }
+    items[i] = it;
+}
+hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDescend *dItems, uint32_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(descend_kernel, dim3((n + 63) / 64), dim3(64), 0, s, f, dX, d, dItems, n);
+    return hipGetLastError();
+}

@@ -46,6 +46,43 @@ struct ZhForestDev {
     uint32_t n_nodes, n_planes, n_trees;
 };
 
+#if defined(__HIPCC__)
+// point_is_above's dot product: sequential k-ascending fma chain from +0 (the order contract of the hash);
+// loads are issued 16 at a time ahead of the chain
+__device__ __forceinline__ bool zh_plane_above(const float *__restrict__ w, float c, const float *__restrict__ x,
+                                               uint32_t d) {
+    float acc = 0.0f;
+    if ((d & 3u) == 0) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const uint32_t n4 = d / 4;
+        uint32_t k = 0;
+        for (; k + 8 <= n4; k += 8) {
+            float4 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = w4[k + u]; b[u] = x4[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc = __builtin_fmaf(a[u].x, b[u].x, acc);
+                acc = __builtin_fmaf(a[u].y, b[u].y, acc);
+                acc = __builtin_fmaf(a[u].z, b[u].z, acc);
+                acc = __builtin_fmaf(a[u].w, b[u].w, acc);
+            }
+        }
+        for (; k < n4; k++) {
+            float4 a = w4[k], b = x4[k];
+            acc = __builtin_fmaf(a.x, b.x, acc);
+            acc = __builtin_fmaf(a.y, b.y, acc);
+            acc = __builtin_fmaf(a.z, b.z, acc);
+            acc = __builtin_fmaf(a.w, b.w, acc);
+        }
+    } else {
+        for (uint32_t k = 0; k < d; k++) acc = __builtin_fmaf(w[k], x[k], acc);
+    }
+    return ((double)acc + (double)c) >= 0.0;  // lsh.rs:40-42; NaN -> false
+}
+#endif
+
 #define ZH_SORT_N 4096        // entries of the LDS sort buffer of the select / final kernels
 #define ZH_INLINE_VISITS 8    // visits a pair may record in the walk's first pass
 
@@ -97,6 +134,13 @@ struct ZhBuildChunk {
     uint32_t count;      // <= 256
     uint64_t pos;        // global position of the chunk's first row in perm
 };
+
+// incremental insert (lsh.rs:350-382): descend a stored row from `node` to a leaf
+struct ZhDescend {
+    uint32_t row, node, depth, tree;
+    uint64_t path;
+};
+hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDescend *dItems, uint32_t n, hipStream_t s);
 
 hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
                                 hipStream_t s);

@@ -197,39 +197,6 @@ hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, 
 // walk: one lane per (query, tree).  Control flow of tree_result depends only on hash signs, leaf
 // lengths and n -- never on distances -- so it runs ahead of the sweep and emits the visit list.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool plane_above_on_demand(const float *__restrict__ w, float c,
-                                                      const float *__restrict__ q, uint32_t d) {
-    float acc = 0.0f;
-    if ((d & 3u) == 0) {
-        const float4 *w4 = reinterpret_cast<const float4 *>(w);
-        const float4 *q4 = reinterpret_cast<const float4 *>(q);
-        const uint32_t n4 = d / 4;
-        uint32_t k = 0;
-        for (; k + 8 <= n4; k += 8) {  // 16 independent 16-B loads in flight, then the ordered chain
-            float4 a[8], x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a[u] = w4[k + u]; x[u] = q4[k + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                acc = __builtin_fmaf(a[u].x, x[u].x, acc);
-                acc = __builtin_fmaf(a[u].y, x[u].y, acc);
-                acc = __builtin_fmaf(a[u].z, x[u].z, acc);
-                acc = __builtin_fmaf(a[u].w, x[u].w, acc);
-            }
-        }
-        for (; k < n4; k++) {
-            float4 a = w4[k], x = q4[k];
-            acc = __builtin_fmaf(a.x, x.x, acc);
-            acc = __builtin_fmaf(a.y, x.y, acc);
-            acc = __builtin_fmaf(a.z, x.z, acc);
-            acc = __builtin_fmaf(a.w, x.w, acc);
-        }
-    } else {
-        for (uint32_t k = 0; k < d; k++) acc = __builtin_fmaf(w[k], q[k], acc);
-    }
-    return ((double)acc + (double)c) >= 0.0;
-}
-
 #define WALK_STACK 64
 
 // emit pass: the s-th visit of a leaf joins group s / ZH_GROUP of that leaf as member s % ZH_GROUP
@@ -294,7 +261,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         while ((p = f.node_plane[cur]) >= 0) {
             bool above;
             if ((uint32_t)p < P_dense) above = (bits[(size_t)b * wpq + ((uint32_t)p >> 5)] >> (p & 31)) & 1u;
-            else above = plane_above_on_demand(f.planes + (size_t)p * d, f.consts[p], q, d);
+            else above = zh_plane_above(f.planes + (size_t)p * d, f.consts[p], q, d);
             int32_t l = f.node_left[cur], r = f.node_right[cur];
             if (sp < WALK_STACK) { st_node[sp] = above ? l : r; st_n[sp] = ncur; }
             sp++;
