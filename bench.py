@@ -265,7 +265,7 @@ def main():
     if cands and name == "cfg3" and S == 1 and not args.rows:
         try:
             pm = json.load(open(cands[-1]))
-            traffic = pm[kname]["hbm_bytes_per_launch"]
+            traffic = [v for k_, v in pm.items() if k_.startswith(kname[:-1])][0]["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(cands[-1], ROOT)
         except Exception:
             traffic = None

@@ -19,6 +19,7 @@ import shutil
 import sys
 
 tag, d_stats, d_fetch, d_write = sys.argv[1:5]
+d_mfma = sys.argv[5] if len(sys.argv) > 5 else None
 here = os.path.dirname(os.path.abspath(__file__))
 stats = glob.glob(os.path.join(d_stats, "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
@@ -44,5 +45,18 @@ for k in sorted(set(fetch) | set(write)):
               "hbm_bytes_per_launch": (2 * f["avg_value_KiB"] * 1024 if f else 0) + (w["avg_value_KiB"] * 1024 if w else 0),
               "avg_ns_under_pmc": (f or w)["avg_ns_under_pmc"]}
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_hbm_bytes.json"), "w"), indent=1)
+
+if d_mfma:  # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace ...
+    f = glob.glob(os.path.join(d_mfma, "**", "*counter_collection.csv"), recursive=True)[0]
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        a[k]["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    m = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in a.items()}
+    json.dump(m, open(os.path.join(here, f"{tag}_pmc_mfma.json"), "w"), indent=1)
+    for k, v in m.items():
+        if "hash_dense" in k or "sweep" in k:
+            print("MFMA pass:", k, {c: round(x, 1) for c, x in v.items()})
 for k, v in out.items():
     print(f"{k:45s} {v['launches']:4d} launches  {v['hbm_bytes_per_launch'] / 1e9:10.3f} GB/launch  {v['avg_ns_under_pmc'] / 1e6:9.3f} ms")
