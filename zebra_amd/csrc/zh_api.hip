@@ -781,7 +781,8 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
     HIPCHK(hipMemcpyAsync(ix->h_totals, ix->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const ZhTotals tot = *ix->h_totals;
-    if (tot.visits > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "more than 2^31 leaf visits in one batch; use a smaller batch");
+    if (tot.visits > 0xFFFFFFFull || tot.rows >= (1ull << 36))
+        return fail(ZH_ELIMIT, "more than 2^28 leaf visits or 2^36 scored rows in one batch; use a smaller batch");
     if ((rc = ix->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
     if ((rc = ix->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
     if ((rc = ix->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;

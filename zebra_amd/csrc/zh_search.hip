@@ -218,6 +218,47 @@ __device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__r
     }
 }
 
+// One WAVE per (query, tree) pair: control flow is wave-uniform.  A plane below the dense levels is hashed
+// on demand: the 64 lanes stage the plane (and, once, the query) into LDS with coalesced 16-B loads -- one
+// memory round trip instead of d/32 dependent ones -- and every lane then runs the ordered fma chain from
+// LDS broadcast reads (all lanes read the same address), so the sign is wave-uniform by construction.
+#define WALK_CHUNK 1024  // floats of plane / query staged per pass (d <= 1024: a single pass)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void stage_chunk(float *dst, const float *__restrict__ src, uint32_t n, uint32_t lane,
+                                            bool vec4) {
+    if (vec4) {
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        for (uint32_t i = lane; i < n / 4; i += 64) d4[i] = s4[i];
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ float chain_chunk(const float *w, const float *x, uint32_t n, bool vec4, float acc) {
+    if (vec4) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+#pragma unroll 4
+        for (uint32_t k = 0; k < n / 4; k++) {
+            float4 a = w4[k], b = x4[k];
+            acc = __builtin_fmaf(a.x, b.x, acc);
+            acc = __builtin_fmaf(a.y, b.y, acc);
+            acc = __builtin_fmaf(a.z, b.z, acc);
+            acc = __builtin_fmaf(a.w, b.w, acc);
+        }
+    } else {
+        for (uint32_t k = 0; k < n; k++) acc = __builtin_fmaf(w[k], x[k], acc);
+    }
+    return acc;
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__restrict__ Q, uint32_t B, uint32_t d,
                                                    int32_t n, const uint32_t *__restrict__ bits, uint32_t wpq,
@@ -230,26 +271,29 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    const uint32_t *__restrict__ groupBase,
                                                    const uint64_t *__restrict__ groupRowBase,
                                                    ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff) {
-    const uint32_t T = f.n_trees;
-    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= (uint64_t)B * T) return;
+    __shared__ __attribute__((aligned(16))) float s_w[WALK_CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_q[WALK_CHUNK];
+    __shared__ int32_t st_node[WALK_STACK], st_n[WALK_STACK];
+    const uint32_t T = f.n_trees, lane = threadIdx.x;
+    const uint64_t pair = blockIdx.x;  // one wave (= one block) per pair
     const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
     if (EMIT) {
         uint32_t nv = counts[pair].visits;
-        if (nv <= ZH_INLINE_VISITS) {
-            uint64_t vb = visitBase[pair], rb = rowBase[pair], cb = candBase[pair];
-            for (uint32_t i = 0; i < nv; i++) {
-                ZhVisit v = inl[pair * ZH_INLINE_VISITS + i];
-                v.row_off += rb;
-                v.cand_off += cb;
-                visits[vb + i] = v;
+        if (nv <= ZH_INLINE_VISITS) {  // the first pass recorded every visit: place them, one lane each
+            if (lane < nv) {
+                ZhVisit v = inl[pair * ZH_INLINE_VISITS + lane];
+                v.row_off += rowBase[pair];
+                v.cand_off += candBase[pair];
+                visits[visitBase[pair] + lane] = v;
                 join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
             }
             return;
         }
     }
     const float *q = Q + (size_t)b * d;
-    int32_t st_node[WALK_STACK], st_n[WALK_STACK];
+    const bool vec4 = (d & 3u) == 0;
+    const bool one_pass = d <= WALK_CHUNK;
+    bool q_staged = false;
     int sp = 0;
     int32_t cur = (int32_t)f.roots[t], ncur = n;
     uint32_t nv = 0;
@@ -261,9 +305,29 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         while ((p = f.node_plane[cur]) >= 0) {
             bool above;
             if ((uint32_t)p < P_dense) above = (bits[(size_t)b * wpq + ((uint32_t)p >> 5)] >> (p & 31)) & 1u;
-            else above = zh_plane_above(f.planes + (size_t)p * d, f.consts[p], q, d);
+            else {
+                const float *w = f.planes + (size_t)p * d;
+                float acc = 0.0f;
+                if (one_pass) {
+                    stage_chunk(s_w, w, d, lane, vec4);
+                    if (!q_staged) { stage_chunk(s_q, q, d, lane, vec4); q_staged = true; }
+                    wave_lds_sync();
+                    acc = chain_chunk(s_w, s_q, d, vec4, acc);
+                    wave_lds_sync();
+                } else {
+                    for (uint32_t k0 = 0; k0 < d; k0 += WALK_CHUNK) {
+                        uint32_t m = d - k0 < WALK_CHUNK ? d - k0 : WALK_CHUNK;
+                        stage_chunk(s_w, w + k0, m, lane, vec4);
+                        stage_chunk(s_q, q + k0, m, lane, vec4);
+                        wave_lds_sync();
+                        acc = chain_chunk(s_w, s_q, m, vec4, acc);
+                        wave_lds_sync();
+                    }
+                }
+                above = ((double)acc + (double)f.consts[p]) >= 0.0;  // lsh.rs:40-42
+            }
             int32_t l = f.node_left[cur], r = f.node_right[cur];
-            if (sp < WALK_STACK) { st_node[sp] = above ? l : r; st_n[sp] = ncur; }
+            if (sp < WALK_STACK && lane == 0) { st_node[sp] = above ? l : r; st_n[sp] = ncur; }
             sp++;
             cur = above ? r : l;  // lsh.rs:335-338: above -> right is main
         }
@@ -271,21 +335,24 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         uint32_t take = ncur <= 0 ? 0u : (len < (uint32_t)ncur ? len : (uint32_t)ncur);
         int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
         if (take > 0) {
-            ZhVisit v;
-            v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
-            if (EMIT) {
-                v.row_off = rb + nrows; v.cand_off = cb + ntakes;
-                visits[vb + nv] = v;
-                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
-            } else {
-                atomicAdd(&leafCount[cur], 1u);
-                if (nv < ZH_INLINE_VISITS) {
-                    v.row_off = nrows; v.cand_off = ntakes;
-                    inl[pair * ZH_INLINE_VISITS + nv] = v;
+            if (lane == 0) {
+                ZhVisit v;
+                v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
+                if (EMIT) {
+                    v.row_off = rb + nrows; v.cand_off = cb + ntakes;
+                    visits[vb + nv] = v;
+                    join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+                } else {
+                    atomicAdd(&leafCount[cur], 1u);
+                    if (nv < ZH_INLINE_VISITS) {
+                        v.row_off = nrows; v.cand_off = ntakes;
+                        inl[pair * ZH_INLINE_VISITS + nv] = v;
+                    }
                 }
             }
             nv++; nrows += len; ntakes += take;
         }
+        wave_lds_sync();  // lane 0's stack writes -> every lane's reads
         bool down = false;
         while (sp > 0) {
             sp--;
@@ -296,9 +363,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 break;
             }
         }
+        wave_lds_sync();
         if (!down) break;
     }
-    if (!EMIT) {
+    if (!EMIT && lane == 0) {
         ZhPairCounts c;
         c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
         counts[pair] = c;
@@ -310,7 +378,7 @@ hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint
                                 ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
+    hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)pairs), dim3(64), 0, s, f, dQ, B, d, n, dBits,
                        words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr, dLeafCount, nullptr,
                        nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError();
@@ -323,50 +391,43 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
+    hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)pairs), dim3(64), 0, s, f, dQ, B, d, n, dBits,
                        words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts), const_cast<ZhVisit *>(dInline),
                        dRowBase, dCandBase, dVisitBase, dVisits, const_cast<uint32_t *>(dLeafCount), dLeafFill,
                        dGroupBase, dGroupRowBase, dGroups, dGroupRowOff);
     return hipGetLastError();
 }
 
-// leaf scan: one block; node i with c visits forms ceil(c / ZH_GROUP) groups of len(i) rows each
-__global__ __launch_bounds__(1024) void leaf_scan_kernel(ZhForestDev f, const uint32_t *__restrict__ leafCount,
+// leaf allocation: node i with c visits forms ceil(c / ZH_GROUP) groups of len(i) rows each.  Group indices
+// and flat row offsets are handed out by ONE packed 64-bit atomic (groups << 36 | rows), so both are
+// monotone in the same (arbitrary) order -- the sweep's binary search only needs that.
+__global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const uint32_t *__restrict__ leafCount,
                                                           uint32_t *__restrict__ groupBase,
                                                           uint64_t *__restrict__ groupRowBase,
-                                                          ZhTotals *__restrict__ totals) {
-    __shared__ uint64_t sg[1024], sr[1024];
-    const uint32_t tid = threadIdx.x, n = f.n_nodes;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = lo + per < n ? lo + per : n;
-    uint64_t g = 0, r = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t c = leafCount[i];
-        if (c) { uint32_t ng = (c + ZH_GROUP - 1) / ZH_GROUP; g += ng; r += (uint64_t)ng * (uint32_t)f.node_right[i]; }
-    }
-    sg[tid] = g; sr[tid] = r;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint64_t ag = 0, ar = 0;
-        if (tid >= off) { ag = sg[tid - off]; ar = sr[tid - off]; }
-        __syncthreads();
-        sg[tid] += ag; sr[tid] += ar;
-        __syncthreads();
-    }
-    uint64_t bg = sg[tid] - g, br = sr[tid] - r;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t c = leafCount[i];
-        if (c) {
-            groupBase[i] = (uint32_t)bg; groupRowBase[i] = br;
-            uint32_t ng = (c + ZH_GROUP - 1) / ZH_GROUP;
-            bg += ng; br += (uint64_t)ng * (uint32_t)f.node_right[i];
-        }
-    }
-    if (tid == 1023) { totals->groups = sg[1023]; totals->group_rows = sr[1023]; }
+                                                          unsigned long long *__restrict__ packed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n_nodes) return;
+    uint32_t c = leafCount[i];
+    if (!c) return;
+    uint64_t ng = (c + ZH_GROUP - 1) / ZH_GROUP;
+    uint64_t rows = ng * (uint32_t)f.node_right[i];
+    unsigned long long old = atomicAdd(packed, (unsigned long long)((ng << 36) | rows));
+    groupBase[i] = (uint32_t)(old >> 36);
+    groupRowBase[i] = old & ((1ull << 36) - 1);
+}
+__global__ void leaf_totals_kernel(const unsigned long long *__restrict__ packed, ZhTotals *__restrict__ totals) {
+    totals->groups = *packed >> 36;
+    totals->group_rows = *packed & ((1ull << 36) - 1);
 }
 hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
                                uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s) {
-    hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, s, f, dLeafCount, dGroupBase, dGroupRowBase, dTotals);
+    // the packed counter lives in the totals' `flags` word (zeroed here, rewritten by pair_scan afterwards)
+    unsigned long long *packed = reinterpret_cast<unsigned long long *>(&dTotals->flags);
+    hipError_t e = hipMemsetAsync(packed, 0, 8, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(leaf_alloc_kernel, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f, dLeafCount, dGroupBase,
+                       dGroupRowBase, packed);
+    hipLaunchKernelGGL(leaf_totals_kernel, dim3(1), dim3(1), 0, s, packed, dTotals);
     return hipGetLastError();
 }
 
