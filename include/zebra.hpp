@@ -89,6 +89,46 @@ struct L2Distance {
     }
 };
 
+// the `distances`-crate metrics (distance.rs:51-98,116-190): key = f32 bits widened; Hamming an integer count
+#define ZEBRA_SIMPLE_METRIC(NAME, CODE)                                                         \
+    template <std::size_t N>                                                                    \
+    struct NAME {                                                                               \
+        int device = -1;                                                                        \
+        static constexpr int metric = CODE;                                                     \
+        int mode() const { return 0; }                                                          \
+        DistanceUnit distance(const Embedding<N> &a, const Embedding<N> &b) const {             \
+            return detail::metric_pair<N>(metric, 0, a, b, device);                             \
+        }                                                                                       \
+    };
+ZEBRA_SIMPLE_METRIC(ChebyshevDistance, ZH_CHEBYSHEV)
+ZEBRA_SIMPLE_METRIC(CanberraDistance, ZH_CANBERRA)
+ZEBRA_SIMPLE_METRIC(BrayCurtisDistance, ZH_BRAY_CURTIS)
+ZEBRA_SIMPLE_METRIC(ManhattanDistance, ZH_MANHATTAN)
+ZEBRA_SIMPLE_METRIC(L3Distance, ZH_L3)
+ZEBRA_SIMPLE_METRIC(L4Distance, ZH_L4)
+ZEBRA_SIMPLE_METRIC(HammingDistance, ZH_HAMMING)
+#undef ZEBRA_SIMPLE_METRIC
+template <std::size_t N>
+struct MinkowskiDistance {  // distance.rs:160-174
+    int power = 2;
+    int device = -1;
+    static constexpr int metric = ZH_MINKOWSKI;
+    int mode() const { return power; }
+    DistanceUnit distance(const Embedding<N> &a, const Embedding<N> &b) const {
+        return detail::metric_pair<N>(metric, power, a, b, device);
+    }
+};
+template <std::size_t N>
+struct PNormDistance {  // distance.rs:176-190
+    int power = 2;
+    int device = -1;
+    static constexpr int metric = ZH_PNORM;
+    int mode() const { return power; }
+    DistanceUnit distance(const Embedding<N> &a, const Embedding<N> &b) const {
+        return detail::metric_pair<N>(metric, power, a, b, device);
+    }
+};
+
 // ---- src/database/index/lsh.rs ------------------------------------------------------------------------
 template <std::size_t N>
 struct LSHIndexOptions {  // lsh.rs:122-139

@@ -61,11 +61,28 @@ typedef enum zh_status {
     ZH_EUNSUPPORTED = -6
 } zh_status;
 
-typedef enum zh_metric { ZH_COSINE = 0, ZH_L2SQ = 1, ZH_L2 = 2 } zh_metric;
+/* the 13 metric structs of src/distance.rs.  0-2 are the simsimd path (key = f64 bits); 3-11 the `distances`
+ * crate path (key = f32 bits widened, distance.rs:59; Hamming an integer count, distance.rs:144-158) */
+typedef enum zh_metric {
+    ZH_COSINE = 0,      /* CosineDistance      distance.rs:15-32  */
+    ZH_L2SQ = 1,        /* L2SquaredDistance   distance.rs:34-49  */
+    ZH_L2 = 2,          /* L2Distance          distance.rs:99-114 */
+    ZH_CHEBYSHEV = 3,   /* ChebyshevDistance   distance.rs:51-61  */
+    ZH_CANBERRA = 4,    /* CanberraDistance    distance.rs:63-73  */
+    ZH_BRAY_CURTIS = 5, /* BrayCurtisDistance  distance.rs:75-85  */
+    ZH_MANHATTAN = 6,   /* ManhattanDistance   distance.rs:87-97  */
+    ZH_L3 = 7,          /* L3Distance          distance.rs:116-126 */
+    ZH_L4 = 8,          /* L4Distance          distance.rs:128-138 */
+    ZH_HAMMING = 9,     /* HammingDistance     distance.rs:140-158 (low byte of each f32's bits) */
+    ZH_MINKOWSKI = 10,  /* MinkowskiDistance { power }  distance.rs:160-174 */
+    ZH_PNORM = 11       /* PNormDistance { power }      distance.rs:176-190 */
+} zh_metric;
+#define ZH_MAX_POWER 64 /* MinkowskiDistance / PNormDistance power must be in 1..64 */
 
 /* distance.rs:23-25 applies `1.0 - c` to simsimd's cosine, which is already a distance, so the
  * reference key is the bit pattern of the cosine SIMILARITY.  PARITY reproduces that literally;
- * CORRECTED keys on the distance.  Ignored by the L2 metrics. */
+ * CORRECTED keys on the distance.  The `cosine_mode` argument of the calls below is this mode for ZH_COSINE,
+ * the `power` field for ZH_MINKOWSKI / ZH_PNORM, and ignored by the other metrics. */
 typedef enum zh_cosine_mode { ZH_COSINE_PARITY = 0, ZH_COSINE_CORRECTED = 1 } zh_cosine_mode;
 
 #define ZH_MAX_TOPK 1024u

@@ -44,7 +44,8 @@
 
 #define ZO_EXPORT __attribute__((visibility("default")))
 
-enum { ZO_COSINE = 0, ZO_L2SQ = 1, ZO_L2 = 2 };
+enum { ZO_COSINE = 0, ZO_L2SQ = 1, ZO_L2 = 2, ZO_CHEBYSHEV = 3, ZO_CANBERRA = 4, ZO_BRAY_CURTIS = 5, ZO_MANHATTAN = 6,
+       ZO_L3 = 7, ZO_L4 = 8, ZO_HAMMING = 9, ZO_MINKOWSKI = 10, ZO_PNORM = 11 };
 enum { ZO_PARITY = 0, ZO_CORRECTED = 1 };
 #define ZO_MAX_DEPTH 60 /* guard: the reference recurses forever on an unsplittable node */
 
@@ -195,8 +196,99 @@ static inline uint64_t key_from_sums(int metric, int mode, float ab, float a2, f
     }
 }
 
-/* Metric::distance(a = stored, b = query) -> DistanceUnit (u64 bit pattern) */
+
+/* ---- the ten metrics of the `distances` crate path (distance.rs:51-98,116-190): keys are f32::to_bits()
+ * widened to u64 (distance.rs:59 etc.), Hamming is an integer count (distance.rs:144-158).  Semantics of
+ * distances = "1.8.0" restated from its published API: manhattan sum|a-b|, chebyshev max|a-b|,
+ * canberra sum |a-b|/(|a|+|b|), bray_curtis sum|a-b| / sum|a+b|, l3/l4 norms, minkowski(p) and minkowski_p(p)
+ * with powi.  Sums use the same 256-accumulator order as the simsimd-path metrics (the crate sums
+ * sequentially; the difference is within the 1e-5 bar).  Roots other than sqrt are computed by a fixed
+ * Newton iteration in f64 so that CPU and GPU agree bit for bit. */
+static inline float powi_f32(float a, int b) { /* compiler-rt __powisf2: what Rust's f32::powi lowers to */
+    const int recip = b < 0;
+    float r = 1.0f;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+static inline double root_p(double s, int p) { /* s^(1/p), p >= 1, deterministic (only + * / on f64) */
+    if (!(s > 0.0) || s == (double)INFINITY || p == 1) return s; /* 0, NaN, inf pass through */
+    if (p == 2) return sqrt(s);
+    uint64_t u;
+    memcpy(&u, &s, 8);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;            /* s = m * 2^e, m in [1,2): s is a widened f32, never subnormal */
+    int fl = e >= 0 ? e / p : -((-e + p - 1) / p);      /* floor(e / p) */
+    int rem = e - fl * p;                               /* in [0, p) */
+    /* root = 2^fl * 2^(rem/p) * m^(1/p) <= 2^fl * (1 + rem/p) * (1 + 1/p): start just above, Newton from above */
+    double y = ldexp((1.0 + (double)rem / (double)p) * (1.0 + 1.0 / (double)p), fl);
+    for (int it = 0; it < 16; it++) {
+        double yp = 1.0;
+        for (int i = 0; i < p - 1; i++) yp *= y;        /* y^(p-1) */
+        y = ((double)(p - 1) * y + s / yp) / (double)p;
+    }
+    return y;
+}
+
+static inline uint32_t bits32(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+
+typedef struct { float s0, s1; } zo_pairsum;
+
+static inline float combine256_max(const float *acc) {
+    float s[64], t[64];
+    for (int l = 0; l < 64; l++) s[l] = fmaxf(fmaxf(acc[4 * l], acc[4 * l + 1]), fmaxf(acc[4 * l + 2], acc[4 * l + 3]));
+    for (int m = 1; m < 64; m <<= 1) {
+        for (int l = 0; l < 64; l++) t[l] = fmaxf(s[l], s[l ^ m]);
+        memcpy(s, t, sizeof s);
+    }
+    return s[0];
+}
+
+static zo_pairsum sums_generic(int metric, int power, const float *a, const float *b, uint32_t d) {
+    float acc0[256], acc1[256];
+    memset(acc0, 0, sizeof acc0);
+    memset(acc1, 0, sizeof acc1);
+    for (uint32_t e = 0; e < d; e++) {
+        uint32_t i = e & 255;
+        float x = a[e], y = b[e], ad = fabsf(x - y);
+        switch (metric) {
+        case ZO_CHEBYSHEV: acc0[i] = fmaxf(acc0[i], ad); break;
+        case ZO_CANBERRA: acc0[i] = acc0[i] + ad / (fabsf(x) + fabsf(y)); break;
+        case ZO_BRAY_CURTIS: acc0[i] = acc0[i] + ad; acc1[i] = acc1[i] + fabsf(x + y); break;
+        case ZO_MANHATTAN: acc0[i] = acc0[i] + ad; break;
+        case ZO_L3: acc0[i] = acc0[i] + ad * (ad * ad); break;
+        case ZO_L4: { float t = ad * ad; acc0[i] = acc0[i] + t * t; break; }
+        case ZO_HAMMING: acc0[i] = acc0[i] + (float)__builtin_popcount((bits32(x) ^ bits32(y)) & 0xFFu); break;
+        default: acc0[i] = acc0[i] + powi_f32(ad, power); break; /* MINKOWSKI, PNORM */
+        }
+    }
+    zo_pairsum r;
+    r.s0 = metric == ZO_CHEBYSHEV ? combine256_max(acc0) : combine256(acc0);
+    r.s1 = metric == ZO_BRAY_CURTIS ? combine256(acc1) : 0.0f;
+    return r;
+}
+
+static uint64_t key_generic(int metric, int power, zo_pairsum s) {
+    float f;
+    switch (metric) {
+    case ZO_BRAY_CURTIS: f = s.s0 / s.s1; break;
+    case ZO_L3: f = (float)root_p((double)s.s0, 3); break;
+    case ZO_L4: f = sqrtf(sqrtf(s.s0)); break;
+    case ZO_HAMMING: return (uint64_t)s.s0;
+    case ZO_MINKOWSKI: f = (float)root_p((double)s.s0, power); break;
+    default: f = s.s0; break; /* CHEBYSHEV, CANBERRA, MANHATTAN, PNORM */
+    }
+    return (uint64_t)bits32(f);
+}
+
+/* Metric::distance(a = stored, b = query) -> DistanceUnit (u64 bit pattern); `mode` is the cosine mode for
+ * ZO_COSINE and the power for ZO_MINKOWSKI / ZO_PNORM */
 ZO_EXPORT uint64_t zo_distance(int metric, int mode, const float *a, const float *b, uint32_t d) {
+    if (metric >= ZO_CHEBYSHEV) return key_generic(metric, mode, sums_generic(metric, mode, a, b, d));
     if (metric == ZO_COSINE)
         return key_from_sums(metric, mode, sum_prod(a, b, d), sum_prod(a, a, d), sum_prod(b, b, d), 0.0f);
     return key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, b, d));
@@ -207,6 +299,7 @@ ZO_EXPORT void zo_distance_batch(int metric, int mode, const float *rows, const 
     float b2 = metric == ZO_COSINE ? sum_prod(q, q, d) : 0.0f;
     for (uint64_t i = 0; i < n; i++) {
         const float *a = rows + i * d;
+        if (metric >= ZO_CHEBYSHEV) { out_keys[i] = key_generic(metric, mode, sums_generic(metric, mode, a, q, d)); continue; }
         out_keys[i] = metric == ZO_COSINE
                           ? key_from_sums(metric, mode, sum_prod(a, q, d), sum_prod(a, a, d), b2, 0.0f)
                           : key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, q, d));
@@ -471,6 +564,7 @@ typedef struct {
 
 static inline uint64_t ctx_key(zo_ctx *c, uint32_t id) {
     const float *a = c->X + (size_t)id * c->f->d;
+    if (c->metric >= ZO_CHEBYSHEV) return key_generic(c->metric, c->mode, sums_generic(c->metric, c->mode, a, c->q, c->f->d));
     if (c->metric == ZO_COSINE)
         return key_from_sums(c->metric, c->mode, sum_prod(a, c->q, c->f->d), sum_prod(a, a, c->f->d), c->qq, 0.0f);
     return key_from_sums(c->metric, c->mode, 0, 0, 0, sum_l2sq(a, c->q, c->f->d));
@@ -643,6 +737,7 @@ ZO_EXPORT void zo_brute_force(const float *X, uint64_t n, uint32_t d, const floa
     for (uint64_t i = 0; i < n; i++) {
         const float *a = X + i * d;
         r[i].id = (uint32_t)i;
+        if (metric >= ZO_CHEBYSHEV) { r[i].key = key_generic(metric, mode, sums_generic(metric, mode, a, q, d)); continue; }
         r[i].key = metric == ZO_COSINE ? key_from_sums(metric, mode, sum_prod(a, q, d), sum_prod(a, a, d), qq, 0.0f)
                                        : key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, q, d));
     }

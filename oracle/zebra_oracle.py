@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libzebra_oracle.so")
 
 COSINE, L2SQ, L2 = 0, 1, 2
+CHEBYSHEV, CANBERRA, BRAY_CURTIS, MANHATTAN, L3, L4, HAMMING, MINKOWSKI, PNORM = 3, 4, 5, 6, 7, 8, 9, 10, 11
 PARITY, CORRECTED = 0, 1
 SEED_ROWS, SEED_QUERIES, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
 

@@ -43,6 +43,46 @@ def test_distance_keys_bit_exact(za, d):
         assert (m.distance_batch(X[:5], z) == zo.distance_batch(om, omode, X[:5], z)).all(), name
 
 
+def more_metrics(za):
+    return [("chebyshev", za.ChebyshevDistance(), zo.CHEBYSHEV, 0), ("canberra", za.CanberraDistance(), zo.CANBERRA, 0),
+            ("bray_curtis", za.BrayCurtisDistance(), zo.BRAY_CURTIS, 0), ("manhattan", za.ManhattanDistance(), zo.MANHATTAN, 0),
+            ("l3", za.L3Distance(), zo.L3, 0), ("l4", za.L4Distance(), zo.L4, 0), ("hamming", za.HammingDistance(), zo.HAMMING, 0),
+            ("minkowski3", za.MinkowskiDistance(3), zo.MINKOWSKI, 3), ("minkowski7", za.MinkowskiDistance(7), zo.MINKOWSKI, 7),
+            ("minkowski1", za.MinkowskiDistance(1), zo.MINKOWSKI, 1), ("minkowski2", za.MinkowskiDistance(2), zo.MINKOWSKI, 2),
+            ("pnorm2", za.PNormDistance(2), zo.PNORM, 2), ("pnorm5", za.PNormDistance(5), zo.PNORM, 5)]
+
+
+# ------------------------------------------------------- src/distance.rs:51-98,116-190 (f2)
+@pytest.mark.parametrize("d", [3, 100, 128, 384, 768, 1000])
+def test_distances_crate_metric_keys_bit_exact(za, d):
+    rng = np.random.default_rng(d)
+    for scale in (1.0, 1e-6, 1e5):
+        X = (rng.standard_normal((130, d)) * scale).astype(np.float32)
+        X[3] = 0
+        q = (rng.standard_normal(d) * scale).astype(np.float32)
+        for name, m, om, p in more_metrics(za):
+            got, want = m.distance_batch(X, q), zo.distance_batch(om, p, X, q)
+            same = (got == want) | (np.isnan(got.astype(np.uint32).view(np.float32)) & np.isnan(want.astype(np.uint32).view(np.float32)))
+            assert same.all(), (name, d, scale, got[~same][:3], want[~same][:3])
+    with pytest.raises(za.ZhError):
+        za.MinkowskiDistance(0).distance_batch(X, q)
+    with pytest.raises(za.ZhError):
+        za.PNormDistance(65).distance_batch(X, q)
+
+
+@pytest.mark.parametrize("n,d,M,T,k,B", [(6000, 128, 200, 6, 10, 20), (3000, 384, 64, 4, 10, 12), (2500, 50, 40, 3, 7, 9)])
+def test_search_with_distances_crate_metrics(za, n, d, M, T, k, B):
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    for name, m, om, p in more_metrics(za):
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        oi, ok, oc = f.search_batch(Q, k, om, p)
+        assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all(), name
+
+
 def test_distance_special_values(za):
     X = np.array([[np.inf, 1, 2, 3], [np.nan, 0, 0, 0], [1e-30, 1e-30, 0, 0], [3e38, 3e38, 3e38, 3e38],
                   [-0.0, 0, 0, 0], [1, 2, 3, 4]], np.float32)

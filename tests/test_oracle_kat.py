@@ -334,3 +334,44 @@ def test_incremental_insert_rules():
     h.insert(X[:101], 100)
     h.insert(X, 101)
     assert zo.canonical_forest(h.arrays(), d) == zo.canonical_forest(f.arrays(), d)
+
+
+# the ten `distances`-crate metrics, src/distance.rs:51-98,116-190 (semantics restated; parity unpinned)
+@pytest.mark.parametrize("d", [4, 100, 384, 768])
+def test_distances_crate_metrics_vs_float64(d):
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((20, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    X64, q64 = X.astype(np.float64), q.astype(np.float64)
+    ad = np.abs(X64 - q64)
+
+    def f32(m, p=0):
+        keys = zo.distance_batch(m, p, X, q)
+        assert (keys >> np.uint64(32) == 0).all()  # f32::to_bits().into(): upper half zero (distance.rs:59)
+        return keys.astype(np.uint32).view(np.float32).astype(np.float64)
+
+    np.testing.assert_allclose(f32(zo.MANHATTAN), ad.sum(1), rtol=1e-5)
+    assert (f32(zo.CHEBYSHEV) == np.abs(X - q).max(1).astype(np.float64)).all()  # max is order independent: exact
+    np.testing.assert_allclose(f32(zo.CANBERRA), (ad / (np.abs(X64) + np.abs(q64))).sum(1), rtol=1e-5)
+    np.testing.assert_allclose(f32(zo.BRAY_CURTIS), ad.sum(1) / np.abs(X64 + q64).sum(1), rtol=1e-5)
+    np.testing.assert_allclose(f32(zo.L3), (ad ** 3).sum(1) ** (1 / 3), rtol=1e-5)
+    np.testing.assert_allclose(f32(zo.L4), (ad ** 4).sum(1) ** 0.25, rtol=1e-5)
+    for p in (1, 2, 3, 5, 7):
+        np.testing.assert_allclose(f32(zo.MINKOWSKI, p), (ad ** p).sum(1) ** (1 / p), rtol=1e-5)
+        np.testing.assert_allclose(f32(zo.PNORM, p), (ad ** p).sum(1), rtol=1e-5)
+    ham = zo.distance_batch(zo.HAMMING, 0, X, q)
+    want = [sum(bin((int(a) ^ int(b)) & 0xFF).count("1") for a, b in zip(x.view(np.uint32), q.view(np.uint32))) for x in X]
+    assert ham.tolist() == want
+    # KAT: (1,2,3) vs (4,6,8): |d| = 3,4,5
+    a, b = [1, 2, 3], [4, 6, 8]
+    k = lambda m, p=0: np.uint32(zo.distance(m, p, a, b)).view(np.float32)  # noqa: E731
+    assert k(zo.MANHATTAN) == 12 and k(zo.CHEBYSHEV) == 5 and k(zo.PNORM, 2) == 50 and k(zo.PNORM, 3) == 216
+    assert k(zo.L3) == 6 and k(zo.MINKOWSKI, 3) == 6  # (27+64+125)^(1/3) = 6 exactly
+    assert abs(k(zo.CANBERRA) - (3 / 5 + 4 / 8 + 5 / 11)) < 1e-6 and abs(k(zo.BRAY_CURTIS) - 12 / 24) < 1e-7
+
+
+def test_search_with_a_distances_crate_metric():
+    X = zo.synth_rows(3000, 32)
+    f = zo.Forest.build(X, 64, 5)
+    ids, keys = f.search(X[77], 5, zo.MANHATTAN)
+    assert ids[0] == 77 and keys[0] == 0 and (np.diff(keys.astype(np.int64)) >= 0).all()

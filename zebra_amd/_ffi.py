@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libzebra_hip.so")
 
 ZH_OK = 0
 COSINE, L2SQ, L2 = 0, 1, 2
+CHEBYSHEV, CANBERRA, BRAY_CURTIS, MANHATTAN, L3, L4, HAMMING, MINKOWSKI, PNORM = 3, 4, 5, 6, 7, 8, 9, 10, 11
 COSINE_PARITY, COSINE_CORRECTED = 0, 1
 MAX_TOPK = 1024
 

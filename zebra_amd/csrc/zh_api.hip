@@ -835,8 +835,10 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
 }
 
 static int check_metric(int metric, int mode) {
-    if (metric != ZH_COSINE && metric != ZH_L2SQ && metric != ZH_L2) return fail(ZH_EINVAL, "unknown metric %d", metric);
-    if (mode != ZH_COSINE_PARITY && mode != ZH_COSINE_CORRECTED) return fail(ZH_EINVAL, "unknown cosine mode %d", mode);
+    if (metric < ZH_COSINE || metric > ZH_PNORM) return fail(ZH_EINVAL, "unknown metric %d", metric);
+    if (metric == ZH_COSINE && mode != ZH_COSINE_PARITY && mode != ZH_COSINE_CORRECTED) return fail(ZH_EINVAL, "unknown cosine mode %d", mode);
+    if ((metric == ZH_MINKOWSKI || metric == ZH_PNORM) && (mode < 1 || mode > ZH_MAX_POWER))
+        return fail(ZH_ELIMIT, "power %d outside 1..%d", mode, ZH_MAX_POWER);
     return ZH_OK;
 }
 

@@ -51,6 +51,97 @@ __device__ __forceinline__ uint64_t key_l2(float l2sq, int metric) {
     return f64_bits(metric == ZH_L2SQ ? (double)l2sq : sqrt((double)l2sq));
 }
 
+// ---- the `distances`-crate metrics (distance.rs:51-98,116-190): f32 result, key = f32 bits widened ----
+enum { K_L2 = 0, K_COS = 1, K_MAX = 2, K_CANB = 3, K_BRAY = 4, K_ABS = 5, K_P3 = 6, K_P4 = 7, K_HAMM = 8, K_PP = 9 };
+
+__host__ __device__ inline int zh_kind_of(int metric) {
+    switch (metric) {
+    case ZH_COSINE: return K_COS;
+    case ZH_CHEBYSHEV: return K_MAX;
+    case ZH_CANBERRA: return K_CANB;
+    case ZH_BRAY_CURTIS: return K_BRAY;
+    case ZH_MANHATTAN: return K_ABS;
+    case ZH_L3: return K_P3;
+    case ZH_L4: return K_P4;
+    case ZH_HAMMING: return K_HAMM;
+    case ZH_MINKOWSKI: case ZH_PNORM: return K_PP;
+    default: return K_L2;
+    }
+}
+
+__device__ __forceinline__ float powi_f32(float a, int b) {  // compiler-rt __powisf2 (Rust f32::powi)
+    const bool recip = b < 0;
+    float r = 1.0f;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+// s^(1/p), p >= 1: fixed Newton iteration in f64 (only + * /), bit-identical to the oracle's root_p
+__device__ __forceinline__ double root_p(double s, int p) {
+    if (!(s > 0.0) || s == (double)INFINITY || p == 1) return s;
+    if (p == 2) return sqrt(s);
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    int fl = e >= 0 ? e / p : -((-e + p - 1) / p);
+    int rem = e - fl * p;
+    double y = ldexp((1.0 + (double)rem / (double)p) * (1.0 + 1.0 / (double)p), fl);
+    for (int it = 0; it < 16; it++) {
+        double yp = 1.0;
+        for (int i = 0; i < p - 1; i++) yp *= y;
+        y = ((double)(p - 1) * y + s / yp) / (double)p;
+    }
+    return y;
+}
+
+// sums -> DistanceUnit for every metric; s0/s1 are the canonical sums, qq the query norm (cosine)
+__device__ __forceinline__ uint64_t key_of(int metric, int param, float s0, float s1, float qq) {
+    float f;
+    switch (metric) {
+    case ZH_COSINE: return key_cosine(s0, s1, qq, param);
+    case ZH_L2SQ: case ZH_L2: return key_l2(s0, metric);
+    case ZH_BRAY_CURTIS: f = s0 / s1; break;
+    case ZH_L3: f = (float)root_p((double)s0, 3); break;
+    case ZH_L4: f = sqrtf(sqrtf(s0)); break;
+    case ZH_HAMMING: return (uint64_t)s0;
+    case ZH_MINKOWSKI: f = (float)root_p((double)s0, param); break;
+    default: f = s0; break;  // CHEBYSHEV, CANBERRA, MANHATTAN, PNORM
+    }
+    return (uint64_t)__float_as_uint(f);
+}
+
+// one element of the per-lane accumulation, by kind (a = stored, q = query)
+template <int KIND>
+__device__ __forceinline__ void acc_elem(float a, float q, float &x0, float &x1, int power) {
+    if (KIND == K_L2) { float df = a - q; x0 = __builtin_fmaf(df, df, x0); }
+    else if (KIND == K_COS) { x0 = __builtin_fmaf(a, q, x0); }
+    else {
+        float ad = fabsf(a - q);
+        if (KIND == K_MAX) x0 = fmaxf(x0, ad);
+        else if (KIND == K_CANB) x0 = x0 + ad / (fabsf(a) + fabsf(q));
+        else if (KIND == K_BRAY) { x0 = x0 + ad; x1 = x1 + fabsf(a + q); }
+        else if (KIND == K_ABS) x0 = x0 + ad;
+        else if (KIND == K_P3) x0 = x0 + ad * (ad * ad);
+        else if (KIND == K_P4) { float t = ad * ad; x0 = x0 + t * t; }
+        else if (KIND == K_HAMM) x0 = x0 + (float)__popc((__float_as_uint(a) ^ __float_as_uint(q)) & 0xFFu);
+        else x0 = x0 + powi_f32(ad, power);
+    }
+}
+template <int KIND>
+__device__ __forceinline__ float wave_combine(float x, float y, float z, float w) {
+    if (KIND == K_MAX) {
+        float s = fmaxf(fmaxf(x, y), fmaxf(z, w));
+        s = fmaxf(s, __shfl_xor(s, 1)); s = fmaxf(s, __shfl_xor(s, 2)); s = fmaxf(s, __shfl_xor(s, 4));
+        s = fmaxf(s, __shfl_xor(s, 8)); s = fmaxf(s, __shfl_xor(s, 16)); s = fmaxf(s, __shfl_xor(s, 32));
+        return s;
+    }
+    return wave_sum_canonical((x + y) + (z + w));
+}
+
 // ------------------------------------------------------------------------------------------------
 // hash_dense: 64 queries x 64 planes per block, 4 waves each owning a 32x32 tile,
 // K staged 32 at a time through LDS in [k][row] order so that a lane's MFMA operand
@@ -144,29 +235,23 @@ hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlane
 // canonical row sums: one wave per row, lane-strided float4
 // ------------------------------------------------------------------------------------------------
 // generic (runtime d, any d): element e handled by lane (e mod 256)/4, component e mod 4
+template <int KIND>
 __device__ __forceinline__ void lane_sums_generic(const float *__restrict__ a, const float *__restrict__ q,
-                                                  uint32_t d, uint32_t lane, bool cosine, float &o_ab, float &o_a2,
-                                                  float &o_l2) {
-    float ab[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, l2[4] = {0, 0, 0, 0};
+                                                  uint32_t d, uint32_t lane, int power, float &o_s0, float &o_s1) {
+    float x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0};
     for (uint32_t base = 0; base < d; base += 256) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             uint32_t e = base + 4 * lane + t;
             if (e < d) {
-                float av = a[e], qv = q[e];
-                if (cosine) {
-                    ab[t] = __builtin_fmaf(av, qv, ab[t]);
-                    a2[t] = __builtin_fmaf(av, av, a2[t]);
-                } else {
-                    float df = av - qv;
-                    l2[t] = __builtin_fmaf(df, df, l2[t]);
-                }
+                float av = a[e];
+                acc_elem<KIND>(av, q[e], x0[t], x1[t], power);
+                if (KIND == K_COS) x1[t] = __builtin_fmaf(av, av, x1[t]);
             }
         }
     }
-    o_ab = wave_sum_canonical((ab[0] + ab[1]) + (ab[2] + ab[3]));
-    o_a2 = wave_sum_canonical((a2[0] + a2[1]) + (a2[2] + a2[3]));
-    o_l2 = wave_sum_canonical((l2[0] + l2[1]) + (l2[2] + l2[3]));
+    o_s0 = wave_combine<KIND>(x0[0], x0[1], x0[2], x0[3]);
+    o_s1 = (KIND == K_COS || KIND == K_BRAY) ? wave_combine<K_L2>(x1[0], x1[1], x1[2], x1[3]) : 0.0f;
 }
 
 // sum_prod(q, q): the query-side norm of the cosine metric, one wave per query
@@ -504,35 +589,13 @@ __device__ __forceinline__ void load_row(const float *__restrict__ row, uint32_t
     }
 }
 
-template <int D, bool COSINE>
-__device__ __forceinline__ void row_sums(const float4 *v, const float4 *q, uint32_t lane, float &s0, float &s1) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-#pragma unroll
-    for (int j = 0; j < RowVec<D>::NV; j++) {
-        bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-        if (act) {
-            if (COSINE) {
-                a.x = __builtin_fmaf(v[j].x, q[j].x, a.x); a.y = __builtin_fmaf(v[j].y, q[j].y, a.y);
-                a.z = __builtin_fmaf(v[j].z, q[j].z, a.z); a.w = __builtin_fmaf(v[j].w, q[j].w, a.w);
-                c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
-                c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
-            } else {
-                float dx = v[j].x - q[j].x, dy = v[j].y - q[j].y, dz = v[j].z - q[j].z, dw = v[j].w - q[j].w;
-                a.x = __builtin_fmaf(dx, dx, a.x); a.y = __builtin_fmaf(dy, dy, a.y);
-                a.z = __builtin_fmaf(dz, dz, a.z); a.w = __builtin_fmaf(dw, dw, a.w);
-            }
-        }
-    }
-    s0 = wave_sum_canonical((a.x + a.y) + (a.z + a.w));
-    s1 = COSINE ? wave_sum_canonical((c.x + c.y) + (c.z + c.w)) : 0.0f;
-}
-
-// one row against the (up to ZH_GROUP) queries of its group; a2 (the stored row's norm) is shared
-template <int D, bool COSINE>
+// one row against the (up to ZH_GROUP) queries of its group.  s0[m] (and s1[m] for Bray-Curtis) are per
+// member; for cosine s1[0] carries a2, the stored row's norm, shared by the members
+template <int D, int KIND>
 __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q)[RowVec<D>::NV], uint32_t gsize,
-                                               uint32_t lane, float *s0, float &s1) {
+                                               uint32_t lane, int power, float *s0, float *s1) {
     constexpr int NV = RowVec<D>::NV;
-    if (COSINE) {
+    if (KIND == K_COS) {
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
@@ -542,41 +605,36 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
                 c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
             }
         }
-        s1 = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
-    } else
-        s1 = 0.0f;
+        s1[0] = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
+    }
 #pragma unroll
     for (int m = 0; m < ZH_GROUP; m++) {
         if ((uint32_t)m < gsize) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
                 if (act) {
-                    if (COSINE) {
-                        a.x = __builtin_fmaf(v[j].x, q[m][j].x, a.x); a.y = __builtin_fmaf(v[j].y, q[m][j].y, a.y);
-                        a.z = __builtin_fmaf(v[j].z, q[m][j].z, a.z); a.w = __builtin_fmaf(v[j].w, q[m][j].w, a.w);
-                    } else {
-                        float dx = v[j].x - q[m][j].x, dy = v[j].y - q[m][j].y, dz = v[j].z - q[m][j].z,
-                              dw = v[j].w - q[m][j].w;
-                        a.x = __builtin_fmaf(dx, dx, a.x); a.y = __builtin_fmaf(dy, dy, a.y);
-                        a.z = __builtin_fmaf(dz, dz, a.z); a.w = __builtin_fmaf(dw, dw, a.w);
-                    }
+                    acc_elem<KIND>(v[j].x, q[m][j].x, a.x, e.x, power);
+                    acc_elem<KIND>(v[j].y, q[m][j].y, a.y, e.y, power);
+                    acc_elem<KIND>(v[j].z, q[m][j].z, a.z, e.z, power);
+                    acc_elem<KIND>(v[j].w, q[m][j].w, a.w, e.w, power);
                 }
             }
-            s0[m] = wave_sum_canonical((a.x + a.y) + (a.z + a.w));
+            s0[m] = wave_combine<KIND>(a.x, a.y, a.z, a.w);
+            if (KIND == K_BRAY) s1[m] = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
         }
     }
 }
 
 // D > 0: compile-time dimension (multiple of 4); D == 0: runtime d, any value (slow path)
-template <int D, bool COSINE, int SWEEP_RG = 4, bool NT = false>
+template <int D, int KIND, int SWEEP_RG = 4, bool NT = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X, uint32_t d,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
                                                      const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
                                                      const uint32_t *__restrict__ leaf_ids, uint64_t R_grouped,
-                                                     int metric, int mode, uint64_t *__restrict__ keys) {
+                                                     int metric, int param, uint64_t *__restrict__ keys) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t r0 = wave * 64;
@@ -596,9 +654,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
         uint32_t lo_off = groups[lo].leaf_off;
         my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
     }
-    float mine0[ZH_GROUP], mine1 = 0.f;
+    float mine0[ZH_GROUP], mine1[ZH_GROUP];
 #pragma unroll
-    for (int m = 0; m < ZH_GROUP; m++) mine0[m] = 0.f;
+    for (int m = 0; m < ZH_GROUP; m++) { mine0[m] = 0.f; mine1[m] = 0.f; }
     if (D > 0) {
         constexpr int DD = (D > 0 ? D : 4);
         constexpr int NV = RowVec<DD>::NV;
@@ -624,12 +682,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                         for (int m = 0; m < ZH_GROUP; m++)
                             if ((uint32_t)m < gsize) load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[m]);
                     }
-                    float s0[ZH_GROUP], s1;
-                    row_sums_group<DD, COSINE>(v[r], q, gsize, lane, s0, s1);
+                    float s0[ZH_GROUP], s1[ZH_GROUP];
+#pragma unroll
+                    for (int m = 0; m < ZH_GROUP; m++) { s0[m] = 0.f; s1[m] = 0.f; }
+                    row_sums_group<DD, KIND>(v[r], q, gsize, lane, param, s0, s1);
                     if (lane == i) {
 #pragma unroll
-                        for (int m = 0; m < ZH_GROUP; m++) mine0[m] = s0[m];
-                        mine1 = s1;
+                        for (int m = 0; m < ZH_GROUP; m++) { mine0[m] = s0[m]; mine1[m] = KIND == K_COS ? s1[0] : s1[m]; }
                     }
                 }
             }
@@ -640,13 +699,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
             uint32_t g = __builtin_amdgcn_readlane(my_g, i);
             uint32_t gsize = groups[g].gsize;
             for (uint32_t m = 0; m < gsize; m++) {
-                float ab, a2, l2;
-                lane_sums_generic(X + (size_t)id * d, Q + (size_t)groups[g].b[m] * d, d, lane, COSINE, ab, a2, l2);
+                float t0, t1;
+                lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)groups[g].b[m] * d, d, lane, param, t0, t1);
                 if (lane == i) {
 #pragma unroll
                     for (int mm = 0; mm < ZH_GROUP; mm++)
-                        if ((uint32_t)mm == m) mine0[mm] = COSINE ? ab : l2;
-                    mine1 = a2;
+                        if ((uint32_t)mm == m) { mine0[mm] = t0; mine1[mm] = t1; }
                 }
             }
         }
@@ -656,51 +714,77 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
 #pragma unroll
         for (int m = 0; m < ZH_GROUP; m++)
             if ((uint32_t)m < G.gsize)
-                keys[G.key_off[m] + my_within] =
-                    COSINE ? key_cosine(mine0[m], mine1, QQ[G.b[m]], mode) : key_l2(mine0[m], metric);
+                keys[G.key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1[m], KIND == K_COS ? QQ[G.b[m]] : 0.f);
     }
 }
 
-template <int D>
-static hipError_t launch_sweep_d(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
+template <int D, int KIND>
+static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
                                  const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int mode, uint64_t *dKeys,
+                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
                                  hipStream_t s) {
     uint64_t waves = (R_grouped + 63) / 64;
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-#define ZH_SW_LAUNCH(COS, RG, NTV)                                                                              \
-    hipLaunchKernelGGL((sweep_kernel<D, COS, RG, NTV>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,   \
-                       dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys)
     // rows are streamed once per batch: non-temporal loads (+1.3 % measured, profiles/); ZH_SWEEP_VARIANT=1
     // switches them off for A/B runs.  Rows in flight (2/4/8) made no measurable difference: 4.
     static const int variant = [] { const char *e = getenv("ZH_SWEEP_VARIANT"); return e ? atoi(e) : 0; }();
-    const bool cosv = metric == ZH_COSINE;
-    if (variant == 1) { if (cosv) ZH_SW_LAUNCH(true, 4, false); else ZH_SW_LAUNCH(false, 4, false); }
-    else if (cosv) ZH_SW_LAUNCH(true, 4, true);
-    else ZH_SW_LAUNCH(false, 4, true);
-#undef ZH_SW_LAUNCH
+    if (variant == 1)
+        hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+                           dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys);
+    else
+        hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+                           dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys);
     return hipGetLastError();
+}
+
+// the two simsimd-path kinds get every specialised dimension; the ten `distances`-path kinds the three
+// production dimensions (text 384, image/audio 768, SIFT-style 128) and otherwise the runtime-d kernel
+template <int KIND>
+static hipError_t launch_sweep_kind(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
+                                    const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                                    const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param,
+                                    uint64_t *dKeys, hipStream_t s) {
+#define ZH_SWEEP_CASE(DD) \
+    case DD: return launch_sweep_k<DD, KIND>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s)
+    if (KIND == K_L2 || KIND == K_COS) {
+        switch (d) {
+            ZH_SWEEP_CASE(64);
+            ZH_SWEEP_CASE(256);
+            ZH_SWEEP_CASE(512);
+            ZH_SWEEP_CASE(1024);
+            ZH_SWEEP_CASE(1536);
+        default: break;
+        }
+    }
+    switch (d) {
+        ZH_SWEEP_CASE(128);
+        ZH_SWEEP_CASE(384);
+        ZH_SWEEP_CASE(768);
+    default: return launch_sweep_k<0, KIND>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
+    }
+#undef ZH_SWEEP_CASE
 }
 
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
-                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s) {
+                           uint64_t R_grouped, int metric, int param, uint64_t *dKeys, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
-#define ZH_SWEEP_CASE(DD) \
-    case DD: return launch_sweep_d<DD>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys, s)
-    switch (d) {
-        ZH_SWEEP_CASE(64);
-        ZH_SWEEP_CASE(128);
-        ZH_SWEEP_CASE(256);
-        ZH_SWEEP_CASE(384);
-        ZH_SWEEP_CASE(512);
-        ZH_SWEEP_CASE(768);
-        ZH_SWEEP_CASE(1024);
-        ZH_SWEEP_CASE(1536);
-    default: return launch_sweep_d<0>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, mode, dKeys, s);
+#define ZH_KIND_CASE(K) \
+    case K: return launch_sweep_kind<K>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s)
+    switch (zh_kind_of(metric)) {
+        ZH_KIND_CASE(K_COS);
+        ZH_KIND_CASE(K_MAX);
+        ZH_KIND_CASE(K_CANB);
+        ZH_KIND_CASE(K_BRAY);
+        ZH_KIND_CASE(K_ABS);
+        ZH_KIND_CASE(K_P3);
+        ZH_KIND_CASE(K_P4);
+        ZH_KIND_CASE(K_HAMM);
+        ZH_KIND_CASE(K_PP);
+    default: return launch_sweep_kind<K_L2>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
     }
-#undef ZH_SWEEP_CASE
+#undef ZH_KIND_CASE
 }
 
 // n contiguous rows against one query: a single synthetic group, ids = row numbers

@@ -68,6 +68,59 @@ class L2Distance(_Metric):
     metric = _ffi.L2
 
 
+class ChebyshevDistance(_Metric):
+    """src/distance.rs:51-61"""
+    metric = _ffi.CHEBYSHEV
+
+
+class CanberraDistance(_Metric):
+    """src/distance.rs:63-73"""
+    metric = _ffi.CANBERRA
+
+
+class BrayCurtisDistance(_Metric):
+    """src/distance.rs:75-85"""
+    metric = _ffi.BRAY_CURTIS
+
+
+class ManhattanDistance(_Metric):
+    """src/distance.rs:87-97"""
+    metric = _ffi.MANHATTAN
+
+
+class L3Distance(_Metric):
+    """src/distance.rs:116-126"""
+    metric = _ffi.L3
+
+
+class L4Distance(_Metric):
+    """src/distance.rs:128-138"""
+    metric = _ffi.L4
+
+
+class HammingDistance(_Metric):
+    """src/distance.rs:140-158: bitwise Hamming distance of the low bytes of the f32 bit patterns"""
+    metric = _ffi.HAMMING
+
+
+class MinkowskiDistance(_Metric):
+    """src/distance.rs:160-174; `power` is the struct's field"""
+    metric = _ffi.MINKOWSKI
+
+    def __init__(self, power, device=-1):
+        super().__init__(device)
+        self.power = self.mode = int(power)
+
+
+class PNormDistance(_Metric):
+    """src/distance.rs:176-190"""
+    metric = _ffi.PNORM
+
+    def __init__(self, power, device=-1):
+        super().__init__(device)
+        self.power = self.mode = int(power)
+
+
 # ------------------------------------------------------------------- src/database/index/lsh.rs
 @dataclass
 class LSHIndexOptions:
