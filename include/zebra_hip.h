@@ -133,6 +133,7 @@ typedef struct zh_stats_t {
     uint64_t timed_batches;
     uint64_t sweep_rows_accum;  /* rows_scored summed over the timed batches */
     uint64_t swept_rows_accum;  /* rows_swept summed over the timed batches */
+    uint64_t sweep_launches_accum; /* sweep_kernel launches over the timed batches (a batch is several launches) */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -185,6 +186,24 @@ ZH_API int zh_search_batch(zh_index *idx, const float *q, size_t b, size_t k, in
 ZH_API int zh_search_batch_device(zh_index *idx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode,
                            uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
 
+/* Pipelined form of zh_search_batch_device (new; the reference has one blocking search per query): a context
+ * is one in-flight batch with its own scratch.  begin enqueues the hash and the walk's counting pass on
+ * `stream` and returns; finish waits (host side) only for three totals, then enqueues the distance sweep,
+ * the selection and the final top-k and returns; wait blocks until the results are complete.  With two
+ * contexts on two streams one host thread keeps the sweep of batch i and the small latency-bound kernels of
+ * batches i and i+1 on the GPU together.  Queries and outputs must stay valid until wait (or a stream sync). */
+typedef struct zh_search_ctx zh_search_ctx;
+ZH_API int zh_search_ctx_create(zh_index *idx, zh_search_ctx **out);
+ZH_API void zh_search_ctx_destroy(zh_search_ctx *ctx);
+ZH_API int zh_search_begin(zh_search_ctx *ctx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode,
+                    void *stream);
+/* sweep_stream (may be NULL = the begin stream): the stream the HBM-bound distance sweep is enqueued on; sharing
+ * one sweep stream between contexts runs the sweeps of successive batches back to back while the other kernels of
+ * each batch overlap them on the contexts' own streams (the library inserts the event dependencies). */
+ZH_API int zh_search_finish(zh_search_ctx *ctx, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts,
+                     void *sweep_stream);
+ZH_API int zh_search_wait(zh_search_ctx *ctx);
+
 /* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers). */
 ZH_API int zh_distance_batch(int metric, int cosine_mode, const float *a, const float *q, size_t n, size_t dim,
                       uint64_t *out_keys, int device);
@@ -192,7 +211,8 @@ ZH_API int zh_distance_pair(int metric, int cosine_mode, const float *a, const f
                      int device);
 
 /* Shard merge: S lists of b x k (ids, keys) with counts S x b, all in device memory (e.g. the
- * output of an RCCL all-gather of every rank's zh_search_batch_device result) -> b x k merged. */
+ * output of an RCCL all-gather of every rank's zh_search_batch_device result) -> b x k merged.
+ * The kernel is enqueued on `stream` and the call returns; synchronise the stream before reading. */
 ZH_API int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_ids,
                          const uint64_t *d_keys, const uint32_t *d_counts, uint64_t *d_out_ids,
                          uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);

@@ -405,3 +405,55 @@ def test_search_device_entry_point(za):
     st = ix.stats()
     assert st["timed_batches"] == 1 and st["ms_sweep"] > 0 and st["rows_scored"] >= st["rows_unique"] > 0
     assert st["visits"] >= B * T
+
+
+def test_pipelined_contexts_match_blocking_search(za):
+    """zh_search_begin / finish / wait with two contexts on two streams == the blocking call"""
+    import torch
+    n, d, M, T, k, B = 20000, 128, 256, 8, 10, 64
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append_synthetic(n)
+    ix.build()
+    f = zo.Forest.from_arrays(zo.synth_rows(n, d), M, ix.get_forest())
+    m = za.L2SquaredDistance()
+    qs = []
+    for i in range(5):
+        q = torch.empty((B, d), dtype=torch.float32, device="cuda")
+        za.synth_queries_device(0, q.data_ptr(), n, B, d, b0=i * B)
+        qs.append(q)
+    torch.cuda.synchronize()
+    slots = [dict(ctx=ix.search_context(), st=torch.cuda.Stream(), ids=torch.empty((B, k), dtype=torch.int64, device="cuda"),
+                  keys=torch.empty((B, k), dtype=torch.int64, device="cuda"), counts=torch.empty(B, dtype=torch.int32, device="cuda"))
+             for _ in range(2)]
+    got = {}
+    heavy = torch.cuda.Stream()
+    slots[0]["ctx"].begin(qs[0].data_ptr(), B, k, m, slots[0]["st"].cuda_stream)
+    for i in range(5):
+        if i + 1 < 5:
+            sl = slots[(i + 1) % 2]
+            if (i - 1) in got and got[i - 1] is None:
+                pass
+            # the slot's previous results must be consumed before its buffers are reused
+            if i - 1 >= 0:
+                sl["ctx"].wait()
+                got[i - 1] = (sl["ids"].cpu().numpy().view(np.uint64).copy(), sl["keys"].cpu().numpy().view(np.uint64).copy())
+            sl["ctx"].begin(qs[i + 1].data_ptr(), B, k, m, sl["st"].cuda_stream)
+        sl = slots[i % 2]
+        sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(),
+                         heavy.cuda_stream if i % 2 else None)
+    for i in (3, 4):
+        sl = slots[i % 2]
+        sl["ctx"].wait()
+        got[i] = (sl["ids"].cpu().numpy().view(np.uint64).copy(), sl["keys"].cpu().numpy().view(np.uint64).copy())
+    for i in range(5):
+        oi, ok, _ = f.search_batch(zo.synth_queries(B, d, n, b0=i * B), k, zo.L2SQ)
+        assert (got[i][0] == oi).all() and (got[i][1] == ok).all(), i
+    # misuse is reported, not crashed on
+    c = ix.search_context()
+    with pytest.raises(za.ZhError):
+        c.finish(0, 0, 0)
+    c.begin(qs[0].data_ptr(), B, k, m)
+    with pytest.raises(za.ZhError):
+        c.begin(qs[0].data_ptr(), B, k, m)
+    c.finish(slots[0]["ids"].data_ptr(), slots[0]["keys"].data_ptr(), slots[0]["counts"].data_ptr())
+    c.wait()

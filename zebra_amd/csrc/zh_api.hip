@@ -74,6 +74,34 @@ struct DevBuf {
     T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// One in-flight search batch: its own workspace, events and (borrowed) stream, so that several batches can be
+// in flight on different streams (zh_search_begin / zh_search_finish / zh_search_wait).
+struct zh_search_ctx {
+    zh_index *ix = nullptr;
+    DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff;
+    ZhTotals *h_totals = nullptr;  // pinned
+    hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
+    hipEvent_t ev_totals = nullptr, ev_emit = nullptr, ev_sw0 = nullptr, ev_sw1 = nullptr;
+    bool ev_ok = false;
+    // the batch in flight
+    int state = 0;  // 0 idle, 1 begun (first half enqueued), 2 finished (second half enqueued, results pending)
+    bool trivial = false;
+    const float *dQ = nullptr;
+    size_t B = 0, k = 0;
+    int metric = 0, mode = 0;
+    uint32_t P_dense = 0, wpq = 0;
+    hipStream_t s = nullptr;
+    ZhTotals tot{};
+    void release_all() {
+        DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff};
+        for (DevBuf *b : ws) b->release();
+        if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
+        if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
+    }
+};
+
 struct zh_index {
     zh_options opt{};
     int device = 0;
@@ -94,15 +122,13 @@ struct zh_index {
     std::vector<uint32_t> h_leaf_ids;          // host mirror of leaf_ids, materialised by the first incremental add
     uint32_t max_leaf_len = 0;
 
-    // per-batch workspace
-    DevBuf wQ, wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys,
-        wCandIds, wOutIds, wOutKeys, wOutCounts, wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff;
-    ZhTotals *h_totals = nullptr;  // pinned
+    // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
+    zh_search_ctx dctx;
+    DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
 
     int dense_levels = -1;
     int profiling = 0;
-    hipEvent_t ev[8] = {};
-    bool ev_ok = false;
+    std::mutex stats_mu;
     zh_stats_t stats{};
 };
 
@@ -125,6 +151,19 @@ static ZhForestDev forest_dev(const zh_index *ix) {
     f.n_planes = ix->n_planes;
     f.n_trees = ix->n_trees;
     return f;
+}
+
+static int ctx_init(zh_search_ctx *c, zh_index *ix) {
+    c->ix = ix;
+    hipError_t e = hipHostMalloc((void **)&c->h_totals, sizeof(ZhTotals), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_emit, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_sw0));
+    HIPCHK(hipEventCreate(&c->ev_sw1));
+    c->ev_ok = true;
+    return ZH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -167,8 +206,8 @@ extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
     }
     e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ix; return fail(ZH_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    e = hipHostMalloc((void **)&ix->h_totals, sizeof(ZhTotals), hipHostMallocDefault);
-    if (e != hipSuccess) { hipStreamDestroy(ix->stream); delete ix; return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    rc = ctx_init(&ix->dctx, ix);
+    if (rc) { hipStreamDestroy(ix->stream); delete ix; return rc; }
     if (opt->reserve_rows) {
         rc = ix->X.ensure((size_t)opt->reserve_rows * opt->dim * sizeof(float));
         if (rc) { zh_index_destroy(ix); return rc; }
@@ -194,13 +233,9 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (ix->stream) hipStreamSynchronize(ix->stream);
     free_forest(ix);
     ix->X.release();
-    DevBuf *ws[] = {&ix->wQ, &ix->wQQ, &ix->wBits, &ix->wCounts, &ix->wInline, &ix->wRowBase, &ix->wCandBase,
-                    &ix->wVisitBase, &ix->wTotals, &ix->wVisits, &ix->wKeys, &ix->wCandKeys, &ix->wCandIds,
-                    &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts, &ix->wLeafCount, &ix->wLeafFill, &ix->wGroupBase,
-                    &ix->wGroupRowBase, &ix->wGroups, &ix->wGroupRowOff};
+    ix->dctx.release_all();
+    DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
-    if (ix->ev_ok) for (auto &e : ix->ev) hipEventDestroy(e);
-    if (ix->h_totals) hipHostFree(ix->h_totals);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -690,10 +725,6 @@ extern "C" int zh_set_profiling(zh_index *ix, int level) {
     std::lock_guard<std::mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
-    if (level > 0 && !ix->ev_ok) {
-        for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
-        ix->ev_ok = true;
-    }
     ix->profiling = level;
     return ZH_OK;
 }
@@ -704,13 +735,13 @@ extern "C" int zh_set_dense_levels(zh_index *ix, int levels) {
 }
 extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
     if (!ix || !out) return fail(ZH_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
     *out = ix->stats;
     return ZH_OK;
 }
 extern "C" int zh_stats_reset(zh_index *ix) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
     memset(&ix->stats, 0, sizeof ix->stats);
     return ZH_OK;
 }
@@ -732,106 +763,165 @@ static uint32_t choose_dense_planes(const zh_index *ix, size_t B, size_t k) {
     return best;
 }
 
-static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
-                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+int ctx_wait(zh_search_ctx *c);
+
+// first half of a batch: hash, the walk's counting pass, scans; the three totals travel to the host
+static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int metric, int mode, hipStream_t s) {
+    zh_index *ix = c->ix;
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
     int rc;
-    if (B == 0) return ZH_OK;
-    if (k == 0 || ix->n_rows == 0 || T == 0) {  // core.rs:295-297: empty index -> no neighbours
-        HIPCHK(hipMemsetAsync(dOutCounts, 0, B * 4, s));
-        if (k) {
-            HIPCHK(hipMemsetAsync(dOutIds, 0xFF, B * k * 8, s));
-            HIPCHK(hipMemsetAsync(dOutKeys, 0xFF, B * k * 8, s));
+    if (c->state == 1) return fail(ZH_ESTATE, "zh_search_begin: the context already has a batch begun; finish it first");
+    if (c->state == 2 && (rc = ctx_wait(c))) return rc;  // the previous batch was never waited for: retire it
+    c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
+    c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
+    c->state = 1;
+    if (c->trivial) return ZH_OK;
+    const uint64_t pairs = (uint64_t)B * T;
+    if (pairs > 0x7FFFFFFFull) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees too large"); }
+    c->P_dense = choose_dense_planes(ix, B, k);
+    c->wpq = (c->P_dense + 63) / 64 * 2;
+    const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
+    c->state = 0;  // a failure below leaves the context idle
+    if ((rc = c->wQQ.ensure(B * 4))) return rc;
+    if ((rc = c->wBits.ensure(std::max<size_t>((size_t)B * c->wpq * 4, 4)))) return rc;
+    if ((rc = c->wCounts.ensure(pairs * sizeof(ZhPairCounts)))) return rc;
+    if ((rc = c->wInline.ensure(pairs * ZH_INLINE_VISITS * sizeof(ZhVisit)))) return rc;
+    if ((rc = c->wRowBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = c->wCandBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = c->wVisitBase.ensure((pairs + 1) * 8))) return rc;
+    if ((rc = c->wTotals.ensure(sizeof(ZhTotals)))) return rc;
+    if ((rc = c->wLeafCount.ensure(nn * 4))) return rc;
+    if ((rc = c->wLeafFill.ensure(nn * 4))) return rc;
+    if ((rc = c->wGroupBase.ensure(nn * 4))) return rc;
+    if ((rc = c->wGroupRowBase.ensure(nn * 8))) return rc;
+    HIPCHK(hipMemsetAsync(c->wLeafCount.p, 0, nn * 4, s));
+    HIPCHK(hipMemsetAsync(c->wLeafFill.p, 0, nn * 4, s));
+    ZhForestDev f = forest_dev(ix);
+    HIPCHK(hipEventRecord(c->ev[0], s));
+    if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));
+    if (c->P_dense)
+        HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, c->P_dense, d, c->wBits.as<uint32_t>(), c->wpq, nullptr, s));
+    HIPCHK(hipEventRecord(c->ev[1], s));
+    HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
+                                c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), s));
+    HIPCHK(zh_launch_leaf_scan(f, c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
+                               c->wGroupRowBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
+    HIPCHK(zh_launch_pair_scan(c->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, c->wRowBase.as<uint64_t>(),
+                               c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
+    HIPCHK(hipMemcpyAsync(c->h_totals, c->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev_totals, s));
+    c->state = 1;
+    return ZH_OK;
+}
+
+// second half: waits (host side) for the totals only, sizes the scratch, enqueues emit -> sweep -> select -> final
+static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t heavy) {
+    zh_index *ix = c->ix;
+    if (c->state != 1) return fail(ZH_ESTATE, "zh_search_finish without zh_search_begin");
+    const uint32_t d = ix->opt.dim, T = ix->n_trees;
+    const size_t B = c->B, k = c->k;
+    hipStream_t s = c->s;
+    int rc;
+    c->state = 0;
+    if (c->trivial) {
+        if (B) {
+            HIPCHK(hipMemsetAsync(dOutCounts, 0, B * 4, s));
+            if (k) {
+                HIPCHK(hipMemsetAsync(dOutIds, 0xFF, B * k * 8, s));
+                HIPCHK(hipMemsetAsync(dOutKeys, 0xFF, B * k * 8, s));
+            }
         }
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipEventRecord(c->ev[5], s));
+        c->state = 2;
         return ZH_OK;
     }
-    const uint64_t pairs = (uint64_t)B * T;
-    if (pairs > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "batch * num_trees too large");
-    const bool prof = ix->profiling > 0 && ix->ev_ok;
-    const uint32_t P_dense = choose_dense_planes(ix, B, k);
-    const uint32_t wpq = (P_dense + 63) / 64 * 2;
-    if ((rc = ix->wQQ.ensure(B * 4))) return rc;
-    if ((rc = ix->wBits.ensure(std::max<size_t>((size_t)B * wpq * 4, 4)))) return rc;
-    if ((rc = ix->wCounts.ensure(pairs * sizeof(ZhPairCounts)))) return rc;
-    if ((rc = ix->wInline.ensure(pairs * ZH_INLINE_VISITS * sizeof(ZhVisit)))) return rc;
-    if ((rc = ix->wRowBase.ensure((pairs + 1) * 8))) return rc;
-    if ((rc = ix->wCandBase.ensure((pairs + 1) * 8))) return rc;
-    if ((rc = ix->wVisitBase.ensure((pairs + 1) * 8))) return rc;
-    if ((rc = ix->wTotals.ensure(sizeof(ZhTotals)))) return rc;
-    const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
-    if ((rc = ix->wLeafCount.ensure(nn * 4))) return rc;
-    if ((rc = ix->wLeafFill.ensure(nn * 4))) return rc;
-    if ((rc = ix->wGroupBase.ensure(nn * 4))) return rc;
-    if ((rc = ix->wGroupRowBase.ensure(nn * 8))) return rc;
-    HIPCHK(hipMemsetAsync(ix->wLeafCount.p, 0, nn * 4, s));
-    HIPCHK(hipMemsetAsync(ix->wLeafFill.p, 0, nn * 4, s));
-    ZhForestDev f = forest_dev(ix);
-    if (prof) HIPCHK(hipEventRecord(ix->ev[0], s));
-    if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, ix->wQQ.as<float>(), s));
-    if (P_dense)
-        HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, P_dense, d, ix->wBits.as<uint32_t>(), wpq, nullptr, s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev[1], s));
-    HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
-                                ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), ix->wLeafCount.as<uint32_t>(), s));
-    HIPCHK(zh_launch_leaf_scan(f, ix->wLeafCount.as<uint32_t>(), ix->wGroupBase.as<uint32_t>(),
-                               ix->wGroupRowBase.as<uint64_t>(), ix->wTotals.as<ZhTotals>(), s));
-    HIPCHK(zh_launch_pair_scan(ix->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, ix->wRowBase.as<uint64_t>(),
-                               ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wTotals.as<ZhTotals>(), s));
-    HIPCHK(hipMemcpyAsync(ix->h_totals, ix->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const ZhTotals tot = *ix->h_totals;
+    HIPCHK(hipEventSynchronize(c->ev_totals));
+    const ZhTotals tot = c->tot = *c->h_totals;
     if (tot.visits > 0xFFFFFFFull || tot.rows >= (1ull << 36))
         return fail(ZH_ELIMIT, "more than 2^28 leaf visits or 2^36 scored rows in one batch; use a smaller batch");
-    if ((rc = ix->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
-    if ((rc = ix->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
-    if ((rc = ix->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;
-    if ((rc = ix->wKeys.ensure(std::max<uint64_t>(tot.rows, 1) * 8))) return rc;
-    if ((rc = ix->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
-    if ((rc = ix->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
-    HIPCHK(zh_launch_walk_emit(f, dQ, (uint32_t)B, d, (int32_t)k, ix->wBits.as<uint32_t>(), wpq, P_dense,
-                               ix->wCounts.as<ZhPairCounts>(), ix->wInline.as<ZhVisit>(), ix->wRowBase.as<uint64_t>(),
-                               ix->wCandBase.as<uint64_t>(), ix->wVisitBase.as<uint64_t>(), ix->wVisits.as<ZhVisit>(),
-                               ix->wLeafCount.as<uint32_t>(), ix->wLeafFill.as<uint32_t>(), ix->wGroupBase.as<uint32_t>(),
-                               ix->wGroupRowBase.as<uint64_t>(), ix->wGroups.as<ZhGroup>(), ix->wGroupRowOff.as<uint64_t>(), s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev[2], s));
-    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, dQ, ix->wQQ.as<float>(), ix->wGroups.as<ZhGroup>(),
-                           ix->wGroupRowOff.as<uint64_t>(), tot.groups, f.leaf_ids, tot.group_rows, metric, mode,
-                           ix->wKeys.as<uint64_t>(), s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev[3], s));
-    HIPCHK(zh_launch_select(ix->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, ix->wKeys.as<uint64_t>(),
-                            ix->wCandKeys.as<uint64_t>(), ix->wCandIds.as<uint32_t>(), s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev[4], s));
-    HIPCHK(zh_launch_final(ix->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, ix->wCandKeys.as<uint64_t>(),
-                           ix->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev[5], s));
-    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = c->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
+    if ((rc = c->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
+    if ((rc = c->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;
+    if ((rc = c->wKeys.ensure(std::max<uint64_t>(tot.rows, 1) * 8))) return rc;
+    if ((rc = c->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
+    if ((rc = c->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
+    ZhForestDev f = forest_dev(ix);
+    HIPCHK(zh_launch_walk_emit(f, c->dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
+                               c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wRowBase.as<uint64_t>(),
+                               c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wVisits.as<ZhVisit>(),
+                               c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
+                               c->wGroupRowBase.as<uint64_t>(), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), s));
+    HIPCHK(hipEventRecord(c->ev[2], s));
+    // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
+    // successive batches execute back to back while everything else overlaps them on the contexts' own streams
+    hipStream_t hs = heavy ? heavy : s;
+    if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
+    HIPCHK(hipEventRecord(c->ev_sw0, hs));
+    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
+                           c->wGroupRowOff.as<uint64_t>(), tot.groups, f.leaf_ids, tot.group_rows, c->metric, c->mode,
+                           c->wKeys.as<uint64_t>(), hs));
+    HIPCHK(hipEventRecord(c->ev_sw1, hs));
+    if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    HIPCHK(zh_launch_select(c->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, c->wKeys.as<uint64_t>(),
+                            c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), s));
+    HIPCHK(hipEventRecord(c->ev[4], s));
+    HIPCHK(zh_launch_final(c->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, c->wCandKeys.as<uint64_t>(),
+                           c->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    c->state = 2;
+    return ZH_OK;
+}
+
+// block until the batch's results are complete; fold its counters and stage timings into the index's stats
+int ctx_wait(zh_search_ctx *c) {
+    zh_index *ix = c->ix;
+    if (c->state == 1) return fail(ZH_ESTATE, "zh_search_wait: the batch was begun but not finished");
+    if (c->state != 2) return ZH_OK;
+    c->state = 0;
+    HIPCHK(hipEventSynchronize(c->ev[5]));
+    if (c->trivial) return ZH_OK;
+    const ZhTotals tot = c->tot;
+    uint64_t uniq = 0;
+    if (ix->profiling >= 2 && tot.visits) {  // R_unique: rows of the distinct leaves touched by the batch
+        std::vector<ZhVisit> hv(tot.visits);
+        HIPCHK(hipMemcpy(hv.data(), c->wVisits.p, tot.visits * sizeof(ZhVisit), hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint32_t, uint32_t>> leaves(hv.size());
+        for (size_t i = 0; i < hv.size(); i++) leaves[i] = {hv[i].leaf_off, hv[i].len};
+        std::sort(leaves.begin(), leaves.end());
+        leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
+        for (auto &l : leaves) uniq += l.second;
+    }
+    float ms[5] = {0, 0, 0, 0, 0};
+    if (ix->profiling > 0) {
+        for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms[2], c->ev_sw0, c->ev_sw1));  // the sweep kernel alone, on the stream it ran on
+    }
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
     zh_stats_t &st = ix->stats;
-    st.batch = B; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
-    st.planes_dense = P_dense; st.planes_total = ix->n_planes;
+    st.batch = c->B; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
+    st.planes_dense = c->P_dense; st.planes_total = ix->n_planes;
     st.rows_swept = tot.group_rows;
-    st.sweep_bytes = tot.group_rows * ((uint64_t)4 * d + 4) + tot.rows * 8;
-    if (prof) {
-        float ms[5];
-        for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]));
+    st.sweep_bytes = tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
+    if (ix->profiling >= 2) st.rows_unique = uniq;
+    if (ix->profiling > 0) {
         st.ms_hash += ms[0]; st.ms_walk += ms[1]; st.ms_sweep += ms[2]; st.ms_select += ms[3]; st.ms_final += ms[4];
         st.ms_total += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
         st.timed_batches++;
         st.sweep_rows_accum += tot.rows;
         st.swept_rows_accum += tot.group_rows;
-    }
-    if (ix->profiling >= 2 && tot.visits) {  // R_unique: rows of the distinct leaves touched by the batch
-        std::vector<ZhVisit> hv(tot.visits);
-        HIPCHK(hipMemcpy(hv.data(), ix->wVisits.p, tot.visits * sizeof(ZhVisit), hipMemcpyDeviceToHost));
-        std::vector<std::pair<uint32_t, uint32_t>> leaves(hv.size());
-        for (size_t i = 0; i < hv.size(); i++) leaves[i] = {hv[i].leaf_off, hv[i].len};
-        std::sort(leaves.begin(), leaves.end());
-        leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
-        uint64_t u = 0;
-        for (auto &l : leaves) u += l.second;
-        st.rows_unique = u;
+        const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim);
+        st.sweep_launches_accum += (tot.group_rows + rpl - 1) / rpl;
     }
     return ZH_OK;
+}
+
+static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
+                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    int rc = ctx_begin(&ix->dctx, dQ, B, k, metric, mode, s);
+    if (rc) return rc;
+    if ((rc = ctx_finish(&ix->dctx, dOutIds, dOutKeys, dOutCounts, nullptr))) return rc;
+    return ctx_wait(&ix->dctx);
 }
 
 static int check_metric(int metric, int mode) {
@@ -852,6 +942,48 @@ extern "C" int zh_search_batch_device(zh_index *ix, const float *d_q, size_t b, 
     if ((rc = set_device(ix))) return rc;
     return search_locked(ix, d_q, b, k, metric, mode, d_out_ids, d_out_keys, d_out_counts,
                          stream ? (hipStream_t)stream : ix->stream);
+}
+
+// ---- pipelined form: several batches in flight, each on its own context and stream ----------------------
+extern "C" int zh_search_ctx_create(zh_index *ix, zh_search_ctx **out) {
+    if (!ix || !out) return fail(ZH_EINVAL, "zh_search_ctx_create: null argument");
+    int rc = set_device(ix);
+    if (rc) return rc;
+    zh_search_ctx *c = new (std::nothrow) zh_search_ctx();
+    if (!c) return fail(ZH_ENOMEM, "out of host memory");
+    if ((rc = ctx_init(c, ix))) { c->release_all(); delete c; return rc; }
+    *out = c;
+    return ZH_OK;
+}
+extern "C" void zh_search_ctx_destroy(zh_search_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->ix->device);
+    if (c->state == 2) hipEventSynchronize(c->ev[5]);
+    else if (c->state == 1 && c->s) hipStreamSynchronize(c->s);
+    c->release_all();
+    delete c;
+}
+extern "C" int zh_search_begin(zh_search_ctx *c, const float *d_q, size_t b, size_t k, int metric, int mode, void *stream) {
+    if (!c || (b && !d_q)) return fail(ZH_EINVAL, "zh_search_begin: null argument");
+    if (k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k %zu > ZH_MAX_TOPK (%u)", k, ZH_MAX_TOPK);
+    int rc = check_metric(metric, mode);
+    if (rc) return rc;
+    if ((rc = set_device(c->ix))) return rc;
+    return ctx_begin(c, d_q, b, k, metric, mode, stream ? (hipStream_t)stream : c->ix->stream);
+}
+extern "C" int zh_search_finish(zh_search_ctx *c, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts,
+                                void *sweep_stream) {
+    if (!c) return fail(ZH_EINVAL, "zh_search_finish: null context");
+    if (c->B && (!d_out_counts || (c->k && (!d_out_ids || !d_out_keys)))) return fail(ZH_EINVAL, "zh_search_finish: null output");
+    int rc = set_device(c->ix);
+    if (rc) return rc;
+    return ctx_finish(c, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)sweep_stream);
+}
+extern "C" int zh_search_wait(zh_search_ctx *c) {
+    if (!c) return fail(ZH_EINVAL, "zh_search_wait: null context");
+    int rc = set_device(c->ix);
+    if (rc) return rc;
+    return ctx_wait(c);
 }
 
 extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k, int metric, int mode,
@@ -959,8 +1091,7 @@ extern "C" int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, siz
     int rc = pick_device(device);
     if (rc) return rc;
     HIPCHK(zh_launch_merge(n_shards, (uint32_t)b, (uint32_t)k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    return ZH_OK;
+    return ZH_OK;  // enqueued on `stream`; the caller synchronises
 }
 
 extern "C" int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,

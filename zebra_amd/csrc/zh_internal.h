@@ -84,7 +84,7 @@ __device__ __forceinline__ bool zh_plane_above(const float *__restrict__ w, floa
 #endif
 
 #define ZH_SORT_N 4096        // entries of the LDS sort buffer of the select / final kernels
-#define ZH_INLINE_VISITS 8    // visits a pair may record in the walk's first pass
+#define ZH_INLINE_VISITS 32    // visits a pair may record in the walk's first pass
 
 // ---- launchers (zh_search.hip) ---------------------------------------------------------------
 hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlanes, const float *dConsts,
@@ -109,6 +109,8 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
                            uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s);
+// flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
+uint64_t zh_sweep_rows_per_launch(uint32_t d);
 hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
                             const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s);
 hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,

@@ -304,10 +304,11 @@ __device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__r
 }
 
 // One WAVE per (query, tree) pair: control flow is wave-uniform.  A plane below the dense levels is hashed
-// on demand: the 64 lanes stage the plane (and, once, the query) into LDS with coalesced 16-B loads -- one
-// memory round trip instead of d/32 dependent ones -- and every lane then runs the ordered fma chain from
-// LDS broadcast reads (all lanes read the same address), so the sign is wave-uniform by construction.
-#define WALK_CHUNK 1024  // floats of plane / query staged per pass (d <= 1024: a single pass)
+// on demand with the wave's registers: lane l holds the contiguous elements [l*E, l*E+E) of the plane and of the
+// query (E = 16 per 1024-element pass), runs its E ordered fmas on the running sum and hands the sum to lane
+// l+1 through v_readlane -- 64 hops, exactly the k-ascending chain, no LDS and one coalesced load of the plane.
+#define WALK_E 16                       // elements per lane per pass
+#define WALK_PASS (64 * WALK_E)         // 1024 elements per pass
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -315,33 +316,50 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ void stage_chunk(float *dst, const float *__restrict__ src, uint32_t n, uint32_t lane,
-                                            bool vec4) {
-    if (vec4) {
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        for (uint32_t i = lane; i < n / 4; i += 64) d4[i] = s4[i];
+// this lane's E contiguous elements of src[k0 .. k0+1024) (zero beyond d)
+__device__ __forceinline__ void load_lane_block(const float *__restrict__ src, uint32_t k0, uint32_t d, uint32_t E,
+                                                uint32_t lane, bool vec4, float *r) {
+    const uint32_t base = k0 + lane * E;
+    if (vec4 && (E & 3u) == 0) {
+#pragma unroll
+        for (int j4 = 0; j4 < WALK_E / 4; j4++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)(4 * j4) < E && base + 4 * j4 < d) v = *reinterpret_cast<const float4 *>(src + base + 4 * j4);
+            r[4 * j4] = v.x; r[4 * j4 + 1] = v.y; r[4 * j4 + 2] = v.z; r[4 * j4 + 3] = v.w;
+        }
     } else {
-        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+#pragma unroll
+        for (int j = 0; j < WALK_E; j++) r[j] = ((uint32_t)j < E && base + j < d) ? src[base + j] : 0.0f;
     }
 }
 
-__device__ __forceinline__ float chain_chunk(const float *w, const float *x, uint32_t n, bool vec4, float acc) {
-    if (vec4) {
-        const float4 *w4 = reinterpret_cast<const float4 *>(w);
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-#pragma unroll 4
-        for (uint32_t k = 0; k < n / 4; k++) {
-            float4 a = w4[k], b = x4[k];
-            acc = __builtin_fmaf(a.x, b.x, acc);
-            acc = __builtin_fmaf(a.y, b.y, acc);
-            acc = __builtin_fmaf(a.z, b.z, acc);
-            acc = __builtin_fmaf(a.w, b.w, acc);
-        }
-    } else {
-        for (uint32_t k = 0; k < n; k++) acc = __builtin_fmaf(w[k], x[k], acc);
+// sequential fma chain over one pass: the sum visits lanes 0..63 in order
+template <int E>
+__device__ __forceinline__ float chain_pass_e(const float *w, const float *q, float acc) {
+#pragma unroll 1
+    for (int hop = 0; hop < 64; hop++) {
+        float a = acc;
+#pragma unroll
+        for (int j = 0; j < E; j++) a = __builtin_fmaf(w[j], q[j], a);  // padded elements are 0*0: a + 0 = a
+        acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), hop));
     }
     return acc;
+}
+__device__ __forceinline__ float chain_pass(const float *w, const float *q, uint32_t E, float acc) {
+    switch (E) {  // wave-uniform
+    case 4: return chain_pass_e<4>(w, q, acc);
+    case 8: return chain_pass_e<8>(w, q, acc);
+    case 12: return chain_pass_e<12>(w, q, acc);
+    default: return chain_pass_e<16>(w, q, acc);  // E is a multiple of 4 in 4..16; unused slots hold zeros
+    }
+}
+
+// E for a pass over elements [k0, min(k0 + 1024, d)): as few elements per lane as cover it (multiple of 4 when possible)
+__device__ __forceinline__ uint32_t pass_E(uint32_t d, uint32_t k0) {
+    uint32_t m = d - k0 < WALK_PASS ? d - k0 : WALK_PASS;
+    uint32_t E = (m + 63) / 64;
+    E = (E + 3) & ~3u;
+    return E > WALK_E ? WALK_E : E;
 }
 
 template <bool EMIT>
@@ -356,8 +374,6 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    const uint32_t *__restrict__ groupBase,
                                                    const uint64_t *__restrict__ groupRowBase,
                                                    ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff) {
-    __shared__ __attribute__((aligned(16))) float s_w[WALK_CHUNK];
-    __shared__ __attribute__((aligned(16))) float s_q[WALK_CHUNK];
     __shared__ int32_t st_node[WALK_STACK], st_n[WALK_STACK];
     const uint32_t T = f.n_trees, lane = threadIdx.x;
     const uint64_t pair = blockIdx.x;  // one wave (= one block) per pair
@@ -377,8 +393,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
     }
     const float *q = Q + (size_t)b * d;
     const bool vec4 = (d & 3u) == 0;
-    const bool one_pass = d <= WALK_CHUNK;
+    const bool one_pass = d <= WALK_PASS;
+    const uint32_t E0 = pass_E(d, 0);
     bool q_staged = false;
+    float qreg[WALK_E];
     int sp = 0;
     int32_t cur = (int32_t)f.roots[t], ncur = n;
     uint32_t nv = 0;
@@ -393,20 +411,17 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
             else {
                 const float *w = f.planes + (size_t)p * d;
                 float acc = 0.0f;
+                float wreg[WALK_E];
                 if (one_pass) {
-                    stage_chunk(s_w, w, d, lane, vec4);
-                    if (!q_staged) { stage_chunk(s_q, q, d, lane, vec4); q_staged = true; }
-                    wave_lds_sync();
-                    acc = chain_chunk(s_w, s_q, d, vec4, acc);
-                    wave_lds_sync();
+                    load_lane_block(w, 0, d, E0, lane, vec4, wreg);
+                    if (!q_staged) { load_lane_block(q, 0, d, E0, lane, vec4, qreg); q_staged = true; }
+                    acc = chain_pass(wreg, qreg, E0, acc);
                 } else {
-                    for (uint32_t k0 = 0; k0 < d; k0 += WALK_CHUNK) {
-                        uint32_t m = d - k0 < WALK_CHUNK ? d - k0 : WALK_CHUNK;
-                        stage_chunk(s_w, w + k0, m, lane, vec4);
-                        stage_chunk(s_q, q + k0, m, lane, vec4);
-                        wave_lds_sync();
-                        acc = chain_chunk(s_w, s_q, m, vec4, acc);
-                        wave_lds_sync();
+                    for (uint32_t k0 = 0; k0 < d; k0 += WALK_PASS) {
+                        const uint32_t E = pass_E(d, k0);
+                        load_lane_block(w, k0, d, E, lane, vec4, wreg);
+                        load_lane_block(q, k0, d, E, lane, vec4, qreg);
+                        acc = chain_pass(wreg, qreg, E, acc);
                     }
                 }
                 above = ((double)acc + (double)f.consts[p]) >= 0.0;  // lsh.rs:40-42
@@ -633,11 +648,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
                                                      const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
-                                                     const uint32_t *__restrict__ leaf_ids, uint64_t R_grouped,
-                                                     int metric, int param, uint64_t *__restrict__ keys) {
+                                                     const uint32_t *__restrict__ leaf_ids, uint64_t row_begin,
+                                                     uint64_t R_grouped, int metric, int param,
+                                                     uint64_t *__restrict__ keys) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t r0 = wave * 64;
+    const uint64_t r0 = row_begin + wave * 64;  // this launch covers flat rows [row_begin, R_grouped)
     if (r0 >= R_grouped) return;
     const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
     // lane i -> (group, stored row) of flat row r0 + i
@@ -718,23 +734,37 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
     }
 }
 
+uint64_t zh_sweep_rows_per_launch(uint32_t d) {
+    static const uint64_t launch_bytes = [] { const char *e = getenv("ZH_SWEEP_LAUNCH_MB"); return (uint64_t)(e ? atoi(e) : 12288) << 20; }();
+    uint64_t rows = launch_bytes / ((uint64_t)4 * (d ? d : 1));
+    rows = (rows + 255) / 256 * 256;
+    return rows < 65536 ? 65536 : rows;
+}
+
 template <int D, int KIND>
 static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
                                  const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                  const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
                                  hipStream_t s) {
-    uint64_t waves = (R_grouped + 63) / 64;
-    uint64_t blocks = (waves + 3) / 4;
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     // rows are streamed once per batch: non-temporal loads (+1.3 % measured, profiles/); ZH_SWEEP_VARIANT=1
     // switches them off for A/B runs.  Rows in flight (2/4/8) made no measurable difference: 4.
     static const int variant = [] { const char *e = getenv("ZH_SWEEP_VARIANT"); return e ? atoi(e) : 0; }();
-    if (variant == 1)
-        hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
-                           dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys);
-    else
-        hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
-                           dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys);
+    // One batch is issued as several launches of ~ZH_SWEEP_LAUNCH_BYTES each (about 2 ms of HBM time): a single
+    // 18-ms dispatch keeps its dispatch pipe busy until its last workgroup is issued, and kernels of other
+    // queues that share the pipe (the next batch's hash / walk, RCCL) would wait that long.
+    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(d);
+    for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
+        uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
+        uint64_t waves = (r_end - r + 63) / 64;
+        uint64_t blocks = (waves + 3) / 4;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if (variant == 1)
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+                               dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
+        else
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+                               dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
+    }
     return hipGetLastError();
 }
 

@@ -244,6 +244,10 @@ class LSHIndex:
         check(lib().zh_index_read_rows(self._h, first, n, _p(out)))
         return out
 
+    def search_context(self):
+        """one in-flight batch (zh_search_begin / finish / wait); create two to software-pipeline batches"""
+        return SearchContext(self)
+
     def rows_device_ptr(self):
         return lib().zh_index_rows_device(self._h)
 
@@ -259,6 +263,31 @@ class LSHIndex:
         if reset:
             check(lib().zh_stats_reset(self._h))
         return s.as_dict()
+
+
+class SearchContext:
+    """Pipelined search (include/zebra_hip.h, zh_search_begin/finish/wait) on raw device pointers."""
+
+    def __init__(self, index):
+        self._index = index  # keeps the index alive
+        self._h = C.c_void_p()
+        check(lib().zh_search_ctx_create(index._h, C.byref(self._h)))
+
+    def begin(self, d_q_ptr, b, top_k, metric, stream=None):
+        check(lib().zh_search_begin(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode, stream))
+
+    def finish(self, d_ids_ptr, d_keys_ptr, d_counts_ptr, sweep_stream=None):
+        check(lib().zh_search_finish(self._h, d_ids_ptr, d_keys_ptr, d_counts_ptr, sweep_stream))
+
+    def wait(self):
+        check(lib().zh_search_wait(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zh_search_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, stream=None):
