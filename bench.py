@@ -328,11 +328,11 @@ def main():
     traffic, traffic_src = None, None
     import glob
     cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
-    kname = "sweep_kernel<%d, %s>" % (d, "true" if wl["metric"] == "cosine" else "false")
+    kname = "sweep_kernel<%d, %d," % (d, 1 if wl["metric"] == "cosine" else 0)  # <D, KIND (0 = L2, 1 = cosine), ...>
     if cands and name == "cfg3" and S == 1 and not args.rows:
         try:
             pm = json.load(open(cands[-1]))
-            traffic = [v for k_, v in pm.items() if k_.startswith(kname[:-1])][0]["hbm_bytes_per_launch"]
+            traffic = [v for k_, v in pm.items() if k_.startswith(kname)][0]["hbm_bytes_per_launch"]
             if abs(traffic / bytes_alg - 1) > 0.5:
                 traffic = None  # the committed summary is from a different launch granularity
             traffic_src = os.path.relpath(cands[-1], ROOT)
