@@ -7,6 +7,8 @@
 // (point_is_above for every member, the hash's sequential fma chain) -> stable partition
 // (below | above) by a scan over per-chunk counts.  Leaves end up as contiguous runs of perm,
 // which is then used directly as leaf_ids.
+#include <cstdlib>
+
 #include "zh_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -164,10 +166,75 @@ __global__ __launch_bounds__(256) void classify_kernel(const float *__restrict__
     __syncthreads();
     if (tid == 0) chunk_above[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
+// The same classification with the rows staged through LDS: the block loads its 256 rows in coalesced 256-B
+// pieces (16 lanes per row piece, 4 rows per wave instruction) into a [row][64 + 4] tile -- every fetched line is
+// used whole, where the thread-per-row loads above re-fetch each line eight times -- and thread r then runs the
+// ordered chain over row r of the tile (ds_read_b128, pitch 68 floats: conflict-free) against the block-uniform
+// plane.  Requires d % 4 == 0.
+#define CL_KC 64
+#define CL_PITCH (CL_KC + 4)
+__global__ __launch_bounds__(256) void classify_lds_kernel(const float *__restrict__ X, uint32_t d,
+                                                            const uint32_t *__restrict__ perm,
+                                                            const ZhBuildNode *__restrict__ nodes,
+                                                            const ZhBuildChunk *__restrict__ chunks,
+                                                            const float *__restrict__ planes,
+                                                            const float *__restrict__ consts,
+                                                            uint8_t *__restrict__ flags,
+                                                            uint32_t *__restrict__ chunk_above) {
+    __shared__ __attribute__((aligned(16))) float tile[256 * CL_PITCH];
+    __shared__ uint32_t ids_s[256];
+    __shared__ uint32_t wsum[4];
+    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const uint32_t plane = nodes[ch.node].plane;
+    const float4 *__restrict__ w4 = reinterpret_cast<const float4 *>(planes + (size_t)plane * d);
+    const float c = consts[plane];
+    const uint32_t tid = threadIdx.x;
+    ids_s[tid] = tid < ch.count ? perm[ch.pos + tid] : 0xFFFFFFFFu;
+    __syncthreads();
+    float acc = 0.0f;
+    for (uint32_t k0 = 0; k0 < d; k0 += CL_KC) {
+        const uint32_t kc = d - k0 < CL_KC ? d - k0 : CL_KC;  // multiple of 4
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            uint32_t fidx = tid + 256 * i;
+            uint32_t row = fidx >> 4, c4 = fidx & 15;
+            uint32_t id = ids_s[row];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id != 0xFFFFFFFFu && 4 * c4 < kc) v = *reinterpret_cast<const float4 *>(X + (size_t)id * d + k0 + 4 * c4);
+            *reinterpret_cast<float4 *>(&tile[row * CL_PITCH + 4 * c4]) = v;
+        }
+        __syncthreads();
+        const float4 *mine = reinterpret_cast<const float4 *>(&tile[tid * CL_PITCH]);
+        for (uint32_t j = 0; j < kc / 4; j++) {
+            float4 x = mine[j], wv = w4[(k0 >> 2) + j];
+            acc = __builtin_fmaf(wv.x, x.x, acc);
+            acc = __builtin_fmaf(wv.y, x.y, acc);
+            acc = __builtin_fmaf(wv.z, x.z, acc);
+            acc = __builtin_fmaf(wv.w, x.w, acc);
+        }
+        __syncthreads();
+    }
+    bool above = false;
+    if (tid < ch.count) {
+        above = ((double)acc + (double)c) >= 0.0;  // lsh.rs:40-42
+        flags[ch.pos + tid] = above ? 1 : 0;
+    }
+    unsigned long long m = __ballot(above);
+    if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (tid == 0) chunk_above[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 hipError_t zh_launch_classify(const float *dX, uint32_t d, const uint32_t *dPerm, const ZhBuildNode *dNodes,
                               const ZhBuildChunk *dChunks, uint32_t n_chunks, const float *dPlanes,
                               const float *dConsts, uint8_t *dFlags, uint32_t *dChunkAbove, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
+    static const int variant = [] { const char *e = getenv("ZH_CLASSIFY_VARIANT"); return e ? atoi(e) : 0; }();
+    if ((d & 3u) == 0 && d >= 64 && variant != 1) {
+        hipLaunchKernelGGL(classify_lds_kernel, dim3(n_chunks), dim3(256), 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes,
+                           dConsts, dFlags, dChunkAbove);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(classify_kernel, dim3(n_chunks), dim3(256), 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes,
                        dConsts, dFlags, dChunkAbove);
     return hipGetLastError();
