@@ -24,16 +24,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum_canonical(float s) {
-    s = s + __shfl_xor(s, 1);
-    s = s + __shfl_xor(s, 2);
-    s = s + __shfl_xor(s, 4);
-    s = s + __shfl_xor(s, 8);
-    s = s + __shfl_xor(s, 16);
-    s = s + __shfl_xor(s, 32);
-    return s;
+// The canonical 64-lane xor-butterfly (steps 1,2,4,8,16,32; lane l adds its partner group's value).  After a step
+// every lane of a 2^k group holds the same value, so the partner may be ANY lane of the partner group: steps 1,2 are
+// DPP quad_perm, 4 and 8 DPP row_half_mirror / row_mirror, 16 one ds_swizzle, 32 two v_readlane -- no ds_bpermute,
+// bit-identical to s + __shfl_xor(s, m).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
 }
-
+struct OpAdd { __device__ __forceinline__ static float f(float a, float b) { return a + b; } };
+struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
+template <class OP>
+__device__ __forceinline__ float wave_butterfly(float s) {
+    s = OP::f(s, dpp_mov<0xB1>(s));   // quad_perm [1,0,3,2]  : xor 1
+    s = OP::f(s, dpp_mov<0x4E>(s));   // quad_perm [2,3,0,1]  : xor 2
+    s = OP::f(s, dpp_mov<0x141>(s));  // row_half_mirror      : other quad of the 8
+    s = OP::f(s, dpp_mov<0x140>(s));  // row_mirror           : other 8 of the 16
+    s = OP::f(s, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F)));  // xor 16
+    float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+    float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
+    return OP::f(s, (threadIdx.x & 32) ? lo : hi);  // xor 32
+}
+__device__ __forceinline__ float wave_sum_canonical(float s) { return wave_butterfly<OpAdd>(s); }
 __device__ __forceinline__ uint64_t f64_bits(double x) { return (uint64_t)__double_as_longlong(x); }
 
 // simsimd cos(): cosine DISTANCE clipped at 0 with the two zero-norm cases; then distance.rs:23-25
@@ -133,12 +145,7 @@ __device__ __forceinline__ void acc_elem(float a, float q, float &x0, float &x1,
 }
 template <int KIND>
 __device__ __forceinline__ float wave_combine(float x, float y, float z, float w) {
-    if (KIND == K_MAX) {
-        float s = fmaxf(fmaxf(x, y), fmaxf(z, w));
-        s = fmaxf(s, __shfl_xor(s, 1)); s = fmaxf(s, __shfl_xor(s, 2)); s = fmaxf(s, __shfl_xor(s, 4));
-        s = fmaxf(s, __shfl_xor(s, 8)); s = fmaxf(s, __shfl_xor(s, 16)); s = fmaxf(s, __shfl_xor(s, 32));
-        return s;
-    }
+    if (KIND == K_MAX) return wave_butterfly<OpMax>(fmaxf(fmaxf(x, y), fmaxf(z, w)));
     return wave_sum_canonical((x + y) + (z + w));
 }
 
