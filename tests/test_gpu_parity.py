@@ -457,3 +457,30 @@ def test_pipelined_contexts_match_blocking_search(za):
         c.begin(qs[0].data_ptr(), B, k, m)
     c.finish(slots[0]["ids"].data_ptr(), slots[0]["keys"].data_ptr(), slots[0]["counts"].data_ptr())
     c.wait()
+
+
+def test_concurrent_searches_from_threads(za):
+    """the reference calls search from rayon workers (core.rs:299-303): concurrent calls on one index are safe"""
+    import threading
+    n, d, M, T, k = 8000, 64, 128, 6, 10
+    X = zo.synth_rows(n, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    f = zo.Forest.build(X, M, T)
+    Qs = [zo.synth_queries(16, d, n, b0=16 * i) for i in range(8)]
+    want = [f.search_batch(q, k, zo.L2SQ) for q in Qs]
+    got, errs = [None] * 8, []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = ix.search_batch(Qs[i], k, za.L2SquaredDistance())
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for i in range(8):
+        assert (got[i][0] == want[i][0]).all() and (got[i][1] == want[i][1]).all() and (got[i][2] == want[i][2]).all()

@@ -172,17 +172,18 @@ __global__ __launch_bounds__(256) void hash_dense_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     const bool vec4 = (d & 3u) == 0;
-    for (uint32_t k0 = 0; k0 < d; k0 += HD_KT) {
+    // tile (k0): thread t owns two float4 of the Q tile and two of the W tile: rows (t + 256*it) >> 3, k offset 4*((t + 256*it) & 7)
+    auto fetch = [&](uint32_t k0, float4 *qv, float4 *wv) {
 #pragma unroll
         for (int it = 0; it < 2; it++) {
-            uint32_t i = tid + it * 256;  // 512 float4 per tile
-            uint32_t row = i >> 3, c4 = (i & 7) * 4;
-            uint32_t k = k0 + c4;
-            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), wvv = qv;
+            uint32_t i = tid + it * 256;
+            uint32_t row = i >> 3, k = k0 + (i & 7) * 4;
+            qv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[it] = qv[it];
             if (vec4) {
                 if (k < d) {
-                    if (b0 + row < B) qv = *reinterpret_cast<const float4 *>(Q + (size_t)(b0 + row) * d + k);
-                    if (p0 + row < P) wvv = *reinterpret_cast<const float4 *>(W + (size_t)(p0 + row) * d + k);
+                    if (b0 + row < B) qv[it] = *reinterpret_cast<const float4 *>(Q + (size_t)(b0 + row) * d + k);
+                    if (p0 + row < P) wv[it] = *reinterpret_cast<const float4 *>(W + (size_t)(p0 + row) * d + k);
                 }
             } else {
                 float t[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
@@ -191,13 +192,23 @@ __global__ __launch_bounds__(256) void hash_dense_kernel(const float *__restrict
                         if (b0 + row < B) t[e] = Q[(size_t)(b0 + row) * d + k + e];
                         if (p0 + row < P) u[e] = W[(size_t)(p0 + row) * d + k + e];
                     }
-                qv = make_float4(t[0], t[1], t[2], t[3]);
-                wvv = make_float4(u[0], u[1], u[2], u[3]);
+                qv[it] = make_float4(t[0], t[1], t[2], t[3]);
+                wv[it] = make_float4(u[0], u[1], u[2], u[3]);
             }
-            Qs[c4 + 0][row] = qv.x; Qs[c4 + 1][row] = qv.y; Qs[c4 + 2][row] = qv.z; Qs[c4 + 3][row] = qv.w;
-            Ws[c4 + 0][row] = wvv.x; Ws[c4 + 1][row] = wvv.y; Ws[c4 + 2][row] = wvv.z; Ws[c4 + 3][row] = wvv.w;
+        }
+    };
+    float4 qn[2], wn[2];
+    fetch(0, qn, wn);
+    for (uint32_t k0 = 0; k0 < d; k0 += HD_KT) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            uint32_t i = tid + it * 256;
+            uint32_t row = i >> 3, c4 = (i & 7) * 4;
+            Qs[c4 + 0][row] = qn[it].x; Qs[c4 + 1][row] = qn[it].y; Qs[c4 + 2][row] = qn[it].z; Qs[c4 + 3][row] = qn[it].w;
+            Ws[c4 + 0][row] = wn[it].x; Ws[c4 + 1][row] = wn[it].y; Ws[c4 + 2][row] = wn[it].z; Ws[c4 + 3][row] = wn[it].w;
         }
         __syncthreads();
+        if (k0 + HD_KT < d) fetch(k0 + HD_KT, qn, wn);  // next tile's loads fly during this tile's MFMAs
         const uint32_t r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < HD_KT; kk += 2) {
