@@ -167,6 +167,23 @@ class LSHIndex {  // Clone in the crate shares the store (lsh.rs:144-148): copie
         return ids;
     }
     void clear() const { check(zh_index_clear(h_.get())); }  // lsh.rs:506-529
+    // lsh.rs:473-503 (as intended: the ids leave every tree) -> the ids that were present
+    std::vector<Id> remove(const std::vector<Id> &embedding_ids) const {
+        std::vector<std::uint8_t> found(embedding_ids.size());
+        std::size_t n = 0;
+        check(zh_index_remove(h_.get(), embedding_ids.data(), embedding_ids.size(), found.data(), &n));
+        std::vector<Id> out;
+        for (std::size_t i = 0; i < found.size(); i++) if (found[i]) out.push_back(embedding_ids[i]);
+        return out;
+    }
+    // lsh.rs:270-288 -> ids removed because an earlier vector has the same bits
+    std::vector<Id> deduplicate() const {
+        std::vector<Id> out(zh_index_count(h_.get()) + 1);
+        std::size_t n = 0;
+        check(zh_index_deduplicate(h_.get(), out.data(), out.size(), &n));
+        out.resize(n < out.size() ? n : out.size());
+        return out;
+    }
 
     // lsh.rs:544-565: approximate k nearest neighbours, ascending by (distance key, id)
     template <class Met>

@@ -17,6 +17,7 @@
  *                                        L2Distance               src/distance.rs:19-49, 103-114
  *   zh_index_count / zh_index_num_trees  LSHIndex::no_vectors / no_trees / is_empty  lsh.rs:389-409
  *   zh_index_clear                       LSHIndex::clear          src/database/index/lsh.rs:506-529
+ *   zh_index_remove / zh_index_deduplicate  LSHIndex::remove / deduplicate  src/database/index/lsh.rs:473-503, 270-288
  *   zh_merge_topk_device                 (new) shard merge after the RCCL all-gather
  *
  * Conventions
@@ -156,6 +157,12 @@ ZH_API int zh_index_append_device(zh_index *idx, const float *d_rows, size_t n);
  * kind 0 = ~N(0,1), kind 1 = integer-valued "SIFT-style" in [0,255] */
 ZH_API int zh_index_append_synthetic(zh_index *idx, size_t n, uint64_t seed, uint64_t first_row, int kind);
 ZH_API int zh_index_build(zh_index *idx); /* (re)build all trees on the GPU */
+/* LSHIndex::remove (lsh.rs:473-503) as intended: the ids leave every tree (the reference only edits trees whose root
+ * is a leaf) and zh_index_count drops; their vectors stay addressable for hyperplane sampling.  out_found (may be
+ * NULL): 1 per id that was present.  LSHIndex::deduplicate (lsh.rs:270-288): rows bit-identical to an earlier row are
+ * removed; out_ids (may be NULL) receives up to cap removed ids, ascending. */
+ZH_API int zh_index_remove(zh_index *idx, const uint64_t *ids, size_t n, uint8_t *out_found, size_t *out_n_removed);
+ZH_API int zh_index_deduplicate(zh_index *idx, uint64_t *out_ids, size_t cap, size_t *out_n_removed);
 
 /* ---- forest exchange (parity tests inject / extract the exact same forest) ----------------- */
 ZH_API int zh_index_set_forest(zh_index *idx, const zh_forest_view *forest);

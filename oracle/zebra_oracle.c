@@ -479,6 +479,80 @@ ZO_EXPORT void zo_forest_insert(zo_forest *f, const float *X, uint64_t n_prev, u
     }
 }
 
+/* LSHIndex::remove (lsh.rs:473-503), as what it intends: the reference only edits trees whose ROOT is a leaf, so
+ * ids stay in inner trees while their embedding is deleted; here the id leaves every tree.  The row's
+ * leaf is found by descending with the row's own vector (the path insert/build took); a forest that was injected
+ * with other contents falls back to scanning the tree's leaves.  Returns 1 if the id was present in any tree. */
+static int remove_from_leaf(zo_forest *f, uint32_t node, uint32_t id) {
+    uint32_t off = (uint32_t)f->left[node], len = (uint32_t)f->right[node];
+    for (uint32_t i = 0; i < len; i++)
+        if (f->leaf_ids[off + i] == id) {
+            uint32_t *ids = malloc((len ? len : 1) * sizeof(uint32_t));
+            memcpy(ids, f->leaf_ids + off, i * sizeof(uint32_t));
+            memcpy(ids + i, f->leaf_ids + off + i + 1, (len - i - 1) * sizeof(uint32_t));
+            f->left[node] = (int32_t)push_leaf(f, ids, len - 1);
+            f->right[node] = (int32_t)(len - 1);
+            free(ids);
+            return 1;
+        }
+    return 0;
+}
+ZO_EXPORT uint64_t zo_forest_remove(zo_forest *f, const float *X, const uint64_t *ids, uint64_t n, uint8_t *out_found) {
+    uint64_t removed = 0;
+    for (uint64_t r = 0; r < n; r++) {
+        int found = 0;
+        if (ids[r] < f->n_rows) {
+            uint32_t id = (uint32_t)ids[r];
+            const float *x = X + (size_t)id * f->d;
+            for (uint32_t t = 0; t < f->T; t++) {
+                uint32_t node = f->roots[t];
+                while (f->plane[node] >= 0) {
+                    int32_t p = f->plane[node];
+                    node = (uint32_t)(zo_point_is_above(f->planes + (size_t)p * f->d, f->consts[p], x, f->d) ? f->right[node] : f->left[node]);
+                }
+                int hit = remove_from_leaf(f, node, id);
+                if (!hit) { /* not where it hashes to (injected forest): scan this tree's leaves */
+                    uint32_t *stack = malloc((f->n_nodes + 1) * sizeof(uint32_t));
+                    uint32_t sp = 0;
+                    stack[sp++] = f->roots[t];
+                    while (sp && !hit) {
+                        uint32_t m = stack[--sp];
+                        if (f->plane[m] < 0) hit = remove_from_leaf(f, m, id);
+                        else { stack[sp++] = (uint32_t)f->left[m]; stack[sp++] = (uint32_t)f->right[m]; }
+                    }
+                    free(stack);
+                }
+                found |= hit;
+            }
+        }
+        if (out_found) out_found[r] = (uint8_t)found;
+        removed += found;
+    }
+    return removed;
+}
+
+/* LSHIndex::deduplicate (lsh.rs:270-288): rows whose f32 bit patterns equal an EARLIER live row's are removed;
+ * `alive` (may be NULL = all alive) marks rows still in the index; out_dup[i] = 1 for the rows to remove */
+typedef struct { const uint32_t *bits; uint32_t d; } zo_rowcmp_ctx;
+static zo_rowcmp_ctx g_rc;
+static int rowcmp(const void *a, const void *b) {
+    uint32_t i = *(const uint32_t *)a, j = *(const uint32_t *)b;
+    int c = memcmp(g_rc.bits + (size_t)i * g_rc.d, g_rc.bits + (size_t)j * g_rc.d, (size_t)g_rc.d * 4);
+    if (c) return c;
+    return i < j ? -1 : (i > j);
+}
+ZO_EXPORT uint64_t zo_find_duplicates(const float *X, uint64_t n, uint32_t d, const uint8_t *alive, uint8_t *out_dup) {
+    uint32_t *order = malloc((n ? n : 1) * sizeof(uint32_t));
+    uint64_t m = 0, dups = 0;
+    for (uint64_t i = 0; i < n; i++) { out_dup[i] = 0; if (!alive || alive[i]) order[m++] = (uint32_t)i; }
+    g_rc.bits = (const uint32_t *)X; g_rc.d = d;
+    qsort(order, m, sizeof(uint32_t), rowcmp);
+    for (uint64_t i = 1; i < m; i++)
+        if (memcmp(X + (size_t)order[i] * d, X + (size_t)order[i - 1] * d, (size_t)d * 4) == 0) { out_dup[order[i]] = 1; dups++; }
+    free(order);
+    return dups;
+}
+
 /* lsh.rs:411-429 build_index: T independent trees over all ids */
 ZO_EXPORT zo_forest *zo_forest_build(const float *X, uint64_t n_rows, uint32_t d, uint32_t M, uint32_t T,
                                      uint64_t seed) {

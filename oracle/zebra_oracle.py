@@ -58,6 +58,10 @@ def lib():
         L.zo_forest_from_arrays.argtypes = [u64, u32, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.zo_forest_from_arrays.restype = vp
         L.zo_forest_insert.argtypes = [vp, vp, u64, u64]
+        L.zo_forest_remove.argtypes = [vp, vp, vp, u64, vp]
+        L.zo_forest_remove.restype = u64
+        L.zo_find_duplicates.argtypes = [vp, u64, u32, vp, vp]
+        L.zo_find_duplicates.restype = u64
         L.zo_forest_free.argtypes = [vp]
         L.zo_forest_sizes.argtypes = [vp, vp, vp, vp]
         L.zo_forest_export.argtypes = [vp] * 8
@@ -181,6 +185,13 @@ class Forest:
         self.X = X_all
         self.n_rows = X_all.shape[0]
 
+    def remove(self, ids):
+        """LSHIndex::remove as intended (the id leaves every tree) -> bool array: was it present"""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        found = np.zeros(ids.size, np.uint8)
+        lib().zo_forest_remove(self._h, _p(self.X), _p(ids), ids.size, _p(found))
+        return found.astype(bool)
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().zo_forest_free(self._h)
@@ -253,6 +264,15 @@ def brute_force(X, q, k, metric, mode=PARITY):
     ids, keys = np.zeros(k, np.uint64), np.zeros(k, np.uint64)
     lib().zo_brute_force(_p(X), X.shape[0], X.shape[1], _p(q), k, metric, mode, _p(ids), _p(keys))
     return ids, keys
+
+
+def find_duplicates(X, alive=None):
+    """LSHIndex::deduplicate's rule: rows bit-identical to an earlier live row -> bool array"""
+    X = _f32(X)
+    out = np.zeros(X.shape[0], np.uint8)
+    al = None if alive is None else np.ascontiguousarray(alive, np.uint8)
+    lib().zo_find_duplicates(_p(X), X.shape[0], X.shape[1], _p(al) if al is not None else None, _p(out))
+    return out.astype(bool)
 
 
 def num_threads():

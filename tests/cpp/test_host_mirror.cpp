@@ -87,6 +87,21 @@ int main(int argc, char **argv) {
     auto res = db.query_vectors({rows[5], rows[77]}, 3);
     EXPECT(res.size() == 2 && res[0].count(5) && res[0][5] == "doc5" && res[1].count(77) && res[0].size() == 3);
 
+    // LSHIndex::remove / deduplicate (lsh.rs:473-503, 270-288)
+    {
+        LSHIndex<N> ix2(opt, seed);
+        std::vector<Embedding<N>> dup_rows(rows.begin(), rows.begin() + 200);
+        dup_rows[150] = dup_rows[3];
+        dup_rows[199] = dup_rows[3];
+        ix2.add(dup_rows);
+        auto removed = ix2.deduplicate();
+        EXPECT(removed.size() == 2 && removed[0] == 150 && removed[1] == 199);
+        auto gone = ix2.remove({7, 150, 100000});
+        EXPECT(gone.size() == 1 && gone[0] == 7);
+        auto hit = ix2.search(dup_rows[3], 3, L2SquaredDistance<N>{});
+        EXPECT(hit.size() == 3 && hit[0].first == 3 && hit[0].second == 0 && hit[1].second != 0);
+    }
+
     // error behaviour: a limit violation surfaces as zebra::Error (anyhow::Error in the crate)
     bool threw = false;
     try { index.search(queries[0], ZH_MAX_TOPK + 1, L2SquaredDistance<N>{}); } catch (const Error &e) { threw = e.code == ZH_ELIMIT; }

@@ -484,3 +484,53 @@ def test_concurrent_searches_from_threads(za):
     assert not errs
     for i in range(8):
         assert (got[i][0] == want[i][0]).all() and (got[i][1] == want[i][1]).all() and (got[i][2] == want[i][2]).all()
+
+
+# ------------------------------------------ lsh.rs:473-503 (remove), 270-288 (deduplicate) -- f4
+def test_remove_and_deduplicate(za):
+    n, d, M, T = 3000, 32, 24, 5
+    X = zo.synth_rows(n, d)
+    X[1000], X[2000], X[2999] = X[5], X[5], X[17]  # exact duplicates of earlier rows
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=9)
+    ix.add(X)
+    f = zo.Forest.build(X, M, T, seed=9)
+    want_dups = np.nonzero(zo.find_duplicates(X))[0]
+    assert want_dups.tolist() == [1000, 2000, 2999]
+    got = ix.deduplicate()
+    assert got.tolist() == want_dups.tolist()
+    assert f.remove(want_dups).all()
+    assert len(ix) == n - 3
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+    assert ix.deduplicate().size == 0  # idempotent
+    # remove: present ids leave every tree; unknown / repeated / already removed ids are reported as absent
+    ids = np.array([7, 8, 7, 1000, 10**9, 2500], np.uint64)
+    removed = ix.remove(ids)
+    assert sorted(removed.tolist()) == [7, 8, 2500]
+    f.remove([7, 8, 2500])
+    assert len(ix) == n - 6
+    g = ix.get_forest()
+    assert zo.canonical_forest(g, d) == zo.canonical_forest(f.arrays(), d)
+    for t in range(T):  # really gone from every tree
+        stack, seen = [int(g["roots"][t])], []
+        while stack:
+            m = stack.pop()
+            if g["plane"][m] < 0:
+                seen += g["leaf_ids"][g["left"][m]:g["left"][m] + g["right"][m]].tolist()
+            else:
+                stack += [int(g["left"][m]), int(g["right"][m])]
+        assert len(seen) == n - 6 and not ({7, 8, 2500, 1000, 2000, 2999} & set(seen))
+    Q = zo.synth_queries(10, d, n)
+    i_, k_, c_ = ix.search_batch(np.concatenate([Q, X[[7, 5]]]), 10, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(np.concatenate([Q, X[[7, 5]]]), 10, zo.L2SQ)
+    assert (c_ == oc).all() and (i_ == oi).all() and (k_ == ok).all()
+    assert 7 not in i_[10] and i_[11, 0] == 5
+    # inserting after a removal still matches the oracle
+    more = zo.synth_rows(200, d, row0=50000)
+    ix.add(more)
+    Xall = np.concatenate([X, more])
+    f.insert(Xall, n)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+    # a rebuild keeps removed rows out
+    ix.build()
+    g = ix.get_forest()
+    assert g["leaf_ids"].size == T * (n + 200 - 6) and not ({7, 8, 2500, 1000} & set(g["leaf_ids"].tolist()))

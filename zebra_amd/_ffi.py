@@ -60,6 +60,8 @@ SYMBOLS = [
     ("zh_index_append_device", _i, [_vp, _vp, _sz]),
     ("zh_index_append_synthetic", _i, [_vp, _sz, _u64, _u64, _i]),
     ("zh_index_build", _i, [_vp]),
+    ("zh_index_remove", _i, [_vp, _vp, _sz, _vp, _vp]),
+    ("zh_index_deduplicate", _i, [_vp, _vp, _sz, _vp]),
     ("zh_index_set_forest", _i, [_vp, _vp]),
     ("zh_index_forest_sizes", _i, [_vp, _vp]),
     ("zh_index_get_forest", _i, [_vp] * 8),

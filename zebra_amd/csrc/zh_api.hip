@@ -120,6 +120,8 @@ struct zh_index {
     std::vector<uint32_t> h_roots;
     std::vector<uint32_t> planes_below_level;  // [L] = planes whose level < L ; planes are stored level-major
     std::vector<uint32_t> h_leaf_ids;          // host mirror of leaf_ids, materialised by the first incremental add
+    std::vector<uint8_t> h_dead;               // rows removed by zh_index_remove (their vectors stay in X)
+    uint64_t n_dead = 0;
     uint32_t max_leaf_len = 0;
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
@@ -248,10 +250,12 @@ extern "C" int zh_index_clear(zh_index *ix) {
     hipStreamSynchronize(ix->stream);
     free_forest(ix);
     ix->n_rows = 0;
+    ix->h_dead.clear();
+    ix->n_dead = 0;
     return ZH_OK;
 }
 
-extern "C" uint64_t zh_index_count(const zh_index *ix) { return ix ? ix->n_rows : 0; }
+extern "C" uint64_t zh_index_count(const zh_index *ix) { return ix ? ix->n_rows - ix->n_dead : 0; }
 extern "C" uint32_t zh_index_num_trees(const zh_index *ix) { return ix ? ix->n_trees : 0; }
 extern "C" uint32_t zh_index_dim(const zh_index *ix) { return ix ? ix->opt.dim : 0; }
 extern "C" const float *zh_index_rows_device(const zh_index *ix) { return ix ? ix->X.as<float>() : nullptr; }
@@ -567,12 +571,22 @@ static int build_forest_locked(zh_index *ix) {
     hipStreamSynchronize(ix->stream);
     free_forest(ix);
     if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
-    const uint64_t total = (uint64_t)T * N;
+    const uint64_t NL = N - ix->n_dead;  // removed rows stay out of a rebuild (their vectors may still be sampled)
+    const uint64_t total = (uint64_t)T * NL;
     DevBuf perm;
     if ((rc = perm.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
-    if (total) {
+    if (total && ix->n_dead == 0) {
         hipError_t e = zh_launch_iota_perm(perm.as<uint32_t>(), N, T, ix->stream);
         if (e != hipSuccess) { perm.release(); return fail(ZH_EHIP, "iota_perm: %s", hipGetErrorString(e)); }
+    } else if (total) {
+        if (ix->h_dead.size() < N) ix->h_dead.resize(N, 0);  // rows appended after the last removal are alive
+        std::vector<uint32_t> live;
+        live.reserve(NL);
+        for (uint64_t i = 0; i < N; i++) if (!ix->h_dead[i]) live.push_back((uint32_t)i);
+        for (uint32_t t = 0; t < T; t++) {
+            hipError_t e = hipMemcpy(perm.as<uint32_t>() + (size_t)t * NL, live.data(), NL * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { perm.release(); return fail(ZH_EHIP, "perm upload: %s", hipGetErrorString(e)); }
+        }
     }
     std::vector<ActiveNode> active;
     ix->planes_below_level.assign(1, 0);
@@ -580,8 +594,8 @@ static int build_forest_locked(zh_index *ix) {
         ix->h_plane.push_back(-1); ix->h_left.push_back(0); ix->h_right.push_back(0);
         uint32_t n = (uint32_t)(ix->h_plane.size() - 1);
         ix->h_roots.push_back(n);
-        if (N < M) { ix->h_left[n] = (int32_t)(uint32_t)((uint64_t)t * N); ix->h_right[n] = (int32_t)N; }  // lsh.rs:251-252
-        else active.push_back({n, t, (uint32_t)N, 0, (uint64_t)t * N, 1, N});
+        if (NL < M) { ix->h_left[n] = (int32_t)(uint32_t)((uint64_t)t * NL); ix->h_right[n] = (int32_t)NL; }  // lsh.rs:251-252
+        else active.push_back({n, t, (uint32_t)NL, 0, (uint64_t)t * NL, 1, N});
     }
     uint32_t n_planes = 0;
     rc = grow_segments(ix, perm.as<uint32_t>(), total, active, 0, n_planes, true);
@@ -715,6 +729,155 @@ extern "C" int zh_index_add(zh_index *ix, const float *rows, size_t n, uint64_t 
     if ((rc = set_device(ix))) return rc;
     if (!had_trees) return build_forest_locked(ix);  // lsh.rs:441-443
     return insert_rows_locked(ix, n_prev, n);        // lsh.rs:445-462
+}
+
+// LSHIndex::remove (lsh.rs:473-503) as it is meant: the reference only edits trees whose root is a leaf, so an id
+// stays in every inner tree while its embedding is gone.  Here every tree drops the id: the row's
+// leaf is found on the GPU by descending with the row's own vector, the leaf's run shrinks in place.
+static int remove_rows_locked(zh_index *ix, const std::vector<uint32_t> &rows, std::vector<uint8_t> &found) {
+    const uint32_t T = ix->n_trees, d = ix->opt.dim;
+    hipStream_t s = ix->stream;
+    int rc;
+    found.assign(rows.size(), 0);
+    if (rows.empty()) return ZH_OK;
+    if (ix->h_dead.size() < ix->n_rows) ix->h_dead.resize(ix->n_rows, 0);
+    if (T) {
+        if (ix->h_leaf_ids.size() != ix->n_leaf_ids) {
+            ix->h_leaf_ids.resize(ix->n_leaf_ids);
+            if (ix->n_leaf_ids) HIPCHK(hipMemcpy(ix->h_leaf_ids.data(), ix->leaf_ids.p, ix->n_leaf_ids * 4, hipMemcpyDeviceToHost));
+        }
+        std::vector<ZhDescend> items;
+        items.reserve(rows.size() * T);
+        for (size_t r = 0; r < rows.size(); r++)
+            for (uint32_t t = 0; t < T; t++) items.push_back({rows[r], ix->h_roots[t], (uint32_t)r, t, 1});  // depth field carries r
+        DevBuf dItems;
+        struct G { DevBuf *a; ~G() { a->release(); } } g{&dItems};
+        if ((rc = dItems.ensure(items.size() * sizeof(ZhDescend)))) return rc;
+        HIPCHK(hipMemcpyAsync(dItems.p, items.data(), items.size() * sizeof(ZhDescend), hipMemcpyHostToDevice, s));
+        std::vector<uint32_t> slot(items.size());
+        for (size_t i = 0; i < items.size(); i++) slot[i] = items[i].depth;
+        HIPCHK(zh_launch_descend(forest_dev(ix), ix->X.as<float>(), d, dItems.as<ZhDescend>(), (uint32_t)items.size(), s));
+        HIPCHK(hipMemcpyAsync(items.data(), dItems.p, items.size() * sizeof(ZhDescend), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        auto drop = [&](uint32_t node, uint32_t id) {  // remove id from a leaf's run (in place), true if it was there
+            uint32_t off = (uint32_t)ix->h_left[node], len = (uint32_t)ix->h_right[node];
+            uint32_t *run = ix->h_leaf_ids.data() + off;
+            for (uint32_t i = 0; i < len; i++)
+                if (run[i] == id) {
+                    memmove(run + i, run + i + 1, (len - i - 1) * sizeof(uint32_t));
+                    ix->h_right[node] = (int32_t)(len - 1);
+                    return true;
+                }
+            return false;
+        };
+        std::vector<uint32_t> touched;
+        for (size_t i = 0; i < items.size(); i++) {
+            const uint32_t r = slot[i], id = items[i].row, t = items[i].tree;
+            uint32_t node = items[i].node;
+            bool hit = drop(node, id);
+            if (!hit) {  // an injected forest may keep the id elsewhere: scan this tree's leaves
+                std::vector<uint32_t> st{ix->h_roots[t]};
+                while (!st.empty() && !hit) {
+                    uint32_t m = st.back(); st.pop_back();
+                    if (ix->h_plane[m] < 0) { if (drop(m, id)) { hit = true; node = m; } }
+                    else { st.push_back((uint32_t)ix->h_left[m]); st.push_back((uint32_t)ix->h_right[m]); }
+                }
+            }
+            if (hit) { found[r] = 1; touched.push_back(node); }
+        }
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        for (uint32_t node : touched) {  // shrunken runs back to the device
+            uint32_t off = (uint32_t)ix->h_left[node], len = (uint32_t)ix->h_right[node];
+            if (len) HIPCHK(hipMemcpyAsync(ix->leaf_ids.as<uint32_t>() + off, ix->h_leaf_ids.data() + off, (size_t)len * 4, hipMemcpyHostToDevice, s));
+        }
+        if ((rc = upload_nodes(ix))) return rc;
+    } else {
+        for (size_t r = 0; r < rows.size(); r++) found[r] = 1;  // vectors without trees: just forget them
+    }
+    for (size_t r = 0; r < rows.size(); r++)
+        if (found[r] && !ix->h_dead[rows[r]]) { ix->h_dead[rows[r]] = 1; ix->n_dead++; }
+    return ZH_OK;
+}
+
+extern "C" int zh_index_remove(zh_index *ix, const uint64_t *ids, size_t n, uint8_t *out_found, size_t *out_n_removed) {
+    if (!ix || (n && !ids)) return fail(ZH_EINVAL, "zh_index_remove: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    std::vector<uint32_t> rows;
+    std::vector<size_t> where;
+    std::vector<uint8_t> seen(ix->n_rows, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (out_found) out_found[i] = 0;
+        if (ids[i] < ix->opt.id_base) continue;
+        uint64_t r = ids[i] - ix->opt.id_base;
+        if (r >= ix->n_rows || seen[r] || (r < ix->h_dead.size() && ix->h_dead[r])) continue;
+        seen[r] = 1;
+        rows.push_back((uint32_t)r);
+        where.push_back(i);
+    }
+    std::vector<uint8_t> found;
+    if ((rc = remove_rows_locked(ix, rows, found))) return rc;
+    size_t cnt = 0;
+    for (size_t j = 0; j < rows.size(); j++)
+        if (found[j]) { cnt++; if (out_found) out_found[where[j]] = 1; }
+    if (out_n_removed) *out_n_removed = cnt;
+    return ZH_OK;
+}
+
+// LSHIndex::deduplicate (lsh.rs:270-288): every live row whose f32 bit pattern equals an earlier live row's is
+// removed.  Rows are hashed on the GPU (one pass over the stored vectors), equal hashes are confirmed byte for byte.
+extern "C" int zh_index_deduplicate(zh_index *ix, uint64_t *out_ids, size_t cap, size_t *out_n_removed) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    const uint64_t N = ix->n_rows;
+    const uint32_t d = ix->opt.dim;
+    if (out_n_removed) *out_n_removed = 0;
+    if (N < 2) return ZH_OK;
+    DevBuf dh;
+    struct G { DevBuf *a; ~G() { a->release(); } } g{&dh};
+    if ((rc = dh.ensure(N * 8))) return rc;
+    HIPCHK(zh_launch_row_hash(ix->X.as<float>(), N, d, dh.as<uint64_t>(), ix->stream));
+    std::vector<uint64_t> hh(N);
+    HIPCHK(hipMemcpyAsync(hh.data(), dh.p, N * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    std::vector<std::pair<uint64_t, uint32_t>> hv;
+    hv.reserve(N - ix->n_dead);
+    for (uint64_t i = 0; i < N; i++)
+        if (!(i < ix->h_dead.size() && ix->h_dead[i])) hv.push_back({hh[i], (uint32_t)i});
+    std::sort(hv.begin(), hv.end());
+    std::vector<uint32_t> dups;
+    std::vector<float> a(d), b(d);
+    for (size_t i = 0; i < hv.size();) {
+        size_t j = i + 1;
+        while (j < hv.size() && hv[j].first == hv[i].first) j++;
+        if (j - i > 1) {  // same hash: confirm against the earlier distinct rows of the run
+            std::vector<uint32_t> reps;
+            for (size_t p = i; p < j; p++) {
+                HIPCHK(hipMemcpy(a.data(), ix->X.as<float>() + (size_t)hv[p].second * d, (size_t)d * 4, hipMemcpyDeviceToHost));
+                bool dup = false;
+                for (uint32_t rep : reps) {
+                    HIPCHK(hipMemcpy(b.data(), ix->X.as<float>() + (size_t)rep * d, (size_t)d * 4, hipMemcpyDeviceToHost));
+                    if (memcmp(a.data(), b.data(), (size_t)d * 4) == 0) { dup = true; break; }
+                }
+                if (dup) dups.push_back(hv[p].second); else reps.push_back(hv[p].second);
+            }
+        }
+        i = j;
+    }
+    std::sort(dups.begin(), dups.end());
+    std::vector<uint8_t> found;
+    if ((rc = remove_rows_locked(ix, dups, found))) return rc;
+    size_t cnt = 0;
+    for (size_t i = 0; i < dups.size(); i++) {
+        if (out_ids && cnt < cap) out_ids[cnt] = ix->opt.id_base + dups[i];
+        cnt++;
+    }
+    if (out_n_removed) *out_n_removed = cnt;
+    return ZH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -379,3 +379,32 @@ hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDesce
     hipLaunchKernelGGL(descend_kernel, dim3((n + 63) / 64), dim3(64), 0, s, f, dX, d, dItems, n);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// deduplicate (lsh.rs:270-288 compares the f32 bit patterns): one wave per row, h = sum over words of
+// mix(word, position) in wrapping u64 -- order-independent to reduce, position-sensitive by construction
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix_word(uint32_t w, uint32_t pos) {
+    uint64_t x = ((uint64_t)pos << 32 | w) + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void row_hash_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
+                                                        uint64_t *__restrict__ out) {
+    const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(X + (size_t)row * d);
+    uint64_t h = 0;
+    for (uint32_t e = lane; e < d; e += 64) h += mix_word(w[e], e);
+    for (int m = 1; m < 64; m <<= 1) h += __shfl_xor(h, m);
+    if (lane == 0) out[row] = h;
+}
+hipError_t zh_launch_row_hash(const float *dX, uint64_t n, uint32_t d, uint64_t *dHash, hipStream_t s) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, n, d, dHash);
+    return hipGetLastError();
+}

@@ -144,6 +144,9 @@ struct ZhDescend {
 };
 hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDescend *dItems, uint32_t n, hipStream_t s);
 
+// 64-bit content hash of every stored row (order-sensitive, exact integer arithmetic): deduplicate
+hipError_t zh_launch_row_hash(const float *dX, uint64_t n, uint32_t d, uint64_t *dHash, hipStream_t s);
+
 hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
                                 hipStream_t s);
 hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,

@@ -185,6 +185,21 @@ class LSHIndex:
     def clear(self):
         check(lib().zh_index_clear(self._h))
 
+    def remove(self, embedding_ids):
+        """lsh.rs:473-503 (as intended: the ids leave every tree) -> the ids that were present"""
+        ids = np.ascontiguousarray(embedding_ids, np.uint64)
+        found = np.zeros(ids.size, np.uint8)
+        n = C.c_size_t()
+        check(lib().zh_index_remove(self._h, _p(ids), ids.size, _p(found), C.byref(n)))
+        return ids[found.astype(bool)]
+
+    def deduplicate(self):
+        """lsh.rs:270-288 -> ids removed because an earlier vector has the same bits"""
+        out = np.zeros(max(len(self), 1), np.uint64)
+        n = C.c_size_t()
+        check(lib().zh_index_deduplicate(self._h, _p(out), out.size, C.byref(n)))
+        return out[:n.value]
+
     def set_forest(self, arrays):
         a = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
         keep = [a["plane"].astype(np.int32), a["left"].astype(np.int32), a["right"].astype(np.int32),
