@@ -849,24 +849,43 @@ extern "C" int zh_index_deduplicate(zh_index *ix, uint64_t *out_ids, size_t cap,
     for (uint64_t i = 0; i < N; i++)
         if (!(i < ix->h_dead.size() && ix->h_dead[i])) hv.push_back({hh[i], (uint32_t)i});
     std::sort(hv.begin(), hv.end());
+    // runs of equal hash: every member is compared (on the GPU, bit for bit) with the run's current representative;
+    // members that differ from it -- a hash collision -- form the next round against the next representative
     std::vector<uint32_t> dups;
-    std::vector<float> a(d), b(d);
+    std::vector<std::vector<uint32_t>> runs;
     for (size_t i = 0; i < hv.size();) {
         size_t j = i + 1;
         while (j < hv.size() && hv[j].first == hv[i].first) j++;
-        if (j - i > 1) {  // same hash: confirm against the earlier distinct rows of the run
-            std::vector<uint32_t> reps;
-            for (size_t p = i; p < j; p++) {
-                HIPCHK(hipMemcpy(a.data(), ix->X.as<float>() + (size_t)hv[p].second * d, (size_t)d * 4, hipMemcpyDeviceToHost));
-                bool dup = false;
-                for (uint32_t rep : reps) {
-                    HIPCHK(hipMemcpy(b.data(), ix->X.as<float>() + (size_t)rep * d, (size_t)d * 4, hipMemcpyDeviceToHost));
-                    if (memcmp(a.data(), b.data(), (size_t)d * 4) == 0) { dup = true; break; }
-                }
-                if (dup) dups.push_back(hv[p].second); else reps.push_back(hv[p].second);
-            }
+        if (j - i > 1) {
+            std::vector<uint32_t> r;
+            for (size_t p = i; p < j; p++) r.push_back(hv[p].second);  // ascending ids (sorted by (hash, id))
+            runs.push_back(std::move(r));
         }
         i = j;
+    }
+    DevBuf dPairs, dEq;
+    struct G2 { DevBuf *a, *b; ~G2() { a->release(); b->release(); } } g2{&dPairs, &dEq};
+    while (!runs.empty()) {
+        std::vector<uint32_t> pairs;
+        for (auto &r : runs)
+            for (size_t p = 1; p < r.size(); p++) { pairs.push_back(r[0]); pairs.push_back(r[p]); }
+        const uint32_t np = (uint32_t)(pairs.size() / 2);
+        std::vector<uint8_t> eq(np);
+        if ((rc = dPairs.ensure(pairs.size() * 4)) || (rc = dEq.ensure(np))) return rc;
+        HIPCHK(hipMemcpyAsync(dPairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(zh_launch_rows_equal(ix->X.as<float>(), d, dPairs.as<uint32_t>(), np, dEq.as<uint8_t>(), ix->stream));
+        HIPCHK(hipMemcpyAsync(eq.data(), dEq.p, np, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        std::vector<std::vector<uint32_t>> next;
+        size_t q = 0;
+        for (auto &r : runs) {
+            std::vector<uint32_t> rest;
+            for (size_t p = 1; p < r.size(); p++, q++) {
+                if (eq[q]) dups.push_back(r[p]); else rest.push_back(r[p]);
+            }
+            if (rest.size() > 1) next.push_back(std::move(rest));
+        }
+        runs.swap(next);
     }
     std::sort(dups.begin(), dups.end());
     std::vector<uint8_t> found;

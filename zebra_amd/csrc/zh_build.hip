@@ -408,3 +408,22 @@ hipError_t zh_launch_row_hash(const float *dX, uint64_t n, uint32_t d, uint64_t 
     hipLaunchKernelGGL(row_hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, n, d, dHash);
     return hipGetLastError();
 }
+
+__global__ __launch_bounds__(256) void rows_equal_kernel(const float *__restrict__ X, uint32_t d,
+                                                          const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                          uint8_t *__restrict__ out) {
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (p >= n_pairs) return;
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(X + (size_t)pairs[2 * p] * d);
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(X + (size_t)pairs[2 * p + 1] * d);
+    bool same = true;
+    for (uint32_t e = lane; e < d; e += 64) same = same && (a[e] == b[e]);
+    unsigned long long m = __ballot(same);
+    if (lane == 0) out[p] = (m == ~0ull) ? 1 : 0;
+}
+hipError_t zh_launch_rows_equal(const float *dX, uint32_t d, const uint32_t *dPairs, uint32_t n_pairs, uint8_t *dOut,
+                                hipStream_t s) {
+    if (!n_pairs) return hipSuccess;
+    hipLaunchKernelGGL(rows_equal_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, dX, d, dPairs, n_pairs, dOut);
+    return hipGetLastError();
+}

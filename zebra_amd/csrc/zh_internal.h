@@ -147,6 +147,10 @@ hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDesce
 // 64-bit content hash of every stored row (order-sensitive, exact integer arithmetic): deduplicate
 hipError_t zh_launch_row_hash(const float *dX, uint64_t n, uint32_t d, uint64_t *dHash, hipStream_t s);
 
+// out[i] = 1 when rows pairs[2i] and pairs[2i+1] have identical f32 bit patterns
+hipError_t zh_launch_rows_equal(const float *dX, uint32_t d, const uint32_t *dPairs, uint32_t n_pairs, uint8_t *dOut,
+                                hipStream_t s);
+
 hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
                                 hipStream_t s);
 hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,
