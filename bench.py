@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
+                    help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zh_search_batch_device per step")
     ap.add_argument("--in-flight", type=int, default=3, help="batches in flight when pipelined")
     ap.add_argument("--debug-single-device", action="store_true",
@@ -165,6 +167,8 @@ def main():
         wl["rows"] = args.rows
     if args.max_node_size:
         wl["M"] = args.max_node_size
+    if args.data == "clustered" and wl["kind"] == 0:
+        wl["kind"] = 2
     S = world
     first_row, rows_local = sharding.shard_rows(wl["rows"], S, rank)
     wl["rows_local"] = rows_local
@@ -412,7 +416,7 @@ def main():
         out = {
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": S, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
             "pipelined_batches_in_flight": max(2, args.in_flight) if pipelined else 1,
             "config": {"workload": f"{name}: {wl['desc']}", "rows_total": n_total, "rows_per_gpu": rows_local,
                        "dim": d, "metric": wl["metric"] + ("(parity key)" if wl["metric"] == "cosine" else ""),

@@ -154,7 +154,8 @@ ZH_API int zh_index_add(zh_index *idx, const float *rows, size_t n, uint64_t *ou
 ZH_API int zh_index_append(zh_index *idx, const float *rows, size_t n, uint64_t *out_row_ids);
 ZH_API int zh_index_append_device(zh_index *idx, const float *d_rows, size_t n);
 /* append n synthetic rows generated on the device (bit-identical to oracle zo_synth_rows);
- * kind 0 = ~N(0,1), kind 1 = integer-valued "SIFT-style" in [0,255] */
+ * kind 0 = ~N(0,1), kind 1 = integer-valued "SIFT-style" in [0,255], kind 2 = clustered (128 consecutive rows
+ * share a centre: centre + 0.25 * noise) */
 ZH_API int zh_index_append_synthetic(zh_index *idx, size_t n, uint64_t seed, uint64_t first_row, int kind);
 ZH_API int zh_index_build(zh_index *idx); /* (re)build all trees on the GPU */
 /* LSHIndex::remove (lsh.rs:473-503) as intended: the ids leave every tree (the reference only edits trees whose root

@@ -66,6 +66,8 @@ static inline int32_t synth_centered(uint64_t seed, uint64_t idx) {
                  (uint32_t)(z >> 48);
     return (int32_t)s - 131070;
 }
+/* kind 2 ("clustered"): 128 consecutive rows share a centre: x = centre + 0.25 * own noise */
+#define ZO_CLUSTER_ROWS 128
 static inline float synth_value(uint64_t seed, uint64_t idx, int kind) {
     int32_t t = synth_centered(seed, idx);
     if (kind == 1) { /* "SIFT-style": integer-valued in [0,255] -> L2^2 exact in f32 */
@@ -77,9 +79,17 @@ static inline float synth_value(uint64_t seed, uint64_t idx, int kind) {
     return (float)t * (1.0f / 37837.2f);
 }
 
+static inline float synth_elem(uint64_t seed, uint64_t row, uint32_t col, uint32_t d, int kind) {
+    if (kind == 2) {
+        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, (row / ZO_CLUSTER_ROWS) * d + col) * (1.0f / 37837.2f);
+        float own = (float)synth_centered(seed, row * d + col) * (1.0f / 37837.2f);
+        return fmaf(0.25f, own, centre);
+    }
+    return synth_value(seed, row * d + col, kind);
+}
 ZO_EXPORT void zo_synth_rows(uint64_t seed, uint64_t row0, uint64_t n, uint32_t d, int kind, float *out) {
     for (uint64_t r = 0; r < n; r++)
-        for (uint32_t c = 0; c < d; c++) out[r * d + c] = synth_value(seed, (row0 + r) * d + c, kind);
+        for (uint32_t c = 0; c < d; c++) out[r * d + c] = synth_elem(seed, row0 + r, c, d, kind);
 }
 
 /* query b = stored row r_b + 0.3 * noise (planted neighbour); r_b from the query stream */
@@ -91,9 +101,9 @@ ZO_EXPORT void zo_synth_queries(uint64_t seed_rows, uint64_t seed_q, uint64_t n_
     for (uint64_t i = 0; i < b; i++) {
         uint64_t r = zo_synth_query_row(seed_q, b0 + i, n_rows);
         for (uint32_t c = 0; c < d; c++) {
-            float x = synth_value(seed_rows, r * d + c, kind);
+            float x = synth_elem(seed_rows, r, c, d, kind);
             float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, (b0 + i) * d + c) * (1.0f / 37837.2f);
-            out[i * d + c] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : fmaf(0.3f, g, x);
+            out[i * d + c] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : fmaf(kind == 2 ? 0.1f : 0.3f, g, x);
         }
     }
 }

@@ -278,8 +278,11 @@ def test_synthetic_generators_bit_exact(za):
     ix2 = za.LSHIndex(128, za.LSHIndexOptions(64, 2))
     ix2.append_synthetic(500, seed=5, first_row=1000, kind=1)
     assert (ix2.read_rows(0, 500) == zo.synth_rows(500, 128, seed=5, row0=1000, kind=1)).all()
+    ix3 = za.LSHIndex(64, za.LSHIndexOptions(64, 2))
+    ix3.append_synthetic(700, seed=zo.SEED_ROWS, first_row=250, kind=2)
+    assert (ix3.read_rows(0, 700).view(np.uint32) == zo.synth_rows(700, 64, row0=250, kind=2).view(np.uint32)).all()
     import torch
-    for kind, dd in ((0, 384), (1, 128)):
+    for kind, dd in ((0, 384), (1, 128), (2, 64)):
         q = torch.empty((33, dd), dtype=torch.float32, device="cuda")
         za.synth_queries_device(0, q.data_ptr(), 12345, 33, dd, b0=7, kind=kind)
         want = zo.synth_queries(33, dd, 12345, b0=7, kind=kind)

@@ -37,11 +37,20 @@ __device__ __forceinline__ float synth_value(uint64_t seed, uint64_t idx, int ki
     return (float)t * (1.0f / 37837.2f);
 }
 
+// kind 2 ("clustered"): 128 consecutive rows share a centre: x = centre + 0.25 * own noise
+__device__ __forceinline__ float synth_elem(uint64_t seed, uint64_t row, uint32_t col, uint32_t d, int kind) {
+    if (kind == 2) {
+        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, (row / 128) * d + col) * (1.0f / 37837.2f);
+        float own = (float)synth_centered(seed, row * d + col) * (1.0f / 37837.2f);
+        return __builtin_fmaf(0.25f, own, centre);
+    }
+    return synth_value(seed, row * d + col, kind);
+}
 __global__ __launch_bounds__(256) void synth_rows_kernel(float *__restrict__ X, uint64_t n_elems, uint32_t d,
                                                           uint64_t seed, uint64_t row0, int kind) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n_elems; i += stride) X[i] = synth_value(seed, row0 * d + i, kind);
+    for (; i < n_elems; i += stride) X[i] = synth_elem(seed, row0 + i / d, (uint32_t)(i % d), d, kind);
 }
 
 hipError_t zh_launch_synth_rows(float *dX, uint64_t n, uint32_t d, uint64_t seed, uint64_t row0, int kind,
@@ -62,9 +71,9 @@ __global__ __launch_bounds__(256) void synth_queries_kernel(float *__restrict__ 
     uint64_t q = b0 + i / d;
     uint32_t c = (uint32_t)(i % d);
     uint64_t r = zh_splitmix64(seed_q ^ (q * 0xA24BAED4963EE407ull)) % n_rows;
-    float x = synth_value(seed_rows, r * d + c, kind);
+    float x = synth_elem(seed_rows, r, c, d, kind);
     float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, q * d + c) * (1.0f / 37837.2f);
-    out[i] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : __builtin_fmaf(0.3f, g, x);
+    out[i] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : __builtin_fmaf(kind == 2 ? 0.1f : 0.3f, g, x);
 }
 
 hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,
