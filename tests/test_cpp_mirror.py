@@ -44,3 +44,23 @@ def test_cpp_mirror_parity(tmp_path):
     r = subprocess.run([exe, str(fx)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok" in r.stdout
+
+
+EXAMPLE = os.path.join(ROOT, "examples", "search_example.c")
+
+
+def _compile_c(out):
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), EXAMPLE,
+                           "-L", LIBDIR, "-lzebra_hip", f"-Wl,-rpath,{LIBDIR}", "-o", out])
+
+
+def test_c_example_compiles_as_c99(tmp_path):
+    _compile_c(str(tmp_path / "ex"))
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    exe = str(tmp_path / "ex")
+    _compile_c(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "example ok" in r.stdout, r.stdout + r.stderr
