@@ -227,7 +227,7 @@ def main():
         if S > 1:
             dist.barrier()
 
-    # two batches in flight: slot = step parity, each slot has its own context, stream and result buffers
+    # several batches in flight: slot = step mod NS, each slot has its own context, stream and result buffers
     pipelined = not args.no_pipeline
     if pipelined:
         # every batch's sweep back to back on one normal-priority stream; the light work of each slot on a
@@ -353,7 +353,7 @@ def main():
         r_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
         r_counts = torch.empty(B, dtype=torch.int32, device=dev)
 
-        def run(m):
+        def search_ids(m):
             ix.search_batch_device(queries[-1].data_ptr(), B, k, m, r_ids.data_ptr(), r_keys.data_ptr(),
                                    r_counts.data_ptr(), stream)
             out = r_ids.clone()
@@ -364,9 +364,9 @@ def main():
                 out = m_ids.clone()
             return out[:nq]
 
-        got = run(rec_metric)
+        got = search_ids(rec_metric)
         if wl["metric"] == "cosine":
-            got_parity = run(metric)
+            got_parity = search_ids(metric)
         # exact neighbours over the whole (sharded) set: local exact top-k, gathered, merged by distance
         Xt = _wrap_rows(torch, ix, rows_local, d, dev)
         true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + first_row
@@ -391,7 +391,6 @@ def main():
             return hit / (nq * k)
 
         # the planted neighbour (query = stored row + 0.3 * noise): is it among the returned ids?
-        from zebra_amd import _ffi as _f  # noqa: F401
         pl = np.array([_planted_row(SEED_Q, (n_batches - 1) * B + b, n_total) for b in range(nq)], dtype=np.int64)
         planted = float((got.cpu().numpy() == pl[:, None]).any(1).mean())
         recall = rec(got)
@@ -430,6 +429,7 @@ def main():
                          "bytes_per_launch": bytes_alg, "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0},
             "cpu_baseline": cpu, "host_buffers_qps": host_qps,
             "stage_ms_per_batch": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
+            "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
             "setup_s": {"fill": t_fill, "build": t_build},
         }
         print(json.dumps(out))
