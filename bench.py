@@ -67,6 +67,7 @@ def parse():
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zh_search_batch_device per step")
     ap.add_argument("--in-flight", type=int, default=3, help="batches in flight when pipelined")
+    ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority torch stream")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="debug: all ranks on cuda:0, exchange over gloo through host copies (RCCL needs one device per rank)")
     ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
@@ -230,9 +231,13 @@ def main():
     # several batches in flight: slot = step mod NS, each slot has its own context, stream and result buffers
     pipelined = not args.no_pipeline
     if pipelined:
-        # every batch's sweep back to back on one normal-priority stream; the light work of each slot on a
-        # high-priority stream: a different hardware-queue pool, so it is not queued behind the sweep
-        heavy = torch.cuda.Stream(device=dev, priority=0)
+        # every batch's sweep back to back on the index's lowest-priority stream; the light work of each slot on a
+        # high-priority stream; torch's and RCCL's own streams are normal priority: three hardware-queue pools,
+        # so neither the light kernels nor the collectives are queued behind sweep launches
+        heavy = ix.sweep_stream()
+        if args.debug_normal_priority_sweeps:
+            _hs = torch.cuda.Stream(device=dev, priority=0)
+            heavy = _hs.cuda_stream
         slots = []
         NS = max(2, args.in_flight)
         for _ in range(NS):
@@ -251,7 +256,7 @@ def main():
 
         def p_finish(i):
             sl = slots[i % NS]
-            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy.cuda_stream)
+            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
             if S > 1:
                 with torch.cuda.stream(sl["stream"]):
                     if args.debug_single_device:
@@ -283,6 +288,11 @@ def main():
             torch.cuda.synchronize()
 
     torch.cuda.synchronize()
+    if pipelined:  # every slot allocates its scratch once, whatever --warmup is (not counted as warmup)
+        for sl in slots:
+            sl["ctx"].begin(queries[0].data_ptr(), B, k, metric, sl["stream"].cuda_stream)
+            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
+            sl["ctx"].wait()
     if args.warmup:
         run(0, args.warmup)
     ix.set_profiling(1)  # hipEvents around every stage, on the stream the kernels run on

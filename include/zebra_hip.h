@@ -205,6 +205,9 @@ ZH_API int zh_search_ctx_create(zh_index *idx, zh_search_ctx **out);
 ZH_API void zh_search_ctx_destroy(zh_search_ctx *ctx);
 ZH_API int zh_search_begin(zh_search_ctx *ctx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode,
                     void *stream);
+/* A lowest-priority, non-blocking stream owned by the index, meant to be passed as `sweep_stream` below: light kernels
+ * (high-priority streams) and collectives (normal priority) then never share a hardware queue with the sweeps. */
+ZH_API void *zh_index_sweep_stream(const zh_index *idx);
 /* sweep_stream (may be NULL = the begin stream): the stream the HBM-bound distance sweep is enqueued on; sharing
  * one sweep stream between contexts runs the sweeps of successive batches back to back while the other kernels of
  * each batch overlap them on the contexts' own streams (the library inserts the event dependencies). */

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("zh_index_num_trees", _u32, [_vp]),
     ("zh_index_dim", _u32, [_vp]),
     ("zh_index_rows_device", _vp, [_vp]),
+    ("zh_index_sweep_stream", _vp, [_vp]),
     ("zh_index_read_rows", _i, [_vp, _u64, _sz, _vp]),
     ("zh_hash_signs", _i, [_vp, _vp, _sz, _vp, _vp]),
     ("zh_search_batch", _i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _vp]),

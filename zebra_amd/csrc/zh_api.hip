@@ -106,6 +106,7 @@ struct zh_index {
     zh_options opt{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t sweep_stream = nullptr;  // lowest priority: shared by the sweeps of pipelined contexts
     std::mutex mu;
 
     // stored vectors: n_rows x dim row-major f32 (Embedding<N>, lib.rs:18)
@@ -208,8 +209,14 @@ extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
     }
     e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ix; return fail(ZH_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        e = hipStreamCreateWithPriority(&ix->sweep_stream, hipStreamNonBlocking, least);
+        if (e != hipSuccess) { hipStreamDestroy(ix->stream); delete ix; return fail(ZH_EHIP, "hipStreamCreateWithPriority: %s", hipGetErrorString(e)); }
+    }
     rc = ctx_init(&ix->dctx, ix);
-    if (rc) { hipStreamDestroy(ix->stream); delete ix; return rc; }
+    if (rc) { hipStreamDestroy(ix->sweep_stream); hipStreamDestroy(ix->stream); delete ix; return rc; }
     if (opt->reserve_rows) {
         rc = ix->X.ensure((size_t)opt->reserve_rows * opt->dim * sizeof(float));
         if (rc) { zh_index_destroy(ix); return rc; }
@@ -233,11 +240,13 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
+    if (ix->sweep_stream) hipStreamSynchronize(ix->sweep_stream);
     free_forest(ix);
     ix->X.release();
     ix->dctx.release_all();
     DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
+    if (ix->sweep_stream) hipStreamDestroy(ix->sweep_stream);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -259,6 +268,7 @@ extern "C" uint64_t zh_index_count(const zh_index *ix) { return ix ? ix->n_rows 
 extern "C" uint32_t zh_index_num_trees(const zh_index *ix) { return ix ? ix->n_trees : 0; }
 extern "C" uint32_t zh_index_dim(const zh_index *ix) { return ix ? ix->opt.dim : 0; }
 extern "C" const float *zh_index_rows_device(const zh_index *ix) { return ix ? ix->X.as<float>() : nullptr; }
+extern "C" void *zh_index_sweep_stream(const zh_index *ix) { return ix ? (void *)ix->sweep_stream : nullptr; }
 
 // ------------------------------------------------------------------------------------------------
 // rows

@@ -263,6 +263,10 @@ class LSHIndex:
         """one in-flight batch (zh_search_begin / finish / wait); create two to software-pipeline batches"""
         return SearchContext(self)
 
+    def sweep_stream(self):
+        """the index's lowest-priority stream (raw hipStream_t) for SearchContext.finish(..., sweep_stream=)"""
+        return lib().zh_index_sweep_stream(self._h)
+
     def rows_device_ptr(self):
         return lib().zh_index_rows_device(self._h)
 
