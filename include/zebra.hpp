@@ -223,6 +223,17 @@ class Database {
         auto ids = index.add(embeddings);
         for (std::size_t i = 0; i < ids.size() && i < documents.size(); i++) documents_[ids[i]] = documents[i];
     }
+    // core.rs:205-214 / 216-225 / 194-198
+    void remove(const std::vector<Id> &embedding_ids) {
+        for (Id i : index.remove(embedding_ids)) documents_.erase(i);
+    }
+    void deduplicate() {
+        for (Id i : index.deduplicate()) documents_.erase(i);
+    }
+    void clear_database() {
+        index.clear();
+        documents_.clear();
+    }
     // core.rs:290-313: query index -> {id -> document}; order and distances are dropped (core.rs:304-305);
     // a failing search yields an empty entry (unwrap_or_default, core.rs:303)
     std::map<std::size_t, std::map<Id, std::string>> query_vectors(const std::vector<Embedding<N>> &vectors,

@@ -86,6 +86,11 @@ int main(int argc, char **argv) {
     db.insert_records(rows, docs);
     auto res = db.query_vectors({rows[5], rows[77]}, 3);
     EXPECT(res.size() == 2 && res[0].count(5) && res[0][5] == "doc5" && res[1].count(77) && res[0].size() == 3);
+    db.remove({5});
+    auto res2 = db.query_vectors({rows[5]}, 3);
+    EXPECT(res2[0].count(5) == 0);
+    db.clear_database();
+    EXPECT(db.query_vectors({rows[5]}, 3).empty());
 
     // LSHIndex::remove / deduplicate (lsh.rs:473-503, 270-288)
     {

@@ -336,6 +336,13 @@ def test_database_mirror(za):
     res = db.query_vectors(X[[5, 77]], 3)
     assert 5 in res[0] and res[0][5] == b"doc5" and 77 in res[1]
     assert len(res[0]) == 3
+    db.remove([5])  # core.rs:205-214
+    assert 5 not in db.query_vectors(X[[5]], 3)[0]
+    db.insert_records(X[[77]], [b"dup"])  # an exact duplicate of row 77 ...
+    db.deduplicate()                      # ... goes again (core.rs:216-225)
+    assert len(db.index) == n - 1
+    db.clear_database()
+    assert db.query_vectors(X[:1], 3) == {}
 
 
 # ---------------------------------------------------------------- shard merge

@@ -334,6 +334,21 @@ class Database:
         for i, doc in zip(ids.tolist(), documents):
             self._documents[i] = doc
 
+    def remove(self, embedding_ids):
+        """core.rs:205-214: index.remove, then the removed ids' documents go too"""
+        for i in self.index.remove(embedding_ids).tolist():
+            self._documents.pop(i, None)
+
+    def deduplicate(self):
+        """core.rs:216-225"""
+        for i in self.index.deduplicate().tolist():
+            self._documents.pop(i, None)
+
+    def clear_database(self):
+        """core.rs:194-198"""
+        self.index.clear()
+        self._documents.clear()
+
     def query_vectors(self, vectors, number_of_results):
         """-> {query index: {id: document}} ; order and distances are dropped as in core.rs:304-305."""
         if self.index.no_vectors():
