@@ -1,0 +1,62 @@
+"""Seeded fuzz: random small configurations, HIP path vs oracle, bit for bit (forest, ids, keys, counts) --
+odd dimensions, leaves of 1, single trees, k larger than the index, every metric, incremental adds and removes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zebra_oracle as zo  # noqa: E402
+
+
+def _metrics(za, rng):
+    p = int(rng.integers(1, 9))
+    return [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
+            (za.CosineDistance(False), zo.COSINE, zo.CORRECTED), (za.ChebyshevDistance(), zo.CHEBYSHEV, 0),
+            (za.CanberraDistance(), zo.CANBERRA, 0), (za.BrayCurtisDistance(), zo.BRAY_CURTIS, 0),
+            (za.ManhattanDistance(), zo.MANHATTAN, 0), (za.L3Distance(), zo.L3, 0), (za.L4Distance(), zo.L4, 0),
+            (za.HammingDistance(), zo.HAMMING, 0), (za.MinkowskiDistance(p), zo.MINKOWSKI, p), (za.PNormDistance(p), zo.PNORM, p)]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_config(seed):
+    import zebra_amd as za
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([1, 2, 5, 17, 32, 63, 64, 100, 128, 200, 384, 500, 768]))
+    n = int(rng.integers(1, 2500))
+    M = int(rng.choice([1, 2, 5, 9, 33, 100, 400, 5000]))
+    T = int(rng.integers(1, 7))
+    k = int(rng.choice([1, 3, 10, 37, 100, 500]))
+    B = int(rng.integers(1, 20))
+    kind = int(rng.choice([0, 0, 1, 2]))
+    X = zo.synth_rows(n, d, seed=seed, kind=kind)
+    if rng.random() < 0.3 and n > 10:  # some exact duplicates
+        X[rng.integers(0, n, 5)] = X[0]
+    Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
+    ix.add(X)
+    f = zo.Forest.build(X, M, T, seed=seed)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
+    mets = _metrics(za, rng)
+    for m, om, omode in [mets[i] for i in rng.choice(len(mets), 4, replace=False)]:
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), (d, n, M, T, k, om)
+        for b in range(B):
+            c = int(oc[b])
+            kg, kw = keys[b, :c], ok[b, :c]
+            same = (kg == kw) | ((om >= zo.CHEBYSHEV) & np.isnan(kg.astype(np.uint32).view(np.float32)) & np.isnan(kw.astype(np.uint32).view(np.float32)))
+            assert same.all() and (ids[b, :c] == oi[b, :c]).all(), (d, n, M, T, k, om, b)
+    # grow, shrink, search again
+    more = int(rng.integers(1, 300))
+    X2 = np.concatenate([X, zo.synth_rows(more, d, seed=seed, row0=10**6, kind=kind)])
+    ix.add(X2[n:])
+    f.insert(X2, n)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), ("insert", d, n, M, T)
+    gone = rng.choice(n + more, size=min(7, n + more), replace=False).astype(np.uint64)
+    assert sorted(ix.remove(gone).tolist()) == sorted(gone[f.remove(gone)].tolist())
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), ("remove", d, n, M, T)
+    ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ)
+    assert (counts == oc).all()
+    for b in range(B):
+        assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all()
