@@ -1,0 +1,251 @@
+//! Shim that keeps the reference crate's signatures for the hot path on top of `libzebra_hip.so`.
+//!
+//! NOT COMPILED in this repository's build image (no Rust toolchain there); it mirrors
+//! `include/zebra_hip.h` one to one and is kept mechanical on purpose.  What it replaces in emmyoh/zebra:
+//! `src/distance.rs` (the metric structs' `Metric::distance`), `src/database/index/lsh.rs`
+//! (`LSHIndex<N>`: new / add / search / remove / deduplicate / clear / is_empty / no_vectors / no_trees) and the
+//! rayon loop of `Database::query_vectors` (`src/database/core.rs:299-303`) through `search_batch`.
+#![allow(non_camel_case_types)]
+
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+use std::sync::{Arc, RwLock};
+
+use uuid::Uuid;
+
+pub type DistanceUnit = u64; // src/distance.rs:13
+pub type EmbeddingPrecision = f32; // src/lib.rs:48
+
+/// `Embedding<N>` of the reference is a newtype over `[f32; N]` (src/lib.rs:18); the shim takes plain arrays.
+pub type Embedding<const N: usize> = [EmbeddingPrecision; N];
+
+pub mod ffi {
+    use super::*;
+
+    #[repr(C)]
+    pub struct zh_index {
+        _private: [u8; 0],
+    }
+
+    #[repr(C)]
+    #[derive(Clone, Copy)]
+    pub struct zh_options {
+        pub dim: u32,
+        pub max_node_size: u32, // LSHIndexOptions::max_node_size (lsh.rs:126)
+        pub num_trees: u32,     // LSHIndexOptions::num_trees     (lsh.rs:128)
+        pub seed: u64,
+        pub device: i32,
+        pub id_base: u64,
+        pub reserve_rows: u64,
+    }
+
+    pub const ZH_COSINE: c_int = 0;
+    pub const ZH_L2SQ: c_int = 1;
+    pub const ZH_L2: c_int = 2;
+    pub const ZH_CHEBYSHEV: c_int = 3;
+    pub const ZH_CANBERRA: c_int = 4;
+    pub const ZH_BRAY_CURTIS: c_int = 5;
+    pub const ZH_MANHATTAN: c_int = 6;
+    pub const ZH_L3: c_int = 7;
+    pub const ZH_L4: c_int = 8;
+    pub const ZH_HAMMING: c_int = 9;
+    pub const ZH_MINKOWSKI: c_int = 10;
+    pub const ZH_PNORM: c_int = 11;
+    pub const ZH_COSINE_PARITY: c_int = 0; // distance.rs:23-25 literally
+    pub const ZH_COSINE_CORRECTED: c_int = 1;
+
+    extern "C" {
+        pub fn zh_options_default(opt: *mut zh_options);
+        pub fn zh_index_create(opt: *const zh_options, out: *mut *mut zh_index) -> c_int;
+        pub fn zh_index_destroy(idx: *mut zh_index);
+        pub fn zh_index_clear(idx: *mut zh_index) -> c_int;
+        pub fn zh_index_add(idx: *mut zh_index, rows: *const f32, n: usize, out_row_ids: *mut u64) -> c_int;
+        pub fn zh_index_build(idx: *mut zh_index) -> c_int;
+        pub fn zh_index_remove(idx: *mut zh_index, ids: *const u64, n: usize, out_found: *mut u8, out_n_removed: *mut usize) -> c_int;
+        pub fn zh_index_deduplicate(idx: *mut zh_index, out_ids: *mut u64, cap: usize, out_n_removed: *mut usize) -> c_int;
+        pub fn zh_index_count(idx: *const zh_index) -> u64;
+        pub fn zh_index_num_trees(idx: *const zh_index) -> u32;
+        pub fn zh_search_batch(idx: *mut zh_index, q: *const f32, b: usize, k: usize, metric: c_int, cosine_mode: c_int,
+                               out_ids: *mut u64, out_keys: *mut u64, out_counts: *mut u32) -> c_int;
+        pub fn zh_search_batch_device(idx: *mut zh_index, d_q: *const f32, b: usize, k: usize, metric: c_int, cosine_mode: c_int,
+                                      d_out_ids: *mut u64, d_out_keys: *mut u64, d_out_counts: *mut u32, stream: *mut c_void) -> c_int;
+        pub fn zh_distance_pair(metric: c_int, cosine_mode: c_int, a: *const f32, b: *const f32, dim: usize, out_key: *mut u64,
+                                device: c_int) -> c_int;
+        pub fn zh_merge_topk_device(device: c_int, n_shards: u32, b: usize, k: usize, d_ids: *const u64, d_keys: *const u64,
+                                    d_counts: *const u32, d_out_ids: *mut u64, d_out_keys: *mut u64, d_out_counts: *mut u32,
+                                    stream: *mut c_void) -> c_int;
+        pub fn zh_last_error() -> *const c_char;
+    }
+}
+
+fn check(rc: c_int) -> anyhow::Result<()> {
+    if rc == 0 {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(ffi::zh_last_error()) }.to_string_lossy().into_owned();
+    Err(anyhow::anyhow!("zebra_hip error {rc}: {msg}"))
+}
+
+/// Owns the device-side index.  `LSHIndex` is `Clone` in the reference (lsh.rs:144): clones share it.
+struct HipIndex(*mut ffi::zh_index);
+unsafe impl Send for HipIndex {}
+unsafe impl Sync for HipIndex {} // search calls serialise inside the library
+impl Drop for HipIndex {
+    fn drop(&mut self) {
+        unsafe { ffi::zh_index_destroy(self.0) }
+    }
+}
+
+/// What a metric struct must tell the index so that it can run on the device.
+pub trait BatchMetric {
+    const METRIC: c_int;
+    /// cosine mode for `CosineDistance`, `power` for Minkowski / p-norm, ignored otherwise
+    fn param(&self) -> c_int {
+        0
+    }
+}
+
+macro_rules! simple_metric {
+    ($name:ident, $code:expr, $doc:expr) => {
+        #[doc = $doc]
+        #[derive(Default, Debug, Clone)]
+        pub struct $name<const N: usize>;
+        impl<const N: usize> BatchMetric for $name<N> {
+            const METRIC: c_int = $code;
+        }
+        impl<const N: usize> space::Metric<Embedding<N>> for $name<N> {
+            type Unit = DistanceUnit;
+            fn distance(&self, a: &Embedding<N>, b: &Embedding<N>) -> DistanceUnit {
+                let mut key = 0u64;
+                let _ = unsafe { ffi::zh_distance_pair($code, 0, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                key
+            }
+        }
+    };
+}
+simple_metric!(CosineDistance, ffi::ZH_COSINE, "src/distance.rs:15-32 (key = bits of `1.0 - simsimd cosine`, literally)");
+simple_metric!(L2SquaredDistance, ffi::ZH_L2SQ, "src/distance.rs:34-49");
+simple_metric!(L2Distance, ffi::ZH_L2, "src/distance.rs:99-114");
+simple_metric!(ChebyshevDistance, ffi::ZH_CHEBYSHEV, "src/distance.rs:51-61");
+simple_metric!(CanberraDistance, ffi::ZH_CANBERRA, "src/distance.rs:63-73");
+simple_metric!(BrayCurtisDistance, ffi::ZH_BRAY_CURTIS, "src/distance.rs:75-85");
+simple_metric!(ManhattanDistance, ffi::ZH_MANHATTAN, "src/distance.rs:87-97");
+simple_metric!(L3Distance, ffi::ZH_L3, "src/distance.rs:116-126");
+simple_metric!(L4Distance, ffi::ZH_L4, "src/distance.rs:128-138");
+simple_metric!(HammingDistance, ffi::ZH_HAMMING, "src/distance.rs:140-158");
+
+/// src/distance.rs:160-174
+#[derive(Default, Debug, Clone)]
+pub struct MinkowskiDistance<const N: usize> {
+    pub power: i32,
+}
+impl<const N: usize> BatchMetric for MinkowskiDistance<N> {
+    const METRIC: c_int = ffi::ZH_MINKOWSKI;
+    fn param(&self) -> c_int {
+        self.power
+    }
+}
+/// src/distance.rs:176-190
+#[derive(Default, Debug, Clone)]
+pub struct PNormDistance<const N: usize> {
+    pub power: i32,
+}
+impl<const N: usize> BatchMetric for PNormDistance<N> {
+    const METRIC: c_int = ffi::ZH_PNORM;
+    fn param(&self) -> c_int {
+        self.power
+    }
+}
+
+/// lsh.rs:122-139
+#[derive(Debug, Clone)]
+pub struct LSHIndexOptions<const N: usize> {
+    pub max_node_size: usize,
+    pub num_trees: usize,
+}
+impl<const N: usize> Default for LSHIndexOptions<N> {
+    fn default() -> Self {
+        Self { max_node_size: 5, num_trees: 15 }
+    }
+}
+
+/// `LSHIndex<N>` with the reference's public signatures (lsh.rs:144-565); ids are Uuids kept in a row table.
+#[derive(Clone)]
+pub struct LSHIndex<const N: usize> {
+    hip: Arc<HipIndex>,
+    uuids: Arc<RwLock<Vec<Uuid>>>, // row -> Uuid (Uuid::now_v7 at add time, lsh.rs:415)
+}
+
+impl<const N: usize> LSHIndex<N> {
+    pub fn new(_uuid: &Uuid, options: &LSHIndexOptions<N>) -> anyhow::Result<Self> {
+        let mut o = unsafe { std::mem::zeroed::<ffi::zh_options>() };
+        unsafe { ffi::zh_options_default(&mut o) };
+        o.dim = N as u32;
+        o.max_node_size = options.max_node_size as u32;
+        o.num_trees = options.num_trees as u32;
+        let mut h = std::ptr::null_mut();
+        check(unsafe { ffi::zh_index_create(&o, &mut h) })?;
+        Ok(Self { hip: Arc::new(HipIndex(h)), uuids: Default::default() })
+    }
+    pub fn save(&self) -> anyhow::Result<()> {
+        Ok(())
+    }
+    pub fn no_vectors(&self) -> bool {
+        unsafe { ffi::zh_index_count(self.hip.0) == 0 }
+    }
+    pub fn no_trees(&self) -> bool {
+        unsafe { ffi::zh_index_num_trees(self.hip.0) == 0 }
+    }
+    pub fn is_empty(&self) -> bool {
+        self.no_vectors() || self.no_trees()
+    }
+
+    /// lsh.rs:440-466
+    pub fn add(&self, embeddings: &Vec<Embedding<N>>) -> anyhow::Result<Vec<Uuid>> {
+        let ids: Vec<Uuid> = embeddings.iter().map(|_| Uuid::now_v7()).collect();
+        check(unsafe { ffi::zh_index_add(self.hip.0, embeddings.as_ptr() as *const f32, embeddings.len(), std::ptr::null_mut()) })?;
+        self.uuids.write().unwrap().extend(ids.iter().copied());
+        Ok(ids)
+    }
+
+    /// lsh.rs:544-565
+    pub fn search<Met: BatchMetric>(&self, query: &Embedding<N>, top_k: usize, metric: &Met) -> anyhow::Result<Vec<(Uuid, DistanceUnit)>> {
+        Ok(self.search_batch(std::slice::from_ref(query), top_k, metric)?.pop().unwrap_or_default())
+    }
+
+    /// the rayon loop of core.rs:299-303 as one call
+    pub fn search_batch<Met: BatchMetric>(&self, queries: &[Embedding<N>], top_k: usize, metric: &Met) -> anyhow::Result<Vec<Vec<(Uuid, DistanceUnit)>>> {
+        let b = queries.len();
+        let (mut ids, mut keys, mut counts) = (vec![0u64; b * top_k], vec![0u64; b * top_k], vec![0u32; b]);
+        check(unsafe {
+            ffi::zh_search_batch(self.hip.0, queries.as_ptr() as *const f32, b, top_k, Met::METRIC, metric.param(), ids.as_mut_ptr(),
+                                 keys.as_mut_ptr(), counts.as_mut_ptr())
+        })?;
+        let uu = self.uuids.read().unwrap();
+        Ok((0..b).map(|i| (0..counts[i] as usize).map(|j| (uu[ids[i * top_k + j] as usize], keys[i * top_k + j])).collect()).collect())
+    }
+
+    /// lsh.rs:473-503 (as intended: the ids leave every tree)
+    pub fn remove(&self, embedding_ids: &Vec<Uuid>) -> anyhow::Result<Vec<Uuid>> {
+        let uu = self.uuids.read().unwrap();
+        let rows: Vec<u64> = embedding_ids.iter().filter_map(|u| uu.iter().position(|x| x == u).map(|r| r as u64)).collect();
+        let mut found = vec![0u8; rows.len()];
+        check(unsafe { ffi::zh_index_remove(self.hip.0, rows.as_ptr(), rows.len(), found.as_mut_ptr(), std::ptr::null_mut()) })?;
+        Ok(rows.iter().zip(found).filter(|(_, f)| *f != 0).map(|(r, _)| uu[*r as usize]).collect())
+    }
+
+    /// lsh.rs:270-288
+    pub fn deduplicate(&self) -> anyhow::Result<Vec<Uuid>> {
+        let cap = unsafe { ffi::zh_index_count(self.hip.0) } as usize + 1;
+        let (mut out, mut n) = (vec![0u64; cap], 0usize);
+        check(unsafe { ffi::zh_index_deduplicate(self.hip.0, out.as_mut_ptr(), cap, &mut n) })?;
+        let uu = self.uuids.read().unwrap();
+        Ok(out[..n.min(cap)].iter().map(|r| uu[*r as usize]).collect())
+    }
+
+    /// lsh.rs:506-529
+    pub fn clear(&self) -> anyhow::Result<()> {
+        self.uuids.write().unwrap().clear();
+        check(unsafe { ffi::zh_index_clear(self.hip.0) })
+    }
+}
