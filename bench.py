@@ -197,34 +197,38 @@ def main():
         za.synth_queries_device(local_rank, q.data_ptr(), n_total, B, d, b0=i * B, seed_rows=SEED_ROWS, seed_q=SEED_Q,
                                 kind=wl["kind"])
         queries.append(q)
-    ids = torch.empty((B, k), dtype=torch.int64, device=dev)
-    keys = torch.empty((B, k), dtype=torch.int64, device=dev)
-    counts = torch.empty(B, dtype=torch.int32, device=dev)
-    if S > 1:
-        g_ids = torch.empty((S, B, k), dtype=torch.int64, device=dev)
-        g_keys = torch.empty((S, B, k), dtype=torch.int64, device=dev)
-        g_counts = torch.empty((S, B), dtype=torch.int32, device=dev)
-        m_ids = torch.empty((B, k), dtype=torch.int64, device=dev)
-        m_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
-        m_counts = torch.empty(B, dtype=torch.int32, device=dev)
+    # one result buffer per in-flight batch: [ids B*k | keys B*k | counts B] packed so that the N > 1 exchange is ONE
+    # all-gather (B*k*16 + B*4 bytes per rank: latency-bound), merged by zh_merge_topk_packed_device on every rank
+    W = za.packed_result_words(B, k)
 
-    def gather(a, b_, c):
+    def make_exchange():
+        ex = dict(packed=torch.empty(W, dtype=torch.int64, device=dev))
+        ex["ids"], ex["keys"], ex["counts"] = sharding.packed_views(torch, ex["packed"], B, k)
+        if S > 1:
+            ex.update(g_packed=torch.empty((S, W), dtype=torch.int64, device=dev), m_ids=torch.empty((B, k), dtype=torch.int64, device=dev),
+                      m_keys=torch.empty((B, k), dtype=torch.int64, device=dev), m_counts=torch.empty(B, dtype=torch.int32, device=dev))
+        return ex
+
+    def exchange(ex, stream_ptr):
+        """the one exchange step of the path: every rank's packed top-k to every rank, then the merge kernel"""
         if args.debug_single_device:  # gloo: through the host
-            ha, hb, hc = a.cpu(), b_.cpu(), c.cpu()
-            ga, gb, gc = torch.empty(g_ids.shape, dtype=a.dtype), torch.empty(g_keys.shape, dtype=a.dtype), \
-                torch.empty(g_counts.shape, dtype=c.dtype)
-            sharding.all_gather_topk(dist, ha, hb, hc, ga, gb, gc)
-            g_ids.copy_(ga), g_keys.copy_(gb), g_counts.copy_(gc)
+            torch.cuda.synchronize()
+            hp, hg = ex["packed"].cpu(), torch.empty(ex["g_packed"].shape, dtype=torch.int64)
+            sharding.all_gather_packed(dist, hp, hg)
+            ex["g_packed"].copy_(hg)
             torch.cuda.synchronize()
         else:
-            sharding.all_gather_topk(dist, a, b_, c, g_ids, g_keys, g_counts)
+            sharding.all_gather_packed(dist, ex["packed"], ex["g_packed"])
+        za.merge_topk_packed_device(local_rank, S, B, k, ex["g_packed"].data_ptr(), ex["m_ids"].data_ptr(), ex["m_keys"].data_ptr(),
+                                    ex["m_counts"].data_ptr(), stream_ptr)
+
+    ex0 = make_exchange()
+    ids, keys, counts = ex0["ids"], ex0["keys"], ex0["counts"]
 
     def step(q):
         ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
-        if S > 1:  # the one exchange step of the path: every rank's top-k to every rank, then merge
-            gather(ids, keys, counts)
-            za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
-                                 m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
+        if S > 1:
+            exchange(ex0, stream)
 
     def barrier():
         if S > 1:
@@ -243,13 +247,8 @@ def main():
         slots = []
         NS = max(2, args.in_flight)
         for _ in range(NS):
-            sl = dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1),
-                      ids=torch.empty((B, k), dtype=torch.int64, device=dev), keys=torch.empty((B, k), dtype=torch.int64, device=dev),
-                      counts=torch.empty(B, dtype=torch.int32, device=dev))
-            if S > 1:
-                sl.update(g_ids=torch.empty((S, B, k), dtype=torch.int64, device=dev), g_keys=torch.empty((S, B, k), dtype=torch.int64, device=dev),
-                          g_counts=torch.empty((S, B), dtype=torch.int32, device=dev), m_ids=torch.empty((B, k), dtype=torch.int64, device=dev),
-                          m_keys=torch.empty((B, k), dtype=torch.int64, device=dev), m_counts=torch.empty(B, dtype=torch.int32, device=dev))
+            sl = dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1))
+            sl.update(make_exchange())
             slots.append(sl)
 
         def p_begin(i):
@@ -261,17 +260,7 @@ def main():
             sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
             if S > 1:
                 with torch.cuda.stream(sl["stream"]):
-                    if args.debug_single_device:
-                        sl["stream"].synchronize()
-                        ha, hb, hc = sl["ids"].cpu(), sl["keys"].cpu(), sl["counts"].cpu()
-                        ga, gb, gc = torch.empty(sl["g_ids"].shape, dtype=ha.dtype), torch.empty(sl["g_keys"].shape, dtype=ha.dtype), \
-                            torch.empty(sl["g_counts"].shape, dtype=hc.dtype)
-                        sharding.all_gather_topk(dist, ha, hb, hc, ga, gb, gc)
-                        sl["g_ids"].copy_(ga), sl["g_keys"].copy_(gb), sl["g_counts"].copy_(gc)
-                    else:
-                        sharding.all_gather_topk(dist, sl["ids"], sl["keys"], sl["counts"], sl["g_ids"], sl["g_keys"], sl["g_counts"])
-                    za.merge_topk_device(local_rank, S, B, k, sl["g_ids"].data_ptr(), sl["g_keys"].data_ptr(), sl["g_counts"].data_ptr(),
-                                         sl["m_ids"].data_ptr(), sl["m_keys"].data_ptr(), sl["m_counts"].data_ptr(), sl["stream"].cuda_stream)
+                    exchange(sl, sl["stream"].cuda_stream)
 
         def run(first, n):
             # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long
@@ -361,19 +350,13 @@ def main():
         q = queries[-1][:nq]
         got_parity = None
         rec_metric = metric if wl["metric"] != "cosine" else make_metric(za, "cosine", parity=False)
-        r_ids = torch.empty((B, k), dtype=torch.int64, device=dev)
-        r_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
-        r_counts = torch.empty(B, dtype=torch.int32, device=dev)
-
         def search_ids(m):
-            ix.search_batch_device(queries[-1].data_ptr(), B, k, m, r_ids.data_ptr(), r_keys.data_ptr(),
-                                   r_counts.data_ptr(), stream)
-            out = r_ids.clone()
+            ix.search_batch_device(queries[-1].data_ptr(), B, k, m, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
+            out = ids.clone()
             if S > 1:
-                gather(r_ids, r_keys, r_counts)
-                za.merge_topk_device(local_rank, S, B, k, g_ids.data_ptr(), g_keys.data_ptr(), g_counts.data_ptr(),
-                                     m_ids.data_ptr(), m_keys.data_ptr(), m_counts.data_ptr(), stream)
-                out = m_ids.clone()
+                exchange(ex0, stream)
+                torch.cuda.synchronize()
+                out = ex0["m_ids"].clone()
             return out[:nq]
 
         got = search_ids(rec_metric)

@@ -228,6 +228,13 @@ ZH_API int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, size_t 
                          const uint64_t *d_keys, const uint32_t *d_counts, uint64_t *d_out_ids,
                          uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
 
+/* The same merge over ONE buffer per shard -- [ids b*k u64][keys b*k u64][counts b u32, padded to 8 bytes],
+ * zh_packed_result_words(b, k) u64 words -- so that a batch needs a single all-gather: point
+ * zh_search_batch_device / zh_search_finish at the three sections of such a buffer. */
+ZH_API size_t zh_packed_result_words(size_t b, size_t k);
+ZH_API int zh_merge_topk_packed_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_packed,
+                                uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
+
 /* synthetic queries on the device (bit-identical to oracle zo_synth_queries) */
 ZH_API int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,
                             uint64_t b0, size_t b, uint32_t dim, int kind, void *stream);

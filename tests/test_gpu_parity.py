@@ -389,6 +389,21 @@ def test_shard_merge_device(za, S, k):
     assert (gc == want[2]).all()
     for b in range(B):
         assert (gi[b, :gc[b]] == want[0][b, :gc[b]]).all() and (gk[b, :gc[b]] == want[1][b, :gc[b]]).all()
+    # the packed layout (one buffer per shard = one all-gather per batch) merges to the same result
+    from zebra_amd import sharding
+    W = za.packed_result_words(B, k)
+    assert W == 2 * B * k + (B + 1) // 2
+    g_packed = torch.zeros((S, W), dtype=torch.int64, device="cuda")
+    for s_ in range(S):
+        a, b_, c = sharding.packed_views(torch, g_packed[s_], B, k)
+        a.copy_(t_ids[s_]), b_.copy_(t_keys[s_]), c.copy_(t_counts[s_])
+    p_ids, p_keys, p_counts = torch.empty_like(o_ids), torch.empty_like(o_keys), torch.empty_like(o_counts)
+    torch.cuda.synchronize()
+    za.merge_topk_packed_device(0, S, B, k, g_packed.data_ptr(), p_ids.data_ptr(), p_keys.data_ptr(), p_counts.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(p_counts, o_counts)
+    for b in range(B):
+        assert torch.equal(p_ids[b, :gc[b]], o_ids[b, :gc[b]]) and torch.equal(p_keys[b, :gc[b]], o_keys[b, :gc[b]])
 
 
 def test_search_device_entry_point(za):

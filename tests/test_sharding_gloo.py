@@ -49,6 +49,16 @@ def _worker(rank, world, port, out):
     g_keys = torch.empty((world, B, K), dtype=torch.int64)
     g_counts = torch.empty((world, B), dtype=torch.int32)
     sharding.all_gather_topk(dist, t_ids, t_keys, t_counts, g_ids, g_keys, g_counts)
+    # the packed form bench.py uses: one buffer per rank, ONE all-gather
+    W = 2 * B * K + (B + 1) // 2
+    packed = torch.zeros(W, dtype=torch.int64)
+    p_ids, p_keys, p_counts = sharding.packed_views(torch, packed, B, K)
+    p_ids.copy_(t_ids), p_keys.copy_(t_keys), p_counts.copy_(t_counts)
+    g_packed = torch.empty((world, W), dtype=torch.int64)
+    sharding.all_gather_packed(dist, packed, g_packed)
+    for r in range(world):
+        a, b_, c = sharding.packed_views(torch, g_packed[r], B, K)
+        assert torch.equal(a, g_ids[r]) and torch.equal(b_, g_keys[r]) and torch.equal(c, g_counts[r])
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -82,6 +82,8 @@ SYMBOLS = [
     ("zh_distance_batch", _i, [_i, _i, _vp, _vp, _sz, _sz, _vp, _i]),
     ("zh_distance_pair", _i, [_i, _i, _vp, _vp, _sz, _vp, _i]),
     ("zh_merge_topk_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("zh_packed_result_words", _sz, [_sz, _sz]),
+    ("zh_merge_topk_packed_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zh_synth_queries_device", _i, [_i, _vp, _u64, _u64, _u64, _u64, _sz, _u32, _i, _vp]),
     ("zh_set_profiling", _i, [_vp, _i]),
     ("zh_stats", _i, [_vp, _vp]),

@@ -1282,8 +1282,25 @@ extern "C" int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, siz
     if (n_shards == 0 || n_shards > 1024) return fail(ZH_EINVAL, "n_shards must be in 1..1024");
     int rc = pick_device(device);
     if (rc) return rc;
-    HIPCHK(zh_launch_merge(n_shards, (uint32_t)b, (uint32_t)k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)stream));
+    HIPCHK(zh_launch_merge(n_shards, (uint32_t)b, (uint32_t)k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, 0, 0, (hipStream_t)stream));
     return ZH_OK;  // enqueued on `stream`; the caller synchronises
+}
+
+// one buffer per shard: [ids b*k u64][keys b*k u64][counts b u32, padded to 8 bytes] -- what ONE all-gather of
+// every rank's packed result produces
+extern "C" size_t zh_packed_result_words(size_t b, size_t k) { return 2 * b * k + (b + 1) / 2; }
+extern "C" int zh_merge_topk_packed_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_packed,
+                                           uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream) {
+    if (b && (!d_packed || !d_out_ids || !d_out_keys || !d_out_counts)) return fail(ZH_EINVAL, "zh_merge_topk_packed_device: null argument");
+    if (k == 0 || k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k must be in 1..%u", ZH_MAX_TOPK);
+    if (n_shards == 0 || n_shards > 1024) return fail(ZH_EINVAL, "n_shards must be in 1..1024");
+    int rc = pick_device(device);
+    if (rc) return rc;
+    const uint64_t words = zh_packed_result_words(b, k);
+    HIPCHK(zh_launch_merge(n_shards, (uint32_t)b, (uint32_t)k, d_packed, d_packed + b * k,
+                           reinterpret_cast<const uint32_t *>(d_packed + 2 * b * k), d_out_ids, d_out_keys, d_out_counts,
+                           words, 2 * words, (hipStream_t)stream));
+    return ZH_OK;
 }
 
 extern "C" int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,

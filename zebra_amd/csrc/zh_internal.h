@@ -116,9 +116,11 @@ hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uin
 hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,
                            const uint32_t *dCandIds, uint64_t id_base, uint64_t *dOutIds, uint64_t *dOutKeys,
                            uint32_t *dOutCounts, hipStream_t s);
+// stride64 / stride32: distance between consecutive shards' ids (= keys) in u64 units and counts in u32 units
+// (0 = contiguous [S][B][k] / [S][B])
 hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *dIds, const uint64_t *dKeys,
                            const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
-                           hipStream_t s);
+                           uint64_t stride64, uint64_t stride32, hipStream_t s);
 // plain distance of n contiguous rows against one query (zh_distance_batch)
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
                                    uint64_t *dKeys, hipStream_t s);

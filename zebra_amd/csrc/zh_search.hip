@@ -1107,7 +1107,8 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
                                                      const uint64_t *__restrict__ cand_ids64,
                                                      const uint32_t *__restrict__ shard_counts, uint64_t id_base,
                                                      uint64_t *__restrict__ out_ids, uint64_t *__restrict__ out_keys,
-                                                     uint32_t *__restrict__ out_counts) {
+                                                     uint32_t *__restrict__ out_counts, uint64_t stride64,
+                                                     uint64_t stride32) {
     __shared__ uint64_t sk[FIN_SORT_N];
     __shared__ uint64_t si[FIN_SORT_N];
     __shared__ uint64_t rk[ZH_MAX_TOPK];
@@ -1130,8 +1131,8 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
             uint64_t e = pos + i, key, id;
             if (MERGE) {
                 uint32_t s = (uint32_t)(e / k), j = (uint32_t)(e % k);
-                bool valid = j < shard_counts[(size_t)s * B + b];
-                size_t src = ((size_t)s * B + b) * k + j;
+                bool valid = j < shard_counts[(size_t)s * stride32 + b];  // shard s starts stride32 counts further
+                size_t src = (size_t)s * stride64 + (size_t)b * k + j;        // ... and stride64 ids / keys further
                 key = valid ? cand_keys[src] : ~0ull;
                 id = valid ? cand_ids64[src] : ~0ull;
             } else {
@@ -1168,15 +1169,17 @@ hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, ui
                            uint32_t *dOutCounts, hipStream_t s) {
     if (!B) return hipSuccess;
     hipLaunchKernelGGL(final_kernel<false>, dim3(B), dim3(256), 0, s, dCandBase, B, T, k, dCandKeys, dCandIds,
-                       (const uint64_t *)nullptr, (const uint32_t *)nullptr, id_base, dOutIds, dOutKeys, dOutCounts);
+                       (const uint64_t *)nullptr, (const uint32_t *)nullptr, id_base, dOutIds, dOutKeys, dOutCounts,
+                       (uint64_t)0, (uint64_t)0);
     return hipGetLastError();
 }
 
 hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *dIds, const uint64_t *dKeys,
                            const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
-                           hipStream_t s) {
+                           uint64_t stride64, uint64_t stride32, hipStream_t s) {
     if (!B) return hipSuccess;
     hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, S, k, dKeys,
-                       (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts);
+                       (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts,
+                       stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B);
     return hipGetLastError();
 }

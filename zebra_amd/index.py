@@ -314,6 +314,15 @@ def merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids
                                      d_out_counts, stream))
 
 
+def packed_result_words(b, k):
+    """u64 words of one rank's packed result: [ids b*k][keys b*k][counts b u32, padded]"""
+    return int(lib().zh_packed_result_words(b, k))
+
+
+def merge_topk_packed_device(device, n_shards, b, k, d_packed, d_out_ids, d_out_keys, d_out_counts, stream=None):
+    check(lib().zh_merge_topk_packed_device(device, n_shards, b, k, d_packed, d_out_ids, d_out_keys, d_out_counts, stream))
+
+
 def synth_queries_device(device, d_out, n_rows, b, dim, b0=0, seed_rows=0x5EB2A001, seed_q=0x5EB2A002, kind=0, stream=None):
     check(lib().zh_synth_queries_device(device, d_out, seed_rows, seed_q, n_rows, b0, b, dim, kind, stream))
 
