@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the in-tree libraries normally arrive prebuilt (__graft_entry__.build()); if they did not, build them once
+    lib = os.path.join(ROOT, "zebra_amd", "lib", "libzebra_hip.so")
+    ora = os.path.join(ROOT, "oracle", "libzebra_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        try:
+            sys.path.insert(0, ROOT)
+            import __graft_entry__
+            __graft_entry__.build()
+        except Exception as e:  # noqa: BLE001 -- the tests that need the libraries will say what is missing
+            print("conftest: could not build the libraries:", e, file=sys.stderr)
 
 
 def _has_gpu():
