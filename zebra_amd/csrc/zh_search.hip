@@ -321,63 +321,64 @@ __device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__r
     }
 }
 
-// One WAVE per (query, tree) pair: control flow is wave-uniform.  A plane below the dense levels is hashed
-// on demand with the wave's registers: lane l holds the contiguous elements [l*E, l*E+E) of the plane and of the
-// query (E = 16 per 1024-element pass), runs its E ordered fmas on the running sum and hands the sum to lane
-// l+1 through v_readlane -- 64 hops, exactly the k-ascending chain, no LDS and one coalesced load of the plane.
-#define WALK_E 16                       // elements per lane per pass
-#define WALK_PASS (64 * WALK_E)         // 1024 elements per pass
+// Four (query, tree) pairs per wave, one per 16-lane ROW; a row's 16 lanes carry identical copies of the pair's DFS
+// state.  A plane below the dense levels is hashed on demand inside the row: lane lr holds the contiguous elements
+// [lr*E, lr*E+E) of a 16*E-element pass of the plane and of the query, runs its E ordered fmas on the running sum and
+// hands the sum to lane lr+1 with DPP row_newbcast -- 16 hops per pass, exactly the k-ascending chain, no LDS, and
+// the four rows' chains share every instruction (a wave-wide chain would spend the same instructions on ONE pair).
+#define WALK_E 24                      // elements per lane per pass (16 * 24 = 384 elements per pass)
+#define WALK_PASS (16 * WALK_E)
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+template <int HOP>
+__device__ __forceinline__ float row_bcast(float a) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x150 + HOP, 0xF, 0xF, false));
 }
 
-// this lane's E contiguous elements of src[k0 .. k0+1024) (zero beyond d)
-__device__ __forceinline__ void load_lane_block(const float *__restrict__ src, uint32_t k0, uint32_t d, uint32_t E,
-                                                uint32_t lane, bool vec4, float *r) {
-    const uint32_t base = k0 + lane * E;
-    if (vec4 && (E & 3u) == 0) {
+// this lane's E contiguous elements of src[k0 + lr*E ..) (zero beyond d, zero when !on)
+template <int E>
+__device__ __forceinline__ void load_row_block(const float *__restrict__ src, uint32_t k0, uint32_t d, uint32_t lr, bool vec4,
+                                               bool on, float *r) {
+    const uint32_t base = k0 + lr * E;
+    if (vec4) {
 #pragma unroll
-        for (int j4 = 0; j4 < WALK_E / 4; j4++) {
+        for (int j4 = 0; j4 < E / 4; j4++) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((uint32_t)(4 * j4) < E && base + 4 * j4 < d) v = *reinterpret_cast<const float4 *>(src + base + 4 * j4);
+            if (on && base + 4 * j4 < d) v = *reinterpret_cast<const float4 *>(src + base + 4 * j4);
             r[4 * j4] = v.x; r[4 * j4 + 1] = v.y; r[4 * j4 + 2] = v.z; r[4 * j4 + 3] = v.w;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < WALK_E; j++) r[j] = ((uint32_t)j < E && base + j < d) ? src[base + j] : 0.0f;
+        for (int j = 0; j < E; j++) r[j] = (on && base + j < d) ? src[base + j] : 0.0f;
     }
 }
 
-// sequential fma chain over one pass: the sum visits lanes 0..63 in order
+// one pass of the chain: the running sum visits the row's lanes 0..15 in order (padded elements are 0*0: a + 0 = a)
 template <int E>
-__device__ __forceinline__ float chain_pass_e(const float *w, const float *q, float acc) {
-#pragma unroll 1
-    for (int hop = 0; hop < 64; hop++) {
-        float a = acc;
-#pragma unroll
-        for (int j = 0; j < E; j++) a = __builtin_fmaf(w[j], q[j], a);  // padded elements are 0*0: a + 0 = a
-        acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), hop));
+__device__ __forceinline__ float chain_row_pass(const float *w, const float *q, float acc) {
+#define ZH_HOP(H)                                                          \
+    {                                                                      \
+        float a = acc;                                                     \
+        _Pragma("unroll") for (int j = 0; j < E; j++) a = __builtin_fmaf(w[j], q[j], a); \
+        acc = row_bcast<H>(a);                                             \
     }
+    ZH_HOP(0) ZH_HOP(1) ZH_HOP(2) ZH_HOP(3) ZH_HOP(4) ZH_HOP(5) ZH_HOP(6) ZH_HOP(7)
+    ZH_HOP(8) ZH_HOP(9) ZH_HOP(10) ZH_HOP(11) ZH_HOP(12) ZH_HOP(13) ZH_HOP(14) ZH_HOP(15)
+#undef ZH_HOP
     return acc;
 }
-__device__ __forceinline__ float chain_pass(const float *w, const float *q, uint32_t E, float acc) {
-    switch (E) {  // wave-uniform
-    case 4: return chain_pass_e<4>(w, q, acc);
-    case 8: return chain_pass_e<8>(w, q, acc);
-    case 12: return chain_pass_e<12>(w, q, acc);
-    default: return chain_pass_e<16>(w, q, acc);  // E is a multiple of 4 in 4..16; unused slots hold zeros
-    }
-}
 
-// E for a pass over elements [k0, min(k0 + 1024, d)): as few elements per lane as cover it (multiple of 4 when possible)
-__device__ __forceinline__ uint32_t pass_E(uint32_t d, uint32_t k0) {
-    uint32_t m = d - k0 < WALK_PASS ? d - k0 : WALK_PASS;
-    uint32_t E = (m + 63) / 64;
-    E = (E + 3) & ~3u;
-    return E > WALK_E ? WALK_E : E;
+// dot(plane, query) for the rows that need one (`on`), the others ride along on zeros
+template <int E>
+__device__ __forceinline__ float row_dot(const float *__restrict__ w, const float *__restrict__ q, uint32_t d, uint32_t lr,
+                                         bool vec4, bool on) {
+    float acc = 0.0f;
+    for (uint32_t k0 = 0; k0 < d; k0 += 16 * E) {  // d is wave-uniform
+        float wreg[E], qreg[E];
+        load_row_block<E>(w, k0, d, lr, vec4, on, wreg);
+        load_row_block<E>(q, k0, d, lr, vec4, on, qreg);
+        acc = chain_row_pass<E>(wreg, qreg, acc);
+    }
+    return acc;
 }
 
 template <bool EMIT>
@@ -391,100 +392,106 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    uint32_t *__restrict__ leafFill,
                                                    const uint32_t *__restrict__ groupBase,
                                                    const uint64_t *__restrict__ groupRowBase,
-                                                   ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff) {
-    __shared__ int32_t st_node[WALK_STACK], st_n[WALK_STACK];
-    const uint32_t T = f.n_trees, lane = threadIdx.x;
-    const uint64_t pair = blockIdx.x;  // one wave (= one block) per pair
-    const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
-    if (EMIT) {
-        uint32_t nv = counts[pair].visits;
-        if (nv <= ZH_INLINE_VISITS) {  // the first pass recorded every visit: place them, one lane each
-            if (lane < nv) {
-                ZhVisit v = inl[pair * ZH_INLINE_VISITS + lane];
+                                                   ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff,
+                                                   uint32_t ppw) {
+    __shared__ int32_t st_node[4][WALK_STACK], st_n[4][WALK_STACK];
+    // ppw = pairs per wave: 4 (one per 16-lane row) normally; 1 when every plane is hashed densely -- no chains to
+    // share then, and one pair per wave keeps the leaf-heavy DFS of small-leaf forests free of row divergence
+    const uint32_t T = f.n_trees, lane = threadIdx.x, row = ppw == 4 ? lane >> 4 : 0, lr = ppw == 4 ? (lane & 15) : lane;
+    const uint64_t n_pairs = (uint64_t)B * T;
+    const uint64_t pair = (uint64_t)blockIdx.x * ppw + row;  // every lane of a row works on the same pair
+    bool active = pair < n_pairs;
+    const uint32_t b = active ? (uint32_t)(pair / T) : 0, t = active ? (uint32_t)(pair % T) : 0;
+    if (EMIT && active) {
+        uint32_t nv0 = counts[pair].visits;
+        if (nv0 <= ZH_INLINE_VISITS) {  // the first pass recorded every visit: place them, one lane each
+            for (uint32_t i = lr; i < nv0; i += (ppw == 4 ? 16 : 64)) {
+                ZhVisit v = inl[pair * ZH_INLINE_VISITS + i];
                 v.row_off += rowBase[pair];
                 v.cand_off += candBase[pair];
-                visits[visitBase[pair] + lane] = v;
+                visits[visitBase[pair] + i] = v;
                 join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
             }
-            return;
+            active = false;
         }
     }
     const float *q = Q + (size_t)b * d;
     const bool vec4 = (d & 3u) == 0;
-    const bool one_pass = d <= WALK_PASS;
-    const uint32_t E0 = pass_E(d, 0);
-    bool q_staged = false;
-    float qreg[WALK_E];
     int sp = 0;
-    int32_t cur = (int32_t)f.roots[t], ncur = n;
+    int32_t cur = active ? (int32_t)f.roots[t] : 0, ncur = n;
     uint32_t nv = 0;
     uint64_t nrows = 0, ntakes = 0;
     uint64_t vb = 0, rb = 0, cb = 0;
-    if (EMIT) { vb = visitBase[pair]; rb = rowBase[pair]; cb = candBase[pair]; }
+    if (EMIT && active) { vb = visitBase[pair]; rb = rowBase[pair]; cb = candBase[pair]; }
+    bool need = false;   // this row waits for the sign of node `cur` (plane p_need)
+    int32_t p_need = 0;
     for (;;) {
-        int32_t p;
-        while ((p = f.node_plane[cur]) >= 0) {
-            bool above;
-            if ((uint32_t)p < P_dense) above = (bits[(size_t)b * wpq + ((uint32_t)p >> 5)] >> (p & 31)) & 1u;
-            else {
-                const float *w = f.planes + (size_t)p * d;
-                float acc = 0.0f;
-                float wreg[WALK_E];
-                if (one_pass) {
-                    load_lane_block(w, 0, d, E0, lane, vec4, wreg);
-                    if (!q_staged) { load_lane_block(q, 0, d, E0, lane, vec4, qreg); q_staged = true; }
-                    acc = chain_pass(wreg, qreg, E0, acc);
-                } else {
-                    for (uint32_t k0 = 0; k0 < d; k0 += WALK_PASS) {
-                        const uint32_t E = pass_E(d, k0);
-                        load_lane_block(w, k0, d, E, lane, vec4, wreg);
-                        load_lane_block(q, k0, d, E, lane, vec4, qreg);
-                        acc = chain_pass(wreg, qreg, E, acc);
+        // ---- phase A: every row runs its DFS until it needs an on-demand sign or is finished ----
+        if (active && !need) {
+            for (;;) {
+                int32_t p = f.node_plane[cur];
+                if (p >= 0) {
+                    if ((uint32_t)p >= P_dense) { need = true; p_need = p; break; }
+                    bool above = (bits[(size_t)b * wpq + ((uint32_t)p >> 5)] >> (p & 31)) & 1u;
+                    int32_t l = f.node_left[cur], r = f.node_right[cur];
+                    if (sp < WALK_STACK) { st_node[row][sp] = above ? l : r; st_n[row][sp] = ncur; }
+                    sp++;
+                    cur = above ? r : l;  // lsh.rs:335-338: above -> right is main
+                    continue;
+                }
+                uint32_t off = (uint32_t)f.node_left[cur], len = (uint32_t)f.node_right[cur];
+                uint32_t take = ncur <= 0 ? 0u : (len < (uint32_t)ncur ? len : (uint32_t)ncur);
+                int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
+                if (take > 0) {
+                    if (lr == 0) {
+                        ZhVisit v;
+                        v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
+                        if (EMIT) {
+                            v.row_off = rb + nrows; v.cand_off = cb + ntakes;
+                            visits[vb + nv] = v;
+                            join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+                        } else {
+                            atomicAdd(&leafCount[cur], 1u);
+                            if (nv < ZH_INLINE_VISITS) {
+                                v.row_off = nrows; v.cand_off = ntakes;
+                                inl[pair * ZH_INLINE_VISITS + nv] = v;
+                            }
+                        }
+                    }
+                    nv++; nrows += len; ntakes += take;
+                }
+                bool down = false;
+                while (sp > 0) {
+                    sp--;
+                    if (sp < WALK_STACK && ret < st_n[row][sp]) {  // lsh.rs:341-343: k < n -> the backup's count alone
+                        cur = st_node[row][sp];
+                        ncur = st_n[row][sp] - ret;
+                        down = true;
+                        break;
                     }
                 }
-                above = ((double)acc + (double)f.consts[p]) >= 0.0;  // lsh.rs:40-42
+                if (!down) { active = false; break; }
             }
+        }
+        if (!__any(need)) break;  // no row waits for a sign: every row has finished
+        // ---- phase B: the rows that need a sign hash their plane, four chains per wave ----
+        const float *w = f.planes + (size_t)(need ? p_need : 0) * d;
+        float acc;
+        const uint32_t l16 = lane & 15;
+        if (d <= 64) acc = row_dot<4>(w, q, d, l16, vec4, need);
+        else if (d <= 128) acc = row_dot<8>(w, q, d, l16, vec4, need);
+        else if (d <= 256) acc = row_dot<16>(w, q, d, l16, vec4, need);
+        else acc = row_dot<WALK_E>(w, q, d, l16, vec4, need);
+        if (need) {
+            bool above = ((double)acc + (double)f.consts[p_need]) >= 0.0;  // lsh.rs:40-42
             int32_t l = f.node_left[cur], r = f.node_right[cur];
-            if (sp < WALK_STACK && lane == 0) { st_node[sp] = above ? l : r; st_n[sp] = ncur; }
+            if (sp < WALK_STACK) { st_node[row][sp] = above ? l : r; st_n[row][sp] = ncur; }
             sp++;
-            cur = above ? r : l;  // lsh.rs:335-338: above -> right is main
+            cur = above ? r : l;
+            need = false;
         }
-        uint32_t off = (uint32_t)f.node_left[cur], len = (uint32_t)f.node_right[cur];
-        uint32_t take = ncur <= 0 ? 0u : (len < (uint32_t)ncur ? len : (uint32_t)ncur);
-        int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
-        if (take > 0) {
-            if (lane == 0) {
-                ZhVisit v;
-                v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
-                if (EMIT) {
-                    v.row_off = rb + nrows; v.cand_off = cb + ntakes;
-                    visits[vb + nv] = v;
-                    join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
-                } else {
-                    atomicAdd(&leafCount[cur], 1u);
-                    if (nv < ZH_INLINE_VISITS) {
-                        v.row_off = nrows; v.cand_off = ntakes;
-                        inl[pair * ZH_INLINE_VISITS + nv] = v;
-                    }
-                }
-            }
-            nv++; nrows += len; ntakes += take;
-        }
-        wave_lds_sync();  // lane 0's stack writes -> every lane's reads
-        bool down = false;
-        while (sp > 0) {
-            sp--;
-            if (sp < WALK_STACK && ret < st_n[sp]) {  // lsh.rs:341-343: k < n -> the backup's count alone
-                cur = st_node[sp];
-                ncur = st_n[sp] - ret;
-                down = true;
-                break;
-            }
-        }
-        wave_lds_sync();
-        if (!down) break;
     }
-    if (!EMIT && lane == 0) {
+    if (!EMIT && pair < n_pairs && lr == 0) {
         ZhPairCounts c;
         c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
         counts[pair] = c;
@@ -496,9 +503,10 @@ hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint
                                 ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)pairs), dim3(64), 0, s, f, dQ, B, d, n, dBits,
+    const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
+    hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)((pairs + ppw - 1) / ppw)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
                        words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr, dLeafCount, nullptr,
-                       nullptr, nullptr, nullptr, nullptr);
+                       nullptr, nullptr, nullptr, nullptr, ppw);
     return hipGetLastError();
 }
 hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
@@ -509,10 +517,11 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)pairs), dim3(64), 0, s, f, dQ, B, d, n, dBits,
+    const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
+    hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)((pairs + ppw - 1) / ppw)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
                        words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts), const_cast<ZhVisit *>(dInline),
                        dRowBase, dCandBase, dVisitBase, dVisits, const_cast<uint32_t *>(dLeafCount), dLeafFill,
-                       dGroupBase, dGroupRowBase, dGroups, dGroupRowOff);
+                       dGroupBase, dGroupRowBase, dGroups, dGroupRowOff, ppw);
     return hipGetLastError();
 }
 
