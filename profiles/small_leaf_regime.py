@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The reference's default options (max_node_size 5, 15 trees) at batch size: the walk wanders over most of the
+forest, so a batch is millions of 2-4-row leaf visits.  Prints per-stage times; results are checked against
+the oracle for a few queries."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zebra_amd as za  # noqa: E402
+from oracle import zebra_oracle as zo  # noqa: E402
+
+n, d, B, k = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, 384, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 10
+X = zo.synth_rows(n, d)
+Q = zo.synth_queries(B, d, n)
+ix = za.LSHIndex(d, za.LSHIndexOptions(5, 15))
+t0 = time.perf_counter()
+ix.add(X)
+print("build s", round(time.perf_counter() - t0, 2), "planes", ix.get_forest()["consts"].size)
+m = za.L2SquaredDistance()
+ix.search_batch(Q, k, m)
+ix.set_profiling(1)
+ix.stats(reset=True)
+t0 = time.perf_counter()
+for _ in range(3):
+    ids, keys, counts = ix.search_batch(Q, k, m)
+dt = (time.perf_counter() - t0) / 3
+st = ix.stats()
+print("ms/batch", round(dt * 1e3, 2), "qps", round(B / dt), {s: round(st["ms_" + s] / st["timed_batches"], 3) for s in ("hash", "walk", "sweep", "select", "final")},
+      "visits", st["visits"], "rows", st["rows_scored"], "cands", st["candidates"])
+f = zo.Forest.from_arrays(X, 5, ix.get_forest())
+for b in (0, 1, B // 2, B - 2, B - 1):
+    oi, ok = f.search(Q[b], k, zo.L2SQ)
+    assert (ids[b] == oi).all() and (keys[b] == ok).all()
+print("checked against the oracle")

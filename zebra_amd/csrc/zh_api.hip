@@ -79,7 +79,8 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wLogPool, wLogHead, wLogCtl;
+    size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
     hipEvent_t ev_totals = nullptr, ev_emit = nullptr, ev_sw0 = nullptr, ev_sw1 = nullptr;
@@ -95,7 +96,8 @@ struct zh_search_ctx {
     ZhTotals tot{};
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff};
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff,
+                        &wLogPool, &wLogHead, &wLogCtl};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
         if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
@@ -114,7 +116,7 @@ struct zh_index {
     uint64_t n_rows = 0;
 
     // forest
-    DevBuf node_plane, node_left, node_right, roots, planes, consts, leaf_ids;
+    DevBuf node_plane, node_left, node_right, node_pack, roots, planes, consts, leaf_ids;
     uint32_t n_nodes = 0, n_planes = 0, n_trees = 0;
     uint64_t n_leaf_ids = 0;
     std::vector<int32_t> h_plane, h_left, h_right;
@@ -146,6 +148,7 @@ static ZhForestDev forest_dev(const zh_index *ix) {
     f.node_plane = ix->node_plane.as<int32_t>();
     f.node_left = ix->node_left.as<int32_t>();
     f.node_right = ix->node_right.as<int32_t>();
+    f.node_pack = ix->node_pack.as<int4>();
     f.roots = ix->roots.as<uint32_t>();
     f.planes = ix->planes.as<float>();
     f.consts = ix->consts.as<float>();
@@ -226,7 +229,7 @@ extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
 }
 
 static void free_forest(zh_index *ix) {
-    ix->node_plane.release(); ix->node_left.release(); ix->node_right.release(); ix->roots.release();
+    ix->node_plane.release(); ix->node_left.release(); ix->node_right.release(); ix->node_pack.release(); ix->roots.release();
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
@@ -343,11 +346,15 @@ static int upload_nodes(zh_index *ix) {
     if ((rc = ix->node_plane.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
     if ((rc = ix->node_left.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
     if ((rc = ix->node_right.ensure(std::max<size_t>(nn, 1) * 4))) return rc;
+    if ((rc = ix->node_pack.ensure(std::max<size_t>(nn, 1) * sizeof(int4)))) return rc;
     if ((rc = ix->roots.ensure(std::max<size_t>(ix->h_roots.size(), 1) * 4))) return rc;
     if (nn) {
         HIPCHK(hipMemcpyAsync(ix->node_plane.p, ix->h_plane.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
         HIPCHK(hipMemcpyAsync(ix->node_left.p, ix->h_left.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
         HIPCHK(hipMemcpyAsync(ix->node_right.p, ix->h_right.data(), nn * 4, hipMemcpyHostToDevice, ix->stream));
+        // the plane constants are final on this stream by now (set_forest's copy, make_planes of build / insert)
+        HIPCHK(zh_launch_pack_nodes(ix->node_plane.as<int32_t>(), ix->node_left.as<int32_t>(), ix->node_right.as<int32_t>(),
+                                    ix->consts.as<float>(), ix->node_pack.as<int4>(), (uint32_t)nn, ix->stream));
     }
     if (!ix->h_roots.empty())
         HIPCHK(hipMemcpyAsync(ix->roots.p, ix->h_roots.data(), ix->h_roots.size() * 4, hipMemcpyHostToDevice, ix->stream));
@@ -957,6 +964,15 @@ static uint32_t choose_dense_planes(const zh_index *ix, size_t B, size_t k) {
 
 int ctx_wait(zh_search_ctx *c);
 
+static ZhWalkLog walk_log(const zh_search_ctx *c) {
+    ZhWalkLog l;
+    l.pool = c->wLogPool.as<uint2>();
+    l.capacity = (uint32_t)std::min<size_t>(c->log_chunks, 0xFFFFFFFEu);
+    l.head = c->wLogHead.as<uint32_t>();
+    l.ctl = c->wLogCtl.as<ZhLogCtl>();
+    return l;
+}
+
 // first half of a batch: hash, the walk's counting pass, scans; the three totals travel to the host
 static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int metric, int mode, hipStream_t s) {
     zh_index *ix = c->ix;
@@ -969,7 +985,7 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
-    if (pairs > 0x7FFFFFFFull) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees too large"); }
+    if (pairs > (1ull << 26)) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees > 2^26"); }
     c->P_dense = choose_dense_planes(ix, B, k);
     c->wpq = (c->P_dense + 63) / 64 * 2;
     const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
@@ -986,6 +1002,14 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
     if ((rc = c->wLeafFill.ensure(nn * 4))) return rc;
     if ((rc = c->wGroupBase.ensure(nn * 4))) return rc;
     if ((rc = c->wGroupRowBase.ensure(nn * 8))) return rc;
+    if ((rc = c->wLogHead.ensure(pairs * 4))) return rc;
+    if ((rc = c->wLogCtl.ensure(sizeof(ZhLogCtl)))) return rc;
+    if (!c->wLogPool.p) {
+        static const size_t first = [] { const char *e = getenv("ZH_WALK_LOG_CHUNKS"); return e ? (size_t)atoll(e) : (size_t)8192; }();
+        if ((rc = c->wLogPool.ensure(std::max<size_t>(first, 1) * ZH_LOG_CHUNK * sizeof(uint2)))) return rc;
+        c->log_chunks = std::max<size_t>(first, 1);
+    }
+    HIPCHK(hipMemsetAsync(c->wLogCtl.p, 0, sizeof(ZhLogCtl), s));
     HIPCHK(hipMemsetAsync(c->wLeafCount.p, 0, nn * 4, s));
     HIPCHK(hipMemsetAsync(c->wLeafFill.p, 0, nn * 4, s));
     ZhForestDev f = forest_dev(ix);
@@ -995,11 +1019,12 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
         HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, c->P_dense, d, c->wBits.as<uint32_t>(), c->wpq, nullptr, s));
     HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
-                                c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), s));
+                                c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
     HIPCHK(zh_launch_leaf_scan(f, c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
                                c->wGroupRowBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
     HIPCHK(zh_launch_pair_scan(c->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, c->wRowBase.as<uint64_t>(),
-                               c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
+                               c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(),
+                               c->wLogCtl.as<ZhLogCtl>(), s));
     HIPCHK(hipMemcpyAsync(c->h_totals, c->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev_totals, s));
     c->state = 1;
@@ -1038,11 +1063,29 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, u
     if ((rc = c->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
     if ((rc = c->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
     ZhForestDev f = forest_dev(ix);
-    HIPCHK(zh_launch_walk_emit(f, c->dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
-                               c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wRowBase.as<uint64_t>(),
-                               c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wVisits.as<ZhVisit>(),
-                               c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
-                               c->wGroupRowBase.as<uint64_t>(), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), s));
+    if (!(tot.flags & 1u)) {
+        // the counting pass logged every visit: place them (no second walk)
+        HIPCHK(zh_launch_expand(f, (uint32_t)B, c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(),
+                                c->wRowBase.as<uint64_t>(), c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(),
+                                c->wVisits.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(),
+                                c->wGroupBase.as<uint32_t>(), c->wGroupRowBase.as<uint64_t>(), c->wGroups.as<ZhGroup>(),
+                                c->wGroupRowOff.as<uint64_t>(), walk_log(c), s));
+    } else {
+        // the visit log ran out of chunks: walk again, emitting this time, and give the next batch a log that fits
+        HIPCHK(zh_launch_walk_emit(f, c->dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
+                                   c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wRowBase.as<uint64_t>(),
+                                   c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wVisits.as<ZhVisit>(),
+                                   c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
+                                   c->wGroupRowBase.as<uint64_t>(), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), s));
+        const uint64_t pairs = (uint64_t)B * T;
+        const uint64_t want = tot.visits / (ZH_LOG_CHUNK - 1) + std::min<uint64_t>(pairs, tot.visits / (ZH_INLINE_VISITS + 1)) + 16;
+        static const bool fixed = getenv("ZH_WALK_LOG_FIXED") != nullptr;  // tests: keep the log small, always fall back
+        if (!fixed && want > c->log_chunks) {
+            const size_t chunks = (size_t)(want + want / 2);
+            // the pool is idle: the counting pass has completed (its totals are here) and the emit walk does not use it
+            if (c->wLogPool.ensure(chunks * ZH_LOG_CHUNK * sizeof(uint2)) == ZH_OK) c->log_chunks = chunks;
+        }
+    }
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
     // successive batches execute back to back while everything else overlaps them on the contexts' own streams

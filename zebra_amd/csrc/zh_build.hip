@@ -102,13 +102,23 @@ hipError_t zh_launch_iota_perm(uint32_t *dPerm, uint64_t N, uint32_t T, hipStrea
     return hipGetLastError();
 }
 
+// A launch holds fewer than 2^32 threads: block-indexed kernels over many million nodes / chunks / rows are issued
+// in slices of ZH_MAX_BLOCKS blocks, each told the index of its first block.
+#define ZH_MAX_BLOCKS (1u << 23)
+#define ZH_SLICED(KERNEL, N_BLOCKS, THREADS, SHMEM, STREAM, ...)                                              \
+    for (uint64_t b0_ = 0; b0_ < (uint64_t)(N_BLOCKS); b0_ += ZH_MAX_BLOCKS) {                                \
+        const uint64_t nb_ = (uint64_t)(N_BLOCKS) - b0_ < ZH_MAX_BLOCKS ? (uint64_t)(N_BLOCKS) - b0_ : ZH_MAX_BLOCKS; \
+        hipLaunchKernelGGL(KERNEL, dim3((uint32_t)nb_), dim3(THREADS), SHMEM, STREAM, __VA_ARGS__, (uint32_t)b0_); \
+    }
+
 // lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 (sequential fma chain)
 __global__ __launch_bounds__(256) void make_planes_kernel(const float *__restrict__ X, uint32_t d,
                                                            const ZhBuildNode *__restrict__ nodes,
-                                                           float *__restrict__ planes, float *__restrict__ consts) {
+                                                           float *__restrict__ planes, float *__restrict__ consts,
+                                                           uint32_t block0) {
     extern __shared__ float sm[];  // w[d], p[d]
     float *w = sm, *p = sm + d;
-    const ZhBuildNode nd = nodes[blockIdx.x];
+    const ZhBuildNode nd = nodes[blockIdx.x + block0];
     const float *a = nd.sample_a == ~0ull ? nullptr : X + (size_t)nd.sample_a * d;
     const float *b = nd.sample_b == ~0ull ? nullptr : X + (size_t)nd.sample_b * d;
     for (uint32_t k = threadIdx.x; k < d; k += blockDim.x) {
@@ -128,8 +138,7 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const float *__restric
 hipError_t zh_launch_make_planes(const float *dX, uint32_t d, const ZhBuildNode *dNodes, uint32_t n_nodes,
                                  float *dPlanes, float *dConsts, hipStream_t s) {
     if (!n_nodes) return hipSuccess;
-    hipLaunchKernelGGL(make_planes_kernel, dim3(n_nodes), dim3(256), 2 * d * sizeof(float), s, dX, d, dNodes,
-                       dPlanes, dConsts);
+    ZH_SLICED(make_planes_kernel, n_nodes, 256, 2 * d * sizeof(float), s, dX, d, dNodes, dPlanes, dConsts)
     return hipGetLastError();
 }
 
@@ -142,9 +151,10 @@ __global__ __launch_bounds__(256) void classify_kernel(const float *__restrict__
                                                         const float *__restrict__ planes,
                                                         const float *__restrict__ consts,
                                                         uint8_t *__restrict__ flags,
-                                                        uint32_t *__restrict__ chunk_above) {
+                                                        uint32_t *__restrict__ chunk_above, uint32_t block0) {
     __shared__ uint32_t wsum[4];
-    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const uint32_t bid = blockIdx.x + block0;
+    const ZhBuildChunk ch = chunks[bid];
     const uint32_t plane = nodes[ch.node].plane;
     const float *__restrict__ w = planes + (size_t)plane * d;
     const float c = consts[plane];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const float *__restrict__
     unsigned long long m = __ballot(above);
     if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (tid == 0) chunk_above[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) chunk_above[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 // The same classification with the rows staged through LDS: the block loads its 256 rows in coalesced 256-B
 // pieces (16 lanes per row piece, 4 rows per wave instruction) into a [row][64 + 4] tile -- every fetched line is
@@ -189,11 +199,12 @@ __global__ __launch_bounds__(256) void classify_lds_kernel(const float *__restri
                                                             const float *__restrict__ planes,
                                                             const float *__restrict__ consts,
                                                             uint8_t *__restrict__ flags,
-                                                            uint32_t *__restrict__ chunk_above) {
+                                                            uint32_t *__restrict__ chunk_above, uint32_t block0) {
     __shared__ __attribute__((aligned(16))) float tile[256 * CL_PITCH];
     __shared__ uint32_t ids_s[256];
     __shared__ uint32_t wsum[4];
-    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const uint32_t bid = blockIdx.x + block0;
+    const ZhBuildChunk ch = chunks[bid];
     const uint32_t plane = nodes[ch.node].plane;
     const float4 *__restrict__ w4 = reinterpret_cast<const float4 *>(planes + (size_t)plane * d);
     const float c = consts[plane];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256) void classify_lds_kernel(const float *__restri
     unsigned long long m = __ballot(above);
     if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (tid == 0) chunk_above[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) chunk_above[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 hipError_t zh_launch_classify(const float *dX, uint32_t d, const uint32_t *dPerm, const ZhBuildNode *dNodes,
@@ -240,12 +251,10 @@ hipError_t zh_launch_classify(const float *dX, uint32_t d, const uint32_t *dPerm
     if (!n_chunks) return hipSuccess;
     static const int variant = [] { const char *e = getenv("ZH_CLASSIFY_VARIANT"); return e ? atoi(e) : 0; }();
     if ((d & 3u) == 0 && d >= 64 && variant != 1) {
-        hipLaunchKernelGGL(classify_lds_kernel, dim3(n_chunks), dim3(256), 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes,
-                           dConsts, dFlags, dChunkAbove);
+        ZH_SLICED(classify_lds_kernel, n_chunks, 256, 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes, dConsts, dFlags, dChunkAbove)
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(classify_kernel, dim3(n_chunks), dim3(256), 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes,
-                       dConsts, dFlags, dChunkAbove);
+    ZH_SLICED(classify_kernel, n_chunks, 256, 0, s, dX, d, dPerm, dNodes, dChunks, dPlanes, dConsts, dFlags, dChunkAbove)
     return hipGetLastError();
 }
 
@@ -321,9 +330,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint32_t *__restrict
                                                        const ZhBuildChunk *__restrict__ chunks,
                                                        const uint8_t *__restrict__ flags,
                                                        const uint32_t *__restrict__ chunk_scan,
-                                                       uint32_t *__restrict__ node_above) {
+                                                       uint32_t *__restrict__ node_above, uint32_t block0) {
     __shared__ uint32_t sm[256];
-    const ZhBuildChunk ch = chunks[blockIdx.x];
+    const uint32_t bid = blockIdx.x + block0;
+    const ZhBuildChunk ch = chunks[bid];
     const ZhBuildNode nd = nodes[ch.node];
     const uint32_t tid = threadIdx.x;
     uint32_t f = 0, id = 0;
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint32_t *__restrict
     }
     const uint32_t local_above = sm[tid] - f;  // exclusive
     const uint32_t base_scan = chunk_scan[nd.first_chunk];
-    const uint32_t above_before = chunk_scan[blockIdx.x] - base_scan;
+    const uint32_t above_before = chunk_scan[bid] - base_scan;
     const uint32_t n_above = chunk_scan[nd.first_chunk + nd.n_chunks] - base_scan;
     const uint32_t n_below = nd.len - n_above;
     if (tid < ch.count) {
@@ -347,21 +357,19 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint32_t *__restrict
         uint64_t dest = f ? nd.seg_start + n_below + a_excl : nd.seg_start + (pos_in_node - a_excl);
         perm_out[dest] = id;
     }
-    if (blockIdx.x == nd.first_chunk && tid == 0) node_above[ch.node] = n_above;
+    if (bid == nd.first_chunk && tid == 0) node_above[ch.node] = n_above;
 }
 __global__ __launch_bounds__(256) void copyback_kernel(uint32_t *__restrict__ perm, const uint32_t *__restrict__ tmp,
-                                                        const ZhBuildChunk *__restrict__ chunks) {
-    const ZhBuildChunk ch = chunks[blockIdx.x];
+                                                        const ZhBuildChunk *__restrict__ chunks, uint32_t block0) {
+    const ZhBuildChunk ch = chunks[blockIdx.x + block0];
     if (threadIdx.x < ch.count) perm[ch.pos + threadIdx.x] = tmp[ch.pos + threadIdx.x];
 }
 hipError_t zh_launch_scatter(const uint32_t *dPermIn, uint32_t *dPermOut, const ZhBuildNode *dNodes,
                              const ZhBuildChunk *dChunks, uint32_t n_chunks, const uint8_t *dFlags,
                              const uint32_t *dChunkScan, uint32_t *dNodeAbove, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(scatter_kernel, dim3(n_chunks), dim3(256), 0, s, dPermIn, dPermOut, dNodes, dChunks, dFlags,
-                       dChunkScan, dNodeAbove);
-    hipLaunchKernelGGL(copyback_kernel, dim3(n_chunks), dim3(256), 0, s, const_cast<uint32_t *>(dPermIn), dPermOut,
-                       dChunks);
+    ZH_SLICED(scatter_kernel, n_chunks, 256, 0, s, dPermIn, dPermOut, dNodes, dChunks, dFlags, dChunkScan, dNodeAbove)
+    ZH_SLICED(copyback_kernel, n_chunks, 256, 0, s, const_cast<uint32_t *>(dPermIn), dPermOut, dChunks)
     return hipGetLastError();
 }
 
@@ -389,6 +397,23 @@ hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDesce
     return hipGetLastError();
 }
 
+// the walk's 16-byte node records (ZhForestDev::node_pack)
+__global__ __launch_bounds__(256) void pack_nodes_kernel(const int32_t *__restrict__ plane, const int32_t *__restrict__ left,
+                                                          const int32_t *__restrict__ right, const float *__restrict__ consts,
+                                                          int4 *__restrict__ pack, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t p = plane[i];
+    pack[i] = make_int4(p, left[i], right[i], p >= 0 ? __float_as_int(consts[p]) : 0);
+}
+hipError_t zh_launch_pack_nodes(const int32_t *dPlane, const int32_t *dLeft, const int32_t *dRight, const float *dConsts,
+                                int4 *dPack, uint32_t n_nodes, hipStream_t s) {
+    if (!n_nodes) return hipSuccess;
+    hipLaunchKernelGGL(pack_nodes_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, dPlane, dLeft, dRight, dConsts, dPack,
+                       n_nodes);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // deduplicate (lsh.rs:270-288 compares the f32 bit patterns): one wave per row, h = sum over words of
 // mix(word, position) in wrapping u64 -- order-independent to reduce, position-sensitive by construction
@@ -400,8 +425,8 @@ __device__ __forceinline__ uint64_t mix_word(uint32_t w, uint32_t pos) {
     return x ^ (x >> 31);
 }
 __global__ __launch_bounds__(256) void row_hash_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
-                                                        uint64_t *__restrict__ out) {
-    const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                        uint64_t *__restrict__ out, uint32_t block0) {
+    const uint64_t row = (((uint64_t)blockIdx.x + block0) * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (row >= n) return;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(X + (size_t)row * d);
@@ -414,7 +439,7 @@ hipError_t zh_launch_row_hash(const float *dX, uint64_t n, uint32_t d, uint64_t 
     if (!n) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(row_hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, n, d, dHash);
+    ZH_SLICED(row_hash_kernel, blocks, 256, 0, s, dX, n, d, dHash)
     return hipGetLastError();
 }
 

@@ -34,12 +34,28 @@ struct ZhPairCounts {
     uint32_t visits, rows, takes, pad;
 };
 struct ZhTotals {
-    uint64_t visits, rows, takes, flags;
+    uint64_t visits, rows, takes, flags;  // flags bit 0: the visit log overflowed (the emit walk must run)
     uint64_t groups, group_rows;  // filled by the leaf scan
+};
+
+// Visit log of the walk's (single) pass: a pair's visits beyond the ZH_INLINE_VISITS inline ones are appended as
+// {leaf node, take} to 512-byte chunks handed out by a bump allocator; entry 0 of a chunk is {next chunk, unused}.
+#define ZH_LOG_CHUNK 64
+struct ZhLogCtl {
+    uint32_t next_chunk, overflow;
+};
+struct ZhWalkLog {
+    uint2 *pool;          // capacity * ZH_LOG_CHUNK entries
+    uint32_t capacity;    // chunks
+    uint32_t *head;       // first chunk of every pair (valid when the pair has more than ZH_INLINE_VISITS visits)
+    ZhLogCtl *ctl;
 };
 
 struct ZhForestDev {
     const int32_t *node_plane, *node_left, *node_right;
+    // one 16-byte record per node for the walk: {plane, left, right, bits of the plane's constant} for an internal node,
+    // {-1, leaf offset, leaf length, 0} for a leaf -- one dependent load per step instead of four
+    const int4 *node_pack;
     const uint32_t *roots;
     const float *planes, *consts;
     const uint32_t *leaf_ids;
@@ -93,13 +109,21 @@ hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlane
 hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, hipStream_t s);
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                 const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
-                                ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s);
+                                ZhVisit *dInline, uint32_t *dLeafCount, ZhWalkLog log, hipStream_t s);
+// places every visit recorded by the counting pass (inline + log) and joins the leaf groups: the cheap, flat
+// replacement of the emit walk whenever the log did not overflow
+hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCounts, const ZhVisit *dInline,
+                            const uint64_t *dRowBase, const uint64_t *dCandBase, const uint64_t *dVisitBase,
+                            ZhVisit *dVisits, const uint32_t *dLeafCount, uint32_t *dLeafFill,
+                            const uint32_t *dGroupBase, const uint64_t *dGroupRowBase, ZhGroup *dGroups,
+                            uint64_t *dGroupRowOff, ZhWalkLog log, hipStream_t s);
 // per leaf node: visits -> groups; exclusive scans of groups and of groups * len over the nodes
 hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
                                uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s);
 // exclusive scans over the pairs; the three base arrays have n_pairs + 1 entries
 hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, uint64_t *dRowBase,
-                               uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, hipStream_t s);
+                               uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, const ZhLogCtl *dLogCtl,
+                               hipStream_t s);
 hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense,
                                const ZhPairCounts *dCounts, const ZhVisit *dInline, const uint64_t *dRowBase,
@@ -144,6 +168,9 @@ struct ZhDescend {
     uint32_t row, node, depth, tree;
     uint64_t path;
 };
+// node_pack from the three node arrays and the plane constants
+hipError_t zh_launch_pack_nodes(const int32_t *dPlane, const int32_t *dLeft, const int32_t *dRight, const float *dConsts,
+                                int4 *dPack, uint32_t n_nodes, hipStream_t s);
 hipError_t zh_launch_descend(ZhForestDev f, const float *dX, uint32_t d, ZhDescend *dItems, uint32_t n, hipStream_t s);
 
 // 64-bit content hash of every stored row (order-sensitive, exact integer arithmetic): deduplicate

@@ -334,21 +334,37 @@ __device__ __forceinline__ float row_bcast(float a) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x150 + HOP, 0xF, 0xF, false));
 }
 
-// this lane's E contiguous elements of src[k0 + lr*E ..) (zero beyond d, zero when !on)
+// this lane's E contiguous elements of src[k0 + lr*E ..), zero beyond d.  Branch-free: an out-of-range element is
+// read from a clamped (valid) address and replaced by zero; `full` (d a multiple of the pass) skips the selects.
 template <int E>
 __device__ __forceinline__ void load_row_block(const float *__restrict__ src, uint32_t k0, uint32_t d, uint32_t lr, bool vec4,
-                                               bool on, float *r) {
+                                               bool full, float *r) {
     const uint32_t base = k0 + lr * E;
-    if (vec4) {
+    if (vec4) {  // d % 4 == 0: a float4 lies entirely inside or entirely outside the row
+        if (full) {
 #pragma unroll
-        for (int j4 = 0; j4 < E / 4; j4++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (on && base + 4 * j4 < d) v = *reinterpret_cast<const float4 *>(src + base + 4 * j4);
-            r[4 * j4] = v.x; r[4 * j4 + 1] = v.y; r[4 * j4 + 2] = v.z; r[4 * j4 + 3] = v.w;
+            for (int j4 = 0; j4 < E / 4; j4++) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + base + 4 * j4);
+                r[4 * j4] = v.x; r[4 * j4 + 1] = v.y; r[4 * j4 + 2] = v.z; r[4 * j4 + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j4 = 0; j4 < E / 4; j4++) {
+                const uint32_t e = base + 4 * j4;
+                const bool in = e < d;
+                const float4 v = *reinterpret_cast<const float4 *>(src + (in ? e : 0u));
+                r[4 * j4] = in ? v.x : 0.0f; r[4 * j4 + 1] = in ? v.y : 0.0f;
+                r[4 * j4 + 2] = in ? v.z : 0.0f; r[4 * j4 + 3] = in ? v.w : 0.0f;
+            }
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < E; j++) r[j] = (on && base + j < d) ? src[base + j] : 0.0f;
+        for (int j = 0; j < E; j++) {
+            const uint32_t e = base + j;
+            const bool in = e < d;
+            const float v = src[in ? e : 0u];
+            r[j] = in ? v : 0.0f;
+        }
     }
 }
 
@@ -367,21 +383,17 @@ __device__ __forceinline__ float chain_row_pass(const float *w, const float *q, 
     return acc;
 }
 
-// dot(plane, query) for the rows that need one (`on`), the others ride along on zeros
-template <int E>
-__device__ __forceinline__ float row_dot(const float *__restrict__ w, const float *__restrict__ q, uint32_t d, uint32_t lr,
-                                         bool vec4, bool on) {
-    float acc = 0.0f;
-    for (uint32_t k0 = 0; k0 < d; k0 += 16 * E) {  // d is wave-uniform
-        float wreg[E], qreg[E];
-        load_row_block<E>(w, k0, d, lr, vec4, on, wreg);
-        load_row_block<E>(q, k0, d, lr, vec4, on, qreg);
-        acc = chain_row_pass<E>(wreg, qreg, acc);
-    }
-    return acc;
+// component-wise select (a struct-valued ?: goes through scratch memory)
+__device__ __forceinline__ int4 sel4(bool c, const int4 &a, const int4 &b) {
+    return make_int4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
-template <bool EMIT>
+// DFS state of a row: the current node's RECORD travels with its id (the records of both children are fetched as
+// soon as an internal node's record is known -- they arrive while the sign is worked out -- and the backup child's
+// record waits on the LDS stack), so a step's only exposed miss is the plane row of an on-demand hash.
+// E = elements per lane per pass of an on-demand chain; NP = passes whose query block stays in registers for the whole
+// walk (d <= NP * 16 * E), 0 = the query block is re-read with every plane (very long vectors)
+template <bool EMIT, int E, int NP>
 __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__restrict__ Q, uint32_t B, uint32_t d,
                                                    int32_t n, const uint32_t *__restrict__ bits, uint32_t wpq,
                                                    uint32_t P_dense, ZhPairCounts *__restrict__ counts,
@@ -393,8 +405,9 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    const uint32_t *__restrict__ groupBase,
                                                    const uint64_t *__restrict__ groupRowBase,
                                                    ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff,
-                                                   uint32_t ppw) {
-    __shared__ int32_t st_node[4][WALK_STACK], st_n[4][WALK_STACK];
+                                                   uint32_t ppw, ZhWalkLog wlog) {
+    __shared__ int4 st_rec[4][WALK_STACK];
+    __shared__ int2 st_nn[4][WALK_STACK];  // {node, n}
     // ppw = pairs per wave: 4 (one per 16-lane row) normally; 1 when every plane is hashed densely -- no chains to
     // share then, and one pair per wave keeps the leaf-heavy DFS of small-leaf forests free of row divergence
     const uint32_t T = f.n_trees, lane = threadIdx.x, row = ppw == 4 ? lane >> 4 : 0, lr = ppw == 4 ? (lane & 15) : lane;
@@ -416,30 +429,44 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         }
     }
     const float *q = Q + (size_t)b * d;
-    const bool vec4 = (d & 3u) == 0;
+    const bool vec4 = (d & 3u) == 0, full = (d % (16u * E)) == 0;
+    const uint32_t l16 = lane & 15;
+    float qreg[NP > 0 ? NP : 1][E];
+    if (NP > 0 && P_dense < f.n_planes) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            if (p == 0 || (uint32_t)p * 16u * E < d) load_row_block<E>(q, (uint32_t)p * 16u * E, d, l16, vec4, full, qreg[p]);
+    }
     int sp = 0;
     int32_t cur = active ? (int32_t)f.roots[t] : 0, ncur = n;
+    int4 rec = active ? f.node_pack[cur] : make_int4(-1, 0, 0, 0);
     uint32_t nv = 0;
     uint64_t nrows = 0, ntakes = 0;
     uint64_t vb = 0, rb = 0, cb = 0;
     if (EMIT && active) { vb = visitBase[pair]; rb = rowBase[pair]; cb = candBase[pair]; }
-    bool need = false;   // this row waits for the sign of node `cur` (plane p_need)
-    int32_t p_need = 0;
+    uint32_t log_chunk = 0xFFFFFFFFu, log_fill = 0;  // lane lr == 0 of the row keeps the log cursor
+    bool log_ok = true;
+    bool need = false;   // this row waits for the sign of node `cur` (an on-demand plane)
+#define ZH_DESCEND(ABOVE, RL, RR)                                                                        \
+    {                                                                                                    \
+        const bool ab_ = (ABOVE);                                                                        \
+        if (sp < WALK_STACK) { st_rec[row][sp] = sel4(ab_, (RL), (RR)); st_nn[row][sp] = make_int2(ab_ ? rec.y : rec.z, ncur); } \
+        sp++;                                                                                            \
+        cur = ab_ ? rec.z : rec.y; /* lsh.rs:335-338: above -> right is main */                          \
+        rec = sel4(ab_, (RR), (RL));                                                                     \
+    }
     for (;;) {
         // ---- phase A: every row runs its DFS until it needs an on-demand sign or is finished ----
         if (active && !need) {
             for (;;) {
-                int32_t p = f.node_plane[cur];
-                if (p >= 0) {
-                    if ((uint32_t)p >= P_dense) { need = true; p_need = p; break; }
-                    bool above = (bits[(size_t)b * wpq + ((uint32_t)p >> 5)] >> (p & 31)) & 1u;
-                    int32_t l = f.node_left[cur], r = f.node_right[cur];
-                    if (sp < WALK_STACK) { st_node[row][sp] = above ? l : r; st_n[row][sp] = ncur; }
-                    sp++;
-                    cur = above ? r : l;  // lsh.rs:335-338: above -> right is main
+                if (rec.x >= 0) {
+                    if ((uint32_t)rec.x >= P_dense) { need = true; break; }
+                    const int4 rl = f.node_pack[rec.y], rr = f.node_pack[rec.z];
+                    const bool above = (bits[(size_t)b * wpq + ((uint32_t)rec.x >> 5)] >> (rec.x & 31)) & 1u;
+                    ZH_DESCEND(above, rl, rr)
                     continue;
                 }
-                uint32_t off = (uint32_t)f.node_left[cur], len = (uint32_t)f.node_right[cur];
+                uint32_t off = (uint32_t)rec.y, len = (uint32_t)rec.z;
                 uint32_t take = ncur <= 0 ? 0u : (len < (uint32_t)ncur ? len : (uint32_t)ncur);
                 int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
                 if (take > 0) {
@@ -455,6 +482,17 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                             if (nv < ZH_INLINE_VISITS) {
                                 v.row_off = nrows; v.cand_off = ntakes;
                                 inl[pair * ZH_INLINE_VISITS + nv] = v;
+                            } else if (log_ok) {
+                                if (log_chunk == 0xFFFFFFFFu || log_fill == ZH_LOG_CHUNK - 1) {
+                                    const uint32_t c = atomicAdd(&wlog.ctl->next_chunk, 1u);
+                                    if (c >= wlog.capacity) { wlog.ctl->overflow = 1u; log_ok = false; }
+                                    else {
+                                        if (log_chunk == 0xFFFFFFFFu) wlog.head[pair] = c;
+                                        else wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK].x = c;
+                                        log_chunk = c; log_fill = 0;
+                                    }
+                                }
+                                if (log_ok) wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK + 1 + log_fill++] = make_uint2((uint32_t)cur, take);
                             }
                         }
                     }
@@ -463,9 +501,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 bool down = false;
                 while (sp > 0) {
                     sp--;
-                    if (sp < WALK_STACK && ret < st_n[row][sp]) {  // lsh.rs:341-343: k < n -> the backup's count alone
-                        cur = st_node[row][sp];
-                        ncur = st_n[row][sp] - ret;
+                    if (sp < WALK_STACK && ret < st_nn[row][sp].y) {  // lsh.rs:341-343: k < n -> the backup's count alone
+                        cur = st_nn[row][sp].x;
+                        ncur = st_nn[row][sp].y - ret;
+                        rec = st_rec[row][sp];
                         down = true;
                         break;
                     }
@@ -475,22 +514,33 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         }
         if (!__any(need)) break;  // no row waits for a sign: every row has finished
         // ---- phase B: the rows that need a sign hash their plane, four chains per wave ----
-        const float *w = f.planes + (size_t)(need ? p_need : 0) * d;
-        float acc;
-        const uint32_t l16 = lane & 15;
-        if (d <= 64) acc = row_dot<4>(w, q, d, l16, vec4, need);
-        else if (d <= 128) acc = row_dot<8>(w, q, d, l16, vec4, need);
-        else if (d <= 256) acc = row_dot<16>(w, q, d, l16, vec4, need);
-        else acc = row_dot<WALK_E>(w, q, d, l16, vec4, need);
+        int4 rl = make_int4(-1, 0, 0, 0), rr = rl;
+        if (need) { rl = f.node_pack[rec.y]; rr = f.node_pack[rec.z]; }
+        const float *w = f.planes + (size_t)(need ? rec.x : 0) * d;  // a row that needs no sign rides along on plane 0
+        float acc = 0.0f;
+        if (NP > 0) {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                if (p == 0 || (uint32_t)p * 16u * E < d) {  // wave-uniform
+                    float wreg[E];
+                    load_row_block<E>(w, (uint32_t)p * 16u * E, d, l16, vec4, full, wreg);
+                    acc = chain_row_pass<E>(wreg, qreg[p], acc);
+                }
+        } else {
+            for (uint32_t k0 = 0; k0 < d; k0 += 16 * E) {
+                float wreg[E], qr[E];
+                load_row_block<E>(w, k0, d, l16, vec4, full, wreg);
+                load_row_block<E>(q, k0, d, l16, vec4, full, qr);
+                acc = chain_row_pass<E>(wreg, qr, acc);
+            }
+        }
         if (need) {
-            bool above = ((double)acc + (double)f.consts[p_need]) >= 0.0;  // lsh.rs:40-42
-            int32_t l = f.node_left[cur], r = f.node_right[cur];
-            if (sp < WALK_STACK) { st_node[row][sp] = above ? l : r; st_n[row][sp] = ncur; }
-            sp++;
-            cur = above ? r : l;
+            const bool above = ((double)acc + (double)__int_as_float(rec.w)) >= 0.0;  // lsh.rs:40-42
+            ZH_DESCEND(above, rl, rr)
             need = false;
         }
     }
+#undef ZH_DESCEND
     if (!EMIT && pair < n_pairs && lr == 0) {
         ZhPairCounts c;
         c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
@@ -498,15 +548,34 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
     }
 }
 
+template <bool EMIT>
+static void launch_walk(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n, const uint32_t *dBits,
+                        uint32_t wpq, uint32_t P_dense, ZhPairCounts *dCounts, ZhVisit *dInline, const uint64_t *dRowBase,
+                        const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits, uint32_t *dLeafCount,
+                        uint32_t *dLeafFill, const uint32_t *dGroupBase, const uint64_t *dGroupRowBase, ZhGroup *dGroups,
+                        uint64_t *dGroupRowOff, ZhWalkLog log, hipStream_t s) {
+    const uint64_t pairs = (uint64_t)B * f.n_trees;
+    const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
+    const dim3 grid((uint32_t)((pairs + ppw - 1) / ppw));
+#define ZH_WALK(E_, NP_)                                                                                                    \
+    hipLaunchKernelGGL((walk_kernel<EMIT, E_, NP_>), grid, dim3(64), 0, s, f, dQ, B, d, n, dBits, wpq, P_dense, dCounts,     \
+                       dInline, dRowBase, dCandBase, dVisitBase, dVisits, dLeafCount, dLeafFill, dGroupBase, dGroupRowBase, \
+                       dGroups, dGroupRowOff, ppw, log)
+    if (d <= 64) ZH_WALK(4, 1);
+    else if (d <= 128) ZH_WALK(8, 1);
+    else if (d <= 256) ZH_WALK(16, 1);
+    else if (d <= 16 * WALK_E) ZH_WALK(WALK_E, 1);
+    else if (d <= 32 * WALK_E) ZH_WALK(WALK_E, 2);
+    else ZH_WALK(WALK_E, 0);
+#undef ZH_WALK
+}
+
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                 const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
-                                ZhVisit *dInline, uint32_t *dLeafCount, hipStream_t s) {
-    uint64_t pairs = (uint64_t)B * f.n_trees;
-    if (!pairs) return hipSuccess;
-    const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
-    hipLaunchKernelGGL(walk_kernel<false>, dim3((uint32_t)((pairs + ppw - 1) / ppw)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
-                       words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr, dLeafCount, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, ppw);
+                                ZhVisit *dInline, uint32_t *dLeafCount, ZhWalkLog log, hipStream_t s) {
+    if (!((uint64_t)B * f.n_trees)) return hipSuccess;
+    launch_walk<false>(f, dQ, B, d, n, dBits, words_per_q, P_dense, dCounts, dInline, nullptr, nullptr, nullptr, nullptr,
+                       dLeafCount, nullptr, nullptr, nullptr, nullptr, nullptr, log, s);
     return hipGetLastError();
 }
 hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
@@ -515,13 +584,80 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits,
                                const uint32_t *dLeafCount, uint32_t *dLeafFill, const uint32_t *dGroupBase,
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s) {
+    if (!((uint64_t)B * f.n_trees)) return hipSuccess;
+    ZhWalkLog nolog{nullptr, 0, nullptr, nullptr};
+    launch_walk<true>(f, dQ, B, d, n, dBits, words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts),
+                      const_cast<ZhVisit *>(dInline), dRowBase, dCandBase, dVisitBase, dVisits,
+                      const_cast<uint32_t *>(dLeafCount), dLeafFill, dGroupBase, dGroupRowBase, dGroups, dGroupRowOff, nolog, s);
+    return hipGetLastError();
+}
+
+// expand: one wave per (query, tree) pair places the visits the counting pass recorded -- the inline ones, then the
+// log's chunks, 63 entries at a time with a wave scan for the row / candidate offsets -- and joins the leaf groups.
+__global__ __launch_bounds__(64) void expand_kernel(ZhForestDev f, uint32_t T, const ZhPairCounts *__restrict__ counts,
+                                                     const ZhVisit *__restrict__ inl, const uint64_t *__restrict__ rowBase,
+                                                     const uint64_t *__restrict__ candBase,
+                                                     const uint64_t *__restrict__ visitBase, ZhVisit *__restrict__ visits,
+                                                     const uint32_t *__restrict__ leafCount, uint32_t *__restrict__ leafFill,
+                                                     const uint32_t *__restrict__ groupBase,
+                                                     const uint64_t *__restrict__ groupRowBase, ZhGroup *__restrict__ groups,
+                                                     uint64_t *__restrict__ groupRowOff, ZhWalkLog wlog) {
+    const uint64_t pair = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nv = counts[pair].visits;
+    if (!nv) return;
+    const uint32_t b = (uint32_t)(pair / T);
+    const uint64_t vb = visitBase[pair], rb = rowBase[pair], cb = candBase[pair];
+    const uint32_t n_inl = nv < ZH_INLINE_VISITS ? nv : ZH_INLINE_VISITS;
+    if (lane < n_inl) {
+        ZhVisit v = inl[pair * ZH_INLINE_VISITS + lane];
+        v.row_off += rb;
+        v.cand_off += cb;
+        visits[vb + lane] = v;
+        join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+    }
+    if (nv <= ZH_INLINE_VISITS) return;
+    const ZhVisit last = inl[pair * ZH_INLINE_VISITS + ZH_INLINE_VISITS - 1];
+    uint64_t run_rows = last.row_off + last.len, run_takes = last.cand_off + last.take;
+    uint32_t chunk = wlog.head[pair], idx = ZH_INLINE_VISITS, remaining = nv - ZH_INLINE_VISITS;
+    while (remaining) {  // wave-uniform
+        const uint32_t cnt = remaining < ZH_LOG_CHUNK - 1 ? remaining : ZH_LOG_CHUNK - 1;
+        const uint2 *C = wlog.pool + (size_t)chunk * ZH_LOG_CHUNK;
+        const uint32_t next = C[0].x;
+        const bool on = lane >= 1 && lane <= cnt;
+        uint2 e = make_uint2(0, 0);
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (on) { e = C[lane]; r = f.node_pack[e.x]; }
+        const uint32_t len = on ? (uint32_t)r.z : 0u, take = on ? e.y : 0u;
+        uint32_t sl = len, stk = take;  // inclusive scans over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(sl, o), c = __shfl_up(stk, o);
+            if (lane >= (uint32_t)o) { sl += a; stk += c; }
+        }
+        if (on) {
+            ZhVisit v;
+            v.b = b; v.leaf_off = (uint32_t)r.y; v.len = len; v.take = take; v.node = e.x; v.pad = 0;
+            v.row_off = rb + run_rows + (sl - len);
+            v.cand_off = cb + run_takes + (stk - take);
+            visits[vb + idx + lane - 1] = v;
+            join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+        }
+        run_rows += __shfl(sl, 63);
+        run_takes += __shfl(stk, 63);
+        idx += cnt; remaining -= cnt; chunk = next;
+    }
+}
+hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCounts, const ZhVisit *dInline,
+                            const uint64_t *dRowBase, const uint64_t *dCandBase, const uint64_t *dVisitBase,
+                            ZhVisit *dVisits, const uint32_t *dLeafCount, uint32_t *dLeafFill,
+                            const uint32_t *dGroupBase, const uint64_t *dGroupRowBase, ZhGroup *dGroups,
+                            uint64_t *dGroupRowOff, ZhWalkLog log, hipStream_t s) {
     uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
-    hipLaunchKernelGGL(walk_kernel<true>, dim3((uint32_t)((pairs + ppw - 1) / ppw)), dim3(64), 0, s, f, dQ, B, d, n, dBits,
-                       words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts), const_cast<ZhVisit *>(dInline),
-                       dRowBase, dCandBase, dVisitBase, dVisits, const_cast<uint32_t *>(dLeafCount), dLeafFill,
-                       dGroupBase, dGroupRowBase, dGroups, dGroupRowOff, ppw);
+    hipLaunchKernelGGL(expand_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, f.n_trees, dCounts, dInline, dRowBase,
+                       dCandBase, dVisitBase, dVisits, dLeafCount, dLeafFill, dGroupBase, dGroupRowBase, dGroups,
+                       dGroupRowOff, log);
     return hipGetLastError();
 }
 
@@ -563,7 +699,8 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__r
                                                           uint64_t *__restrict__ rowBase,
                                                           uint64_t *__restrict__ candBase,
                                                           uint64_t *__restrict__ visitBase,
-                                                          ZhTotals *__restrict__ totals) {
+                                                          ZhTotals *__restrict__ totals,
+                                                          const ZhLogCtl *__restrict__ logCtl) {
     __shared__ uint64_t sr[1024], sc[1024], sv[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023) / 1024;
@@ -586,14 +723,16 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__r
     }
     if (tid == 1023) {
         rowBase[n] = sr[1023]; candBase[n] = sc[1023]; visitBase[n] = sv[1023];
-        totals->rows = sr[1023]; totals->takes = sc[1023]; totals->visits = sv[1023]; totals->flags = 0;
+        totals->rows = sr[1023]; totals->takes = sc[1023]; totals->visits = sv[1023];
+        totals->flags = logCtl->overflow ? 1u : 0u;
     }
 }
 
 hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, uint64_t *dRowBase,
-                               uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, hipStream_t s) {
+                               uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, const ZhLogCtl *dLogCtl,
+                               hipStream_t s) {
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, dCounts, n_pairs, dRowBase, dCandBase, dVisitBase,
-                       dTotals);
+                       dTotals, dLogCtl);
     return hipGetLastError();
 }
 
@@ -1036,7 +1175,12 @@ __device__ __forceinline__ void select_fast(const ZhVisit &v, const uint32_t *__
 #undef SEL_KEY
 }
 
-__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits,
+// A block owns `chunk` consecutive visits (1 when visits are few and long, up to 256 when the walk produced millions
+// of tiny ones -- small-leaf forests): thread t first looks at visit t; a short leaf taken whole is copied by that
+// thread on the spot, everything else queues for the block's partition code.  (One block per visit would also run into
+// the 2^32-threads-per-launch limit at 2^24 visits.)
+#define SEL_GROUP_LEN 16
+__global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
                                                       const uint32_t *__restrict__ leaf_ids,
                                                       const uint64_t *__restrict__ keys,
                                                       uint64_t *__restrict__ cand_keys,
@@ -1044,22 +1188,63 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
     __shared__ uint64_t sk[ZH_SORT_N];
     __shared__ __attribute__((aligned(16))) uint32_t si[ZH_SORT_N];  // slow path ids; fast path: small-sort buffers + histogram
     __shared__ uint32_t s_u32[8];
-    const ZhVisit v = visits[blockIdx.x];
+    __shared__ uint32_t s_list[256], s_small[256], s_nlist, s_nsmall;
     const uint32_t tid = threadIdx.x;
-    if (v.take == 0) return;
-    if (v.take >= v.len) {
-        for (uint32_t i = tid; i < v.len; i += 256) {
-            cand_keys[v.cand_off + i] = keys[v.row_off + i];
-            cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
+    const uint64_t base = (uint64_t)blockIdx.x * chunk;
+    const uint32_t cnt = (uint32_t)(n_visits - base < chunk ? n_visits - base : chunk);
+    if (tid == 0) { s_nlist = 0; s_nsmall = 0; }
+    __syncthreads();
+    if (tid < cnt) {
+        const uint32_t len = visits[base + tid].len, take = visits[base + tid].take;
+        if (take > 0) {
+            if (len <= SEL_GROUP_LEN) s_small[atomicAdd(&s_nsmall, 1u)] = tid;
+            else s_list[atomicAdd(&s_nlist, 1u)] = tid;
         }
-        return;
     }
-    bool need_slow = false;
-    if (v.len <= ZH_SORT_N) select_fast<true>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
-    else select_fast<false>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
-    if (need_slow) {  // a large group of equal keys straddles the cut: order it by id the slow way
-        __syncthreads();
-        select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si);
+    __syncthreads();
+    // leaves of at most 16 rows: one 16-lane group per visit, a lane per row; a row's rank among the visit's (key, id)
+    // pairs says whether it is one of the `take` smallest (and where it goes)
+    {
+        const uint32_t ns = s_nsmall, g = tid >> 4, l = tid & 15;
+        for (uint32_t i = g; i < ns; i += 16) {
+            const ZhVisit v = visits[base + s_small[i]];
+            const bool on = l < v.len;
+            const uint64_t k = on ? keys[v.row_off + l] : ~0ull;
+            const uint32_t id = on ? leaf_ids[(size_t)v.leaf_off + l] : ~0u;
+            uint32_t rank = l;
+            if (v.take < v.len) {
+                rank = 0;
+#pragma unroll
+                for (int j = 0; j < SEL_GROUP_LEN; j++) {
+                    const uint64_t kj = __shfl(k, j, SEL_GROUP_LEN);
+                    const uint32_t ij = __shfl(id, j, SEL_GROUP_LEN);
+                    rank += (kj < k || (kj == k && ij < id)) ? 1u : 0u;
+                }
+            }
+            if (on && rank < v.take) {
+                cand_keys[v.cand_off + rank] = k;
+                cand_ids[v.cand_off + rank] = id;
+            }
+        }
+    }
+    const uint32_t nl = s_nlist;
+    for (uint32_t li = 0; li < nl; li++) {  // block-uniform
+        const ZhVisit v = visits[base + s_list[li]];
+        if (v.take >= v.len) {
+            for (uint32_t i = tid; i < v.len; i += 256) {
+                cand_keys[v.cand_off + i] = keys[v.row_off + i];
+                cand_ids[v.cand_off + i] = leaf_ids[(size_t)v.leaf_off + i];
+            }
+            continue;
+        }
+        bool need_slow = false;
+        if (v.len <= ZH_SORT_N) select_fast<true>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
+        else select_fast<false>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
+        if (need_slow) {  // a large group of equal keys straddles the cut: order it by id the slow way
+            __syncthreads();
+            select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si);
+        }
+        __syncthreads();  // the LDS buffers are reused by the next visit
     }
 }
 
@@ -1067,8 +1252,11 @@ hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uin
                             const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s) {
     if (!n_visits) return hipSuccess;
     if (n_visits > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_kernel, dim3((uint32_t)n_visits), dim3(256), 0, s, dVisits, dLeafIds, dKeys, dCandKeys,
-                       dCandIds);
+    uint64_t chunk = (n_visits + 16383) / 16384;  // >= 16k blocks before a block takes a second visit
+    if (chunk > 256) chunk = 256;
+    const uint64_t blocks = (n_visits + chunk - 1) / chunk;  // <= 2^23: 2^31 threads
+    hipLaunchKernelGGL(select_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, dLeafIds,
+                       dKeys, dCandKeys, dCandIds);
     return hipGetLastError();
 }
 
