@@ -121,3 +121,25 @@ def test_cfg5_shard_slice_128d_sift_l2_top10_batch4096():
     import zebra_amd as za
     # a 20M-row slice of one cfg5 shard (125M x 128): integer-valued rows -> exact L2
     _check(za, 20_000_000, 128, "l2", 10, 4096, 8192, 15, kind=1, planted_min=0.3, n_check=3)
+
+
+def test_reference_default_options_at_batch_size_more_than_2_24_visits():
+    """lsh.rs:134-135 defaults (max_node_size 5, 15 trees) on 1M rows with a batch of 256: the walk wanders over a good
+    part of every tree -- 17.5M leaf visits in one batch, more than 2^24, past the inline visits and the
+    first visit-log pool, through the 16-lane-group selection.  First, middle and last queries against the oracle."""
+    import zebra_amd as za
+    n, d, B, k = 1_000_000, 64, 256, 10
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(5, 15))
+    ix.add(X)
+    m = za.L2SquaredDistance()
+    ids, keys, counts = ix.search_batch(Q, k, m)      # visit log overflows: the emit walk runs
+    ids2, keys2, counts2 = ix.search_batch(Q, k, m)   # grown log: the flat expansion runs
+    st = ix.stats()
+    assert st["visits"] > (1 << 24)
+    assert (ids == ids2).all() and (keys == keys2).all() and (counts == counts2).all()
+    f = zo.Forest.from_arrays(X, 5, ix.get_forest())
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        oi, ok = f.search(Q[b], k, zo.L2SQ)
+        assert (ids[b] == oi).all() and (keys[b] == ok).all()

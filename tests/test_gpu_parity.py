@@ -602,3 +602,39 @@ def test_three_deep_pipeline_matches_blocking_calls(za):
         assert torch.equal(got[i][2], ref[i][2]) and torch.equal(got[i][0], ref[i][0]) and torch.equal(got[i][1], ref[i][1]), i
     st = ix.stats()
     assert st["rows_scored"] > 0
+
+
+_LOG_FALLBACK_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import zebra_amd as za
+from oracle import zebra_oracle as zo
+n, d, B, k = 30000, 96, 48, 10
+X = zo.synth_rows(n, d); Q = zo.synth_queries(B, d, n)
+ix = za.LSHIndex(d, za.LSHIndexOptions(5, 6)); ix.add(X)
+f = zo.Forest.from_arrays(X, 5, ix.get_forest())
+for metric, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(parity=True), zo.COSINE, zo.PARITY)):
+    for _ in range(2):
+        ids, keys, counts = ix.search_batch(Q, k, metric)
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()
+assert ix.stats()["visits"] > 64 * B * 6, ix.stats()["visits"]
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"ZH_WALK_LOG_CHUNKS": "3", "ZH_WALK_LOG_FIXED": "1"},   # always overflows: emit walk
+                                 {"ZH_WALK_LOG_CHUNKS": "3"},                               # overflows once, then grows
+                                 {"ZH_WALK_LOG_CHUNKS": "1000000"}])                        # never overflows
+def test_visit_log_overflow_falls_back_to_the_emit_walk(za, env):
+    """walk_kernel<false> logs the visits beyond the inline ones in chunks from a bump allocator; when the pool runs
+    out the batch is walked a second time (walk_kernel<true>).  Both ways give the oracle's answers."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _LOG_FALLBACK_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
