@@ -18,6 +18,8 @@ t0 = time.perf_counter()
 ix.add(X)
 print("build s", round(time.perf_counter() - t0, 2), "planes", ix.get_forest()["consts"].size)
 m = za.L2SquaredDistance()
+if os.environ.get("DENSE_LEVELS"):
+    ix.set_dense_levels(int(os.environ["DENSE_LEVELS"]))
 ix.search_batch(Q, k, m)
 ix.set_profiling(1)
 ix.stats(reset=True)

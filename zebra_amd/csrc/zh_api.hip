@@ -132,6 +132,7 @@ struct zh_index {
     DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
 
     int dense_levels = -1;
+    double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
     std::mutex stats_mu;
     zh_stats_t stats{};
@@ -237,6 +238,10 @@ static void free_forest(zh_index *ix) {
     ix->planes_below_level.clear();
     ix->h_leaf_ids.clear();
     ix->max_leaf_len = 0;
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->visits_per_pair = 0;
+    }
 }
 
 extern "C" void zh_index_destroy(zh_index *ix) {
@@ -945,21 +950,34 @@ extern "C" int zh_stats_reset(zh_index *ix) {
     return ZH_OK;
 }
 
-// number of leading planes hashed densely for a batch of B queries asking for k neighbours
-static uint32_t choose_dense_planes(const zh_index *ix, size_t B, size_t k) {
+// number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
+static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     const auto &below = ix->planes_below_level;
     if (below.size() <= 1 || ix->n_planes == 0) return 0;
     if (ix->dense_levels >= 0) return below[std::min<size_t>((size_t)ix->dense_levels, below.size() - 1)];
-    // 1-leaf regime (leaves comfortably >= k): a pair evaluates ~depth planes, cheap on demand, so only the
-    // top levels -- shared by every query -- go to the MFMA kernel.  Small leaves (the reference's defaults,
-    // max_node_size 5 < top_k): the walk wanders over most of the forest, hash everything densely.
-    const bool exhaustive = (size_t)ix->opt.max_node_size < 2 * k + 2;
-    const double budget = exhaustive ? 4e11 : 2e9;  // flops
-    const double per_plane = 2.0 * (double)B * ix->opt.dim;
-    uint32_t best = 0;
+    // The top levels, shared by every query, always go to the MFMA kernel (a 2 GFLOP budget: tens of microseconds).
+    const double d = ix->opt.dim, per_plane = 2.0 * (double)B * d;
+    uint32_t top = 0;
     for (size_t L = 1; L < below.size(); L++)
-        if ((double)below[L] * per_plane <= budget) best = below[L];
-    return best;
+        if ((double)below[L] * per_plane <= 2e9) top = below[L];
+    // Below them a pair either hashes the planes it meets on demand (a 16-lane ordered fma chain per plane) or finds every
+    // sign precomputed.  With leaves comfortably >= k a pair meets ~depth planes and on demand is all but free; with
+    // small leaves (the reference's defaults, max_node_size 5 < top_k) the walk wanders over a good part of every tree
+    //  and the dense kernel, ~20x cheaper per sign, wins although it hashes planes nobody asks for.  The
+    // visits per pair of the previous batches decide; measured constants (MI355X): 90 TF for the dense kernel, 1.4 us per
+    // step of the slowest pair (~5x the mean visit count) or 0.7 us of a SIMD per four steps when waves queue.
+    double vpp;
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        vpp = ix->visits_per_pair;
+    }
+    if (vpp <= 0) vpp = (size_t)ix->opt.max_node_size < 2 * k + 2 ? 1000.0 : 2.0;
+    const double pairs = (double)B * ix->n_trees;
+    const double t_chain = std::max(1.4e-6 * 5.0 * vpp, pairs / 4.0 * 2.3 * vpp * 0.7e-6 * (d / 384.0) / 1024.0);
+    const double t_dense = (double)ix->n_planes * per_plane / 9e13;
+    const double bits_bytes = (double)ix->n_planes * (double)B / 8.0;
+    if (t_dense < t_chain && bits_bytes < 8e9) return ix->n_planes;
+    return top;
 }
 
 int ctx_wait(zh_search_ctx *c);
@@ -1054,6 +1072,11 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, u
     }
     HIPCHK(hipEventSynchronize(c->ev_totals));
     const ZhTotals tot = c->tot = *c->h_totals;
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        const double v = (double)tot.visits / (double)((uint64_t)B * T);
+        ix->visits_per_pair = ix->visits_per_pair > 0 ? 0.5 * (ix->visits_per_pair + v) : v;
+    }
     if (tot.visits > 0xFFFFFFFull || tot.rows >= (1ull << 36))
         return fail(ZH_ELIMIT, "more than 2^28 leaf visits or 2^36 scored rows in one batch; use a smaller batch");
     if ((rc = c->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;

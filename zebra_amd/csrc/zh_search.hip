@@ -301,6 +301,7 @@ hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, 
 // lengths and n -- never on distances -- so it runs ahead of the sweep and emits the visit list.
 // ------------------------------------------------------------------------------------------------
 #define WALK_STACK 64
+#define WALK_BUF 16
 
 // emit pass: the s-th visit of a leaf joins group s / ZH_GROUP of that leaf as member s % ZH_GROUP
 __device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__restrict__ leafCount,
@@ -408,6 +409,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    uint32_t ppw, ZhWalkLog wlog) {
     __shared__ int4 st_rec[4][WALK_STACK];
     __shared__ int2 st_nn[4][WALK_STACK];  // {node, n}
+    // a row's latest visits {node, leaf offset, leaf length, take} and their row / candidate offsets, written out
+    // WALK_BUF at a time
+    __shared__ uint4 vb_a[4][WALK_BUF];
+    __shared__ uint64_t vb_r[4][WALK_BUF], vb_c[4][WALK_BUF];
     // ppw = pairs per wave: 4 (one per 16-lane row) normally; 1 when every plane is hashed densely -- no chains to
     // share then, and one pair per wave keeps the leaf-heavy DFS of small-leaf forests free of row divergence
     const uint32_t T = f.n_trees, lane = threadIdx.x, row = ppw == 4 ? lane >> 4 : 0, lr = ppw == 4 ? (lane & 15) : lane;
@@ -444,8 +449,64 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
     uint64_t nrows = 0, ntakes = 0;
     uint64_t vb = 0, rb = 0, cb = 0;
     if (EMIT && active) { vb = visitBase[pair]; rb = rowBase[pair]; cb = candBase[pair]; }
-    uint32_t log_chunk = 0xFFFFFFFFu, log_fill = 0;  // lane lr == 0 of the row keeps the log cursor
+    uint32_t nbuf = 0;
+    uint32_t log_chunk = 0xFFFFFFFFu;  // the log chunk being filled and its number in the pair's chain (-1: none yet)
+    int32_t log_cn = -1;
     bool log_ok = true;
+    // Stores and atomics share the loads' in-order counter (vmcnt): one issued per visit would stall the very next
+    // record load for a full write round trip.  Visits therefore collect in LDS and leave WALK_BUF at a time, one
+    // lane each: leafCount atomics, inline visits, log entries (count pass) / placed visits and group joins (emit pass).
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t first = nv - nbuf, vi = first + lr;
+        const bool mine = lr < nbuf;
+        const uint4 va = vb_a[row][mine ? lr : 0];
+        ZhVisit v;
+        v.b = b; v.leaf_off = va.y; v.len = va.z; v.take = va.w; v.node = va.x; v.pad = 0;
+        v.row_off = vb_r[row][mine ? lr : 0]; v.cand_off = vb_c[row][mine ? lr : 0];
+        if (EMIT) {
+            if (mine) {
+                visits[vb + vi] = v;
+                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+            }
+        } else {
+            if (mine) {
+                atomicAdd(&leafCount[v.node], 1u);
+                if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
+            }
+            if (nv > ZH_INLINE_VISITS && log_ok) {  // row-uniform: entries [max(first, 32), nv) go to the log
+                constexpr uint32_t PER = ZH_LOG_CHUNK - 1;
+                const int32_t c1 = (int32_t)((nv - 1 - ZH_INLINE_VISITS) / PER);  // chain number of the last entry's chunk
+                uint32_t newc = 0xFFFFFFFFu;
+                if (c1 > log_cn) {  // at most one new chunk per flush (WALK_BUF < PER)
+                    uint32_t c = 0;
+                    if (lr == 0) c = atomicAdd(&wlog.ctl->next_chunk, 1u);
+                    c = __shfl(c, (int)(lane - lr));
+                    if (c >= wlog.capacity) {
+                        if (lr == 0) wlog.ctl->overflow = 1u;
+                        log_ok = false;
+                    } else {
+                        newc = c;
+                        if (lr == 0) {
+                            if (log_cn < 0) wlog.head[pair] = c;
+                            else wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK].x = c;
+                        }
+                    }
+                }
+                if (log_ok) {
+                    if (mine && vi >= ZH_INLINE_VISITS) {
+                        const uint32_t li = vi - ZH_INLINE_VISITS;
+                        const uint32_t id = (int32_t)(li / PER) == log_cn ? log_chunk : newc;
+                        wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = make_uint2(v.node, v.take);
+                    }
+                    if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
+                }
+            }
+        }
+        nbuf = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     bool need = false;   // this row waits for the sign of node `cur` (an on-demand plane)
 #define ZH_DESCEND(ABOVE, RL, RR)                                                                        \
     {                                                                                                    \
@@ -471,32 +532,12 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 int32_t ret = (int32_t)take;  // lsh.rs:306 / 329
                 if (take > 0) {
                     if (lr == 0) {
-                        ZhVisit v;
-                        v.b = b; v.leaf_off = off; v.len = len; v.take = take; v.node = (uint32_t)cur; v.pad = 0;
-                        if (EMIT) {
-                            v.row_off = rb + nrows; v.cand_off = cb + ntakes;
-                            visits[vb + nv] = v;
-                            join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
-                        } else {
-                            atomicAdd(&leafCount[cur], 1u);
-                            if (nv < ZH_INLINE_VISITS) {
-                                v.row_off = nrows; v.cand_off = ntakes;
-                                inl[pair * ZH_INLINE_VISITS + nv] = v;
-                            } else if (log_ok) {
-                                if (log_chunk == 0xFFFFFFFFu || log_fill == ZH_LOG_CHUNK - 1) {
-                                    const uint32_t c = atomicAdd(&wlog.ctl->next_chunk, 1u);
-                                    if (c >= wlog.capacity) { wlog.ctl->overflow = 1u; log_ok = false; }
-                                    else {
-                                        if (log_chunk == 0xFFFFFFFFu) wlog.head[pair] = c;
-                                        else wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK].x = c;
-                                        log_chunk = c; log_fill = 0;
-                                    }
-                                }
-                                if (log_ok) wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK + 1 + log_fill++] = make_uint2((uint32_t)cur, take);
-                            }
-                        }
+                        vb_a[row][nbuf] = make_uint4((uint32_t)cur, off, len, take);
+                        vb_r[row][nbuf] = (EMIT ? rb : 0) + nrows;
+                        vb_c[row][nbuf] = (EMIT ? cb : 0) + ntakes;
                     }
-                    nv++; nrows += len; ntakes += take;
+                    nbuf++; nv++; nrows += len; ntakes += take;
+                    if (nbuf == WALK_BUF) flush();
                 }
                 bool down = false;
                 while (sp > 0) {
@@ -541,6 +582,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         }
     }
 #undef ZH_DESCEND
+    if (nbuf) flush();
     if (!EMIT && pair < n_pairs && lr == 0) {
         ZhPairCounts c;
         c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
@@ -561,7 +603,16 @@ static void launch_walk(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, 
     hipLaunchKernelGGL((walk_kernel<EMIT, E_, NP_>), grid, dim3(64), 0, s, f, dQ, B, d, n, dBits, wpq, P_dense, dCounts,     \
                        dInline, dRowBase, dCandBase, dVisitBase, dVisits, dLeafCount, dLeafFill, dGroupBase, dGroupRowBase, \
                        dGroups, dGroupRowOff, ppw, log)
-    if (d <= 64) ZH_WALK(4, 1);
+    // registers: the query block kept in registers (NP > 0) costs occupancy -- worth it while every wave of the launch
+    // is resident anyway (deep walks of few pairs); with more waves than that, or no chains at all, the lean variants
+    const uint64_t waves = grid.x;
+    if (P_dense >= f.n_planes) ZH_WALK(4, 0);
+    else if (waves > 2048) {
+        if (d <= 64) ZH_WALK(4, 0);
+        else if (d <= 128) ZH_WALK(8, 0);
+        else if (d <= 256) ZH_WALK(16, 0);
+        else ZH_WALK(WALK_E, 0);
+    } else if (d <= 64) ZH_WALK(4, 1);
     else if (d <= 128) ZH_WALK(8, 1);
     else if (d <= 256) ZH_WALK(16, 1);
     else if (d <= 16 * WALK_E) ZH_WALK(WALK_E, 1);
