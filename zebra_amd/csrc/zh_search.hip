@@ -1367,29 +1367,53 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
     uint64_t c0 = 0;
     if (MERGE) n_src = (uint64_t)T * k;  // T carries the shard count here
     else { c0 = candBase[(uint64_t)b * T]; n_src = candBase[(uint64_t)(b + 1) * T] - c0; }
+    __shared__ uint32_t s_fill;
     uint32_t have = 0;
     uint64_t pos = 0;
     bool first = true;
+    // Streaming top-k: the sort buffer holds the k best so far plus new entries.  Once k distinct entries are held, an
+    // entry that does not beat the k-th (key, id) can never be output, so the stream is filtered on the way in and
+    // the buffer is sorted only when 1024 survivors have gathered (a wandering walk hands over ~10^5 candidates per
+    // query, nearly all of them beyond the k-th best after the first round).
+    constexpr uint32_t TILE = 1024;
     while (pos < n_src || first) {
         first = false;
-        uint32_t m = FIN_SORT_N - have;
-        if ((uint64_t)m > n_src - pos) m = (uint32_t)(n_src - pos);
         for (uint32_t i = tid; i < have; i += 256) { sk[i] = rk[i]; si[i] = ri[i]; }
-        for (uint32_t i = tid; i < m; i += 256) {
-            uint64_t e = pos + i, key, id;
-            if (MERGE) {
-                uint32_t s = (uint32_t)(e / k), j = (uint32_t)(e % k);
-                bool valid = j < shard_counts[(size_t)s * stride32 + b];  // shard s starts stride32 counts further
-                size_t src = (size_t)s * stride64 + (size_t)b * k + j;        // ... and stride64 ids / keys further
-                key = valid ? cand_keys[src] : ~0ull;
-                id = valid ? cand_ids64[src] : ~0ull;
-            } else {
-                key = cand_keys[c0 + e];
-                id = id_base + cand_ids32[c0 + e];
+        const bool filt = k > 0 && have == k;
+        const uint64_t tk = filt ? rk[k - 1] : 0, ti = filt ? ri[k - 1] : 0;
+        if (tid == 0) s_fill = have;
+        __syncthreads();
+        for (;;) {
+            const uint32_t fill = s_fill;  // block-uniform
+            if (pos >= n_src || FIN_SORT_N - fill < TILE) break;
+            __syncthreads();  // everyone has read s_fill before anyone appends
+#pragma unroll
+            for (uint32_t u = 0; u < TILE / 256; u++) {
+                const uint64_t e = pos + u * 256 + tid;
+                if (e < n_src) {
+                    uint64_t key, id;
+                    if (MERGE) {
+                        uint32_t s = (uint32_t)(e / k), j = (uint32_t)(e % k);
+                        bool valid = j < shard_counts[(size_t)s * stride32 + b];  // shard s starts stride32 counts further
+                        size_t src = (size_t)s * stride64 + (size_t)b * k + j;        // ... and stride64 ids / keys further
+                        key = valid ? cand_keys[src] : ~0ull;
+                        id = valid ? cand_ids64[src] : ~0ull;
+                    } else {
+                        key = cand_keys[c0 + e];
+                        id = id_base + cand_ids32[c0 + e];
+                    }
+                    if (!filt || key < tk || (key == tk && id < ti)) {
+                        const uint32_t slot = atomicAdd(&s_fill, 1u);
+                        sk[slot] = key; si[slot] = id;
+                    }
+                }
             }
-            sk[have + i] = key; si[have + i] = id;
+            pos = n_src - pos < TILE ? n_src : pos + TILE;
+            __syncthreads();
         }
-        uint32_t total = have + m, np2 = next_pow2(total);
+        if (filt && s_fill == have) continue;  // nothing new beat the k-th best: rk / ri stand
+        uint32_t total = s_fill, np2 = next_pow2(total);
+        __syncthreads();
         for (uint32_t i = total + tid; i < np2; i += 256) { sk[i] = ~0ull; si[i] = ~0ull; }
         block_bitonic_sort<uint64_t>(sk, si, np2);
         if (MERGE) {  // invalid slots sorted last: drop them from the count
@@ -1403,7 +1427,6 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
             __syncthreads();
         }
         have = block_unique_topk(sk, si, total, k, rk, ri, scan);
-        pos += m;
     }
     for (uint32_t i = tid; i < k; i += 256) {
         out_ids[(size_t)b * k + i] = i < have ? ri[i] : ~0ull;
