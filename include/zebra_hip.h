@@ -239,6 +239,29 @@ ZH_API int zh_merge_topk_packed_device(int device, uint32_t n_shards, size_t b, 
 ZH_API int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,
                             uint64_t b0, size_t b, uint32_t dim, int kind, void *stream);
 
+/* ---- the reference's on-disk VALUES ------------------------------------------------
+ * The reference stores an index in two fjall partitions (lsh.rs:62-120): "<uuid>-embeddings" maps a vector's 16 uuid
+ * bytes to bincode(legacy) Embedding<N> -- exactly the N little-endian f32 that zh_index_append takes, no codec
+ * needed (lsh.rs:91-97, lib.rs:15-18) -- and "<uuid>-trees" maps a tree's uuid to bincode(legacy) Node<N>
+ * (lsh.rs:46-60,99-105).  The host shim, which links fjall, iterates the partitions; these functions turn the tree
+ * values into the flat forest of zh_index_set_forest and back, so an existing database can be served by the GPU
+ * path and a GPU-built forest can be saved in the reference's format.  Host code only (no GPU needed).  fjall's own
+ * file layout is not read.  Byte layout: zebra_amd/csrc/zh_refformat.cpp (FORMAT UNVERIFIED against the crates).
+ *
+ * decode: `uuids` holds the keys of the n_vectors stored rows in row order (row i of zh_index_append <-> uuids[16 i]);
+ * leaf ids that are not among them (vectors removed by the reference, whose trees keep them, lsh.rs:473-503) are
+ * dropped and counted in out_unknown_ids (may be NULL). */
+typedef struct zh_ref_forest zh_ref_forest;
+ZH_API int zh_ref_forest_decode(uint32_t dim, size_t n_trees, const uint8_t *const *values, const size_t *lens,
+                                size_t n_vectors, const uint8_t *uuids, zh_ref_forest **out, uint64_t *out_unknown_ids);
+/* borrowed pointers, valid until zh_ref_forest_free */
+ZH_API int zh_ref_forest_view(const zh_ref_forest *forest, zh_forest_view *out);
+ZH_API void zh_ref_forest_free(zh_ref_forest *forest);
+/* one tree of a flat forest as bincode(legacy) Node<N>; uuids = 16 bytes per row.  out == NULL: only *out_len (the
+ * size needed) is written. */
+ZH_API int zh_ref_tree_encode(const zh_forest_view *forest, uint32_t dim, uint32_t tree, const uint8_t *uuids,
+                              uint64_t n_rows, uint8_t *out, size_t cap, size_t *out_len);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 ZH_API int zh_set_profiling(zh_index *idx, int level); /* 0 off, 1 per-stage hipEvent timing, 2 + unique-row count */
 ZH_API int zh_stats(zh_index *idx, zh_stats_t *out);

@@ -74,6 +74,13 @@ pub mod ffi {
         pub fn zh_merge_topk_device(device: c_int, n_shards: u32, b: usize, k: usize, d_ids: *const u64, d_keys: *const u64,
                                     d_counts: *const u32, d_out_ids: *mut u64, d_out_keys: *mut u64, d_out_counts: *mut u32,
                                     stream: *mut c_void) -> c_int;
+        // the reference's on-disk tree values <-> flat forest; host code, no GPU
+        pub fn zh_ref_forest_decode(dim: u32, n_trees: usize, values: *const *const u8, lens: *const usize, n_vectors: usize,
+                                    uuids: *const u8, out: *mut *mut c_void, out_unknown_ids: *mut u64) -> c_int;
+        pub fn zh_ref_forest_view(forest: *const c_void, out: *mut c_void /* zh_forest_view */) -> c_int;
+        pub fn zh_ref_forest_free(forest: *mut c_void);
+        pub fn zh_ref_tree_encode(forest: *const c_void /* zh_forest_view */, dim: u32, tree: u32, uuids: *const u8, n_rows: u64,
+                                  out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
         pub fn zh_last_error() -> *const c_char;
     }
 }

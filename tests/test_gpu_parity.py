@@ -638,3 +638,27 @@ def test_visit_log_overflow_falls_back_to_the_emit_walk(za, env):
     e.update(env)
     out = subprocess.run([sys.executable, "-c", _LOG_FALLBACK_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_reference_format_round_trip_through_the_gpu_index(za):
+    """a forest built on the GPU, written out as the reference's tree values (bincode-legacy Node<N>,
+    lsh.rs:99-105), read back against the vectors in ANOTHER row order (fjall iterates by key), serves the same answers."""
+    from zebra_amd import refformat as rf
+    n, d, M, T, k = 5000, 96, 24, 5, 10
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(16, d, n)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    uu = np.random.default_rng(11).integers(0, 256, (n, 16), dtype=np.uint8)
+    blobs = rf.encode_trees(ix.get_forest(), d, uu)
+    vals = rf.encode_embeddings(X)
+    order = np.lexsort(uu.T[::-1])                       # the key order a partition scan returns
+    ix2 = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix2.append(rf.decode_embeddings([vals[i] for i in order], d))
+    forest, unknown = rf.decode_trees(blobs, d, uu[order])
+    assert unknown == 0
+    ix2.set_forest(forest)
+    m = za.L2SquaredDistance()
+    i1, k1, c1 = ix.search_batch(Q, k, m)
+    i2, k2, c2 = ix2.search_batch(Q, k, m)
+    assert (c1 == c2).all() and (k1 == k2).all() and (order[i2.astype(np.int64)] == i1.astype(np.int64)).all()

@@ -1,0 +1,106 @@
+"""the values of the reference's on-disk partitions (lsh.rs:91-105).  Host-only codec, so
+these run without a GPU.  FORMAT UNVERIFIED against the Rust crates (none is available here): the known-answer bytes
+below are assembled by hand from the published bincode-legacy / serde encodings of the reference's types
+(lsh.rs:16-25,46-60; lib.rs:15-18) and pin this build's reading of them."""
+import struct
+import uuid
+
+import numpy as np
+import pytest
+
+from oracle import zebra_oracle as zo
+from zebra_amd import refformat as rf
+
+
+def _uuids(n, seed=7):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, 16), dtype=np.uint8)
+
+
+def _leaf(ids):
+    return struct.pack("<IQ", 1, len(ids)) + b"".join(struct.pack("<Q", 16) + bytes(i) for i in ids)
+
+
+def _inner(w, c, left, right):
+    return struct.pack("<I", 0) + np.asarray(w, "<f4").tobytes() + struct.pack("<f", c) + left + right
+
+
+def test_known_answer_bytes_of_a_two_level_tree():
+    """Inner(plane A, left = Leaf[u0, u2], right = Inner(plane B, left = Leaf[], right = Leaf[u1])) at N = 3."""
+    u = _uuids(3)
+    blob = _inner([1.0, -2.0, 0.5], 0.25, _leaf([u[0], u[2]]), _inner([0.0, 3.0, 4.0], -1.5, _leaf([]), _leaf([u[1]])))
+    assert len(blob) == 2 * (4 + 12 + 4) + 3 * (4 + 8) + 3 * 24
+    f, unknown = rf.decode_trees([blob], 3, u)
+    assert unknown == 0
+    assert f["roots"].tolist() == [0]
+    assert f["plane"].tolist() == [0, -1, 1, -1, -1]                # pre-order: A, leaf, B, leaf, leaf
+    assert f["left"][0] == 1 and f["right"][0] == 2 and f["left"][2] == 3 and f["right"][2] == 4
+    assert (f["planes"] == np.array([[1, -2, 0.5], [0, 3, 4]], np.float32)).all() and f["consts"].tolist() == [0.25, -1.5]
+    assert (f["left"][1], f["right"][1]) == (0, 2) and f["right"][3] == 0 and f["right"][4] == 1
+    assert f["leaf_ids"].tolist() == [0, 2, 1]
+    assert rf.encode_trees(f, 3, u) == [blob]
+
+
+def test_uuid_bytes_are_the_uuid_crates_as_bytes_order():
+    """Uuid::as_bytes (lsh.rs:92,101) is the big-endian field order = Python's UUID.bytes."""
+    ids = [uuid.UUID(int=(i + 1) * 0x0123456789ABCDEF0123456789ABCDEF % (1 << 128)) for i in range(4)]
+    table = [x.bytes for x in ids]
+    blob = _leaf([ids[3].bytes, ids[0].bytes])
+    f, _ = rf.decode_trees([blob], 8, table)
+    assert f["leaf_ids"].tolist() == [3, 0] and f["plane"].tolist() == [-1]
+
+
+def test_embedding_values_are_raw_le_f32():
+    X = zo.synth_rows(5, 12)
+    vals = rf.encode_embeddings(X)
+    assert all(len(v) == 48 for v in vals) and vals[2] == X[2].astype("<f4").tobytes()
+    assert (rf.decode_embeddings(vals, 12) == X).all()
+    with pytest.raises(ValueError):
+        rf.decode_embeddings([b"\0" * 47], 12)
+
+
+@pytest.mark.parametrize("n,d,M,T", [(400, 8, 5, 3), (3000, 64, 40, 4), (64, 384, 5, 15)])
+def test_round_trip_of_oracle_forests(n, d, M, T):
+    X = zo.synth_rows(n, d)
+    f = zo.Forest.build(X, M, T)
+    g = f.arrays()
+    u = _uuids(n)
+    blobs = rf.encode_trees(g, d, u)
+    assert len(blobs) == T
+    n_inner = int((g["plane"] >= 0).sum())
+    assert sum(map(len, blobs)) == n_inner * (4 + 4 * d + 4) + (len(g["plane"]) - n_inner) * 12 + 24 * len(g["leaf_ids"])
+    back, unknown = rf.decode_trees(blobs, d, u)
+    assert unknown == 0
+    assert zo.canonical_forest(back, d) == zo.canonical_forest(g, d)
+    # the same forest with the rows stored in another order (fjall iterates by key, not by insertion)
+    perm = np.random.default_rng(3).permutation(n)
+    back2, _ = rf.decode_trees(blobs, d, u[perm])
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    assert (np.sort(back2["leaf_ids"]) == np.sort(inv[back["leaf_ids"]])).all()
+    f2 = zo.Forest.from_arrays(X[perm], M, back2)
+    Q = zo.synth_queries(5, d, n)
+    for b in range(5):
+        i1, k1 = f.search(Q[b], 7, zo.L2SQ)
+        i2, k2 = f2.search(Q[b], 7, zo.L2SQ)
+        assert (k1 == k2).all() and (perm[i2.astype(np.int64)] == i1.astype(np.int64)).all()
+
+
+def test_removed_vectors_and_malformed_values():
+    u = _uuids(4)
+    blob = _inner([1.0, 1.0], 0.0, _leaf([u[0], u[1]]), _leaf([u[2], u[3]]))
+    f, unknown = rf.decode_trees([blob], 2, u[[0, 3]])      # u1, u2 were removed: the reference's trees keep them
+    assert unknown == 2 and f["leaf_ids"].tolist() == [0, 1] and f["right"].tolist()[1:] == [1, 1]
+    from zebra_amd import ZhError
+    for bad in (blob[:-1], blob + b"\0", struct.pack("<I", 2), blob[:30], struct.pack("<IQ", 1, 1 << 40)):
+        with pytest.raises(ZhError):
+            rf.decode_trees([bad], 2, u)
+    with pytest.raises(ZhError):
+        rf.decode_trees([blob], 2, np.concatenate([u, u[:1]]))   # duplicate key
+    with pytest.raises(ZhError):
+        rf.encode_trees(f, 2, u[:1])                               # a leaf row without a uuid
+    # 70 nested Inner nodes: deeper than any tree the index accepts
+    deep = _leaf([])
+    for _ in range(70):
+        deep = _inner([0.0, 0.0], 0.0, deep, _leaf([]))
+    with pytest.raises(ZhError):
+        rf.decode_trees([deep], 2, u)

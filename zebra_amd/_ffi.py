@@ -85,6 +85,10 @@ SYMBOLS = [
     ("zh_packed_result_words", _sz, [_sz, _sz]),
     ("zh_merge_topk_packed_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zh_synth_queries_device", _i, [_i, _vp, _u64, _u64, _u64, _u64, _sz, _u32, _i, _vp]),
+    ("zh_ref_forest_decode", _i, [_u32, _sz, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zh_ref_forest_view", _i, [_vp, _vp]),
+    ("zh_ref_forest_free", None, [_vp]),
+    ("zh_ref_tree_encode", _i, [_vp, _u32, _u32, _vp, _u64, _vp, _sz, _vp]),
     ("zh_set_profiling", _i, [_vp, _i]),
     ("zh_stats", _i, [_vp, _vp]),
     ("zh_stats_reset", _i, [_vp]),

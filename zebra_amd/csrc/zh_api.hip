@@ -35,6 +35,17 @@ static int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                        \
     } while (0)
 
+// the same thread-local message for the host-only translation units
+int zh_set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
 extern "C" const char *zh_last_error(void) { return g_err.c_str(); }
 extern "C" const char *zh_version(void) { return "zebra-hip 0.1 (gfx950)"; }
 

@@ -6,6 +6,9 @@
 
 #include "../../include/zebra_hip.h"
 
+// sets zh_last_error() for the calling thread and returns `code`
+int zh_set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
 // ---- one leaf visit of the walk (tree_result, lsh.rs:290-348): score `len` rows of a leaf for
 // query `b`, keep the `take` smallest.  row_off / cand_off are the visit's slices of the key
 // scratch and of the candidate pool.
