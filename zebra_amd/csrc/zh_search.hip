@@ -235,10 +235,105 @@ __global__ __launch_bounds__(256) void hash_dense_kernel(const float *__restrict
     }
 }
 
+// The same contraction for GEMM-sized launches (every plane of a small-leaf forest: millions of planes x hundreds of
+// queries): a 128 x 128 tile per block, each of the four waves owns 64 x 64 of it as 2 x 2 MFMA accumulators, so one
+// k-step of four ds_read_b32 feeds four MFMAs (the 64 x 64 kernel: two reads per MFMA) and every plane row crosses
+// L2 once per 128 queries.  Same per-output arithmetic: the k-ascending chain of v_mfma_f32_32x32x2_f32, no split-K.
+#define HB_KT 16
+#define HB_PITCH 129
+template <bool WRITE_DOTS>
+__global__ __launch_bounds__(256) void hash_dense_big_kernel(const float *__restrict__ Q, uint32_t B,
+                                                              const float *__restrict__ W,
+                                                              const float *__restrict__ C, uint32_t P, uint32_t d,
+                                                              uint32_t *__restrict__ bits, uint32_t wpq,
+                                                              float *__restrict__ dots) {
+    __shared__ float Qs[HB_KT][HB_PITCH];
+    __shared__ float Ws[HB_KT][HB_PITCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t wr = wv >> 1, wc = wv & 1;
+    const uint32_t p0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    // K-tile: 128 rows x 16 k of Q and of W = 512 float4 each; thread t owns float4 number t and t + 256:
+    // row = i >> 2, k offset = 4 * (i & 3)   (requires d % 4 == 0: the launcher falls back to the small kernel otherwise)
+    auto fetch = [&](uint32_t k0, float4 *qv, float4 *wvv) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const uint32_t i = tid + it * 256, row = i >> 2, k = k0 + (i & 3) * 4;
+            qv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wvv[it] = qv[it];
+            if (k < d) {
+                if (b0 + row < B) qv[it] = *reinterpret_cast<const float4 *>(Q + (size_t)(b0 + row) * d + k);
+                if (p0 + row < P) wvv[it] = *reinterpret_cast<const float4 *>(W + (size_t)(p0 + row) * d + k);
+            }
+        }
+    };
+    float4 qn[2], wn[2];
+    fetch(0, qn, wn);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    for (uint32_t k0 = 0; k0 < d; k0 += HB_KT) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const uint32_t i = tid + it * 256, row = i >> 2, c4 = (i & 3) * 4;
+            Qs[c4 + 0][row] = qn[it].x; Qs[c4 + 1][row] = qn[it].y; Qs[c4 + 2][row] = qn[it].z; Qs[c4 + 3][row] = qn[it].w;
+            Ws[c4 + 0][row] = wn[it].x; Ws[c4 + 1][row] = wn[it].y; Ws[c4 + 2][row] = wn[it].z; Ws[c4 + 3][row] = wn[it].w;
+        }
+        __syncthreads();
+        if (k0 + HB_KT < d) fetch(k0 + HB_KT, qn, wn);  // next tile's loads fly during this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < HB_KT; kk += 2) {
+            const float a0 = Qs[kk + h][wr * 64 + r], a1 = Qs[kk + h][wr * 64 + 32 + r];
+            const float c0 = Ws[kk + h][wc * 64 + r], c1 = Ws[kk + h][wc * 64 + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t pbase = p0 + wc * 64 + j * 32, plane = pbase + (lane & 31);
+            const double cval = plane < P ? (double)C[plane] : 0.0;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const uint32_t qrow_lo = b0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2);
+                const uint32_t qrow = qrow_lo + 4 * (lane >> 5);
+                const float sdot = acc[i][j][reg];
+                const bool above = ((double)sdot + cval) >= 0.0;  // lsh.rs:40-42, NaN -> false
+                const unsigned long long m = __ballot(above);
+                const uint32_t word = pbase >> 5;
+                if (pbase < P) {  // a word of planes beyond P does not exist in the bit rows
+                    if (lane == 0 && qrow_lo < B) bits[(size_t)qrow_lo * wpq + word] = (uint32_t)m;
+                    if (lane == 32 && qrow_lo + 4 < B) bits[(size_t)(qrow_lo + 4) * wpq + word] = (uint32_t)(m >> 32);
+                }
+                if (WRITE_DOTS && qrow < B && plane < P) dots[(size_t)qrow * P + plane] = sdot;
+            }
+        }
+}
+
 hipError_t zh_launch_hash_dense(const float *dQ, uint32_t B, const float *dPlanes, const float *dConsts,
                                 uint32_t P, uint32_t d, uint32_t *dBits, uint32_t words_per_q, float *dDots,
                                 hipStream_t s) {
     if (B == 0 || P == 0) return hipSuccess;
+    static const int variant = [] { const char *e = getenv("ZH_HASH_VARIANT"); return e ? atoi(e) : 0; }();  // 1: small tiles only
+    if ((d & 3u) == 0 && B >= 128 && (uint64_t)P * B >= (1ull << 22) && variant != 1) {
+        dim3 grid((P + 127) / 128, (B + 127) / 128);
+        if (dDots)
+            hipLaunchKernelGGL(hash_dense_big_kernel<true>, grid, dim3(256), 0, s, dQ, B, dPlanes, dConsts, P, d, dBits,
+                               words_per_q, dDots);
+        else
+            hipLaunchKernelGGL(hash_dense_big_kernel<false>, grid, dim3(256), 0, s, dQ, B, dPlanes, dConsts, P, d, dBits,
+                               words_per_q, dDots);
+        return hipGetLastError();
+    }
     dim3 grid((P + 63) / 64, (B + 63) / 64);
     if (dDots)
         hipLaunchKernelGGL(hash_dense_kernel<true>, grid, dim3(256), 0, s, dQ, B, dPlanes, dConsts, P, d, dBits,
