@@ -1,5 +1,9 @@
 """Seeded fuzz: random small configurations, HIP path vs oracle, bit for bit (forest, ids, keys, counts) --
-odd dimensions, leaves of 1, single trees, k larger than the index, every metric, incremental adds and removes."""
+odd dimensions, leaves of 1, single trees, k larger than the index, every metric, incremental adds and removes,
+signs from the dense MFMA kernel or from the walk's on-demand chains (random number of dense levels).
+ZH_FUZZ_SEEDS=first:count runs a soak over other seeds."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,11 +21,14 @@ def _metrics(za, rng):
             (za.HammingDistance(), zo.HAMMING, 0), (za.MinkowskiDistance(p), zo.MINKOWSKI, p), (za.PNormDistance(p), zo.PNORM, p)]
 
 
-@pytest.mark.parametrize("seed", range(24))
+_first, _count = (int(x) for x in os.environ.get("ZH_FUZZ_SEEDS", "0:24").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_first, _first + _count))
 def test_fuzz_config(seed):
     import zebra_amd as za
     rng = np.random.default_rng(1000 + seed)
-    d = int(rng.choice([1, 2, 5, 17, 32, 63, 64, 100, 128, 200, 384, 500, 768]))
+    d = int(rng.choice([1, 2, 5, 17, 32, 63, 64, 100, 128, 200, 384, 500, 768, 1000, 1540]))
     n = int(rng.integers(1, 2500))
     M = int(rng.choice([1, 2, 5, 9, 33, 100, 400, 5000]))
     T = int(rng.integers(1, 7))
@@ -34,6 +41,7 @@ def test_fuzz_config(seed):
     Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
+    ix.set_dense_levels(int(rng.choice([-1, -1, 0, 1, 3, 64])))
     f = zo.Forest.build(X, M, T, seed=seed)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
     mets = _metrics(za, rng)

@@ -987,7 +987,7 @@ static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     const double t_chain = std::max(1.4e-6 * 5.0 * vpp, pairs / 4.0 * 2.3 * vpp * 0.7e-6 * (d / 384.0) / 1024.0);
     const double t_dense = (double)ix->n_planes * per_plane / 9e13;
     const double bits_bytes = (double)ix->n_planes * (double)B / 8.0;
-    if (t_dense < t_chain && bits_bytes < 8e9) return ix->n_planes;
+    if (t_dense < t_chain && bits_bytes < 2e9) return ix->n_planes;  // (every context in flight holds its own sign bits)
     return top;
 }
 
