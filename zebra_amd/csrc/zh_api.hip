@@ -1133,7 +1133,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, u
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
     HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(zh_launch_select(c->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, c->wKeys.as<uint64_t>(),
-                            c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), s));
+                            c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), ix->max_leaf_len, s));
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(zh_launch_final(c->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, c->wCandKeys.as<uint64_t>(),
                            c->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));

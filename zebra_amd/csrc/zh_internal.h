@@ -138,8 +138,10 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
                            uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);
+// max_leaf_len: the longest leaf of the forest (picks the LDS footprint of the select blocks)
 hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
-                            const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s);
+                            const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, uint32_t max_leaf_len,
+                            hipStream_t s);
 hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,
                            const uint32_t *dCandIds, uint64_t id_base, uint64_t *dOutIds, uint64_t *dOutKeys,
                            uint32_t *dOutCounts, hipStream_t s);

@@ -1192,11 +1192,11 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t x) {
 
 __device__ __forceinline__ void select_slow(const ZhVisit &v, const uint32_t *__restrict__ leaf_ids,
                                             const uint64_t *__restrict__ keys, uint64_t *__restrict__ cand_keys,
-                                            uint32_t *__restrict__ cand_ids, uint64_t *sk, uint32_t *si) {
+                                            uint32_t *__restrict__ cand_ids, uint64_t *sk, uint32_t *si, uint32_t cap) {
     const uint32_t tid = threadIdx.x;
     uint32_t have = 0, pos = 0;
     while (pos < v.len) {
-        uint32_t m = ZH_SORT_N - have;
+        uint32_t m = cap - have;
         if (m > v.len - pos) m = v.len - pos;
         for (uint32_t i = tid; i < m; i += 256) {
             sk[have + i] = keys[v.row_off + pos + i];
@@ -1326,13 +1326,16 @@ __device__ __forceinline__ void select_fast(const ZhVisit &v, const uint32_t *__
 // thread on the spot, everything else queues for the block's partition code.  (One block per visit would also run into
 // the 2^32-threads-per-launch limit at 2^24 visits.)
 #define SEL_GROUP_LEN 16
+// CAP = entries of the LDS key buffer: 4096 in general; 1024 when no leaf of the forest is longer (16 KB instead of
+// 48 KB of LDS per block: 8 blocks per CU instead of 3)
+template <int CAP>
 __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
                                                       const uint32_t *__restrict__ leaf_ids,
                                                       const uint64_t *__restrict__ keys,
                                                       uint64_t *__restrict__ cand_keys,
                                                       uint32_t *__restrict__ cand_ids) {
-    __shared__ uint64_t sk[ZH_SORT_N];
-    __shared__ __attribute__((aligned(16))) uint32_t si[ZH_SORT_N];  // slow path ids; fast path: small-sort buffers + histogram
+    __shared__ uint64_t sk[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t si[CAP < 2048 ? 2048 : CAP];  // slow path ids; fast path: small-sort buffers + histogram (1808 words)
     __shared__ uint32_t s_u32[8];
     __shared__ uint32_t s_list[256], s_small[256], s_nlist, s_nsmall;
     const uint32_t tid = threadIdx.x;
@@ -1384,25 +1387,30 @@ __global__ __launch_bounds__(256) void select_kernel(const ZhVisit *__restrict__
             continue;
         }
         bool need_slow = false;
-        if (v.len <= ZH_SORT_N) select_fast<true>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
+        if (v.len <= CAP) select_fast<true>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
         else select_fast<false>(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, s_u32, need_slow);
         if (need_slow) {  // a large group of equal keys straddles the cut: order it by id the slow way
             __syncthreads();
-            select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si);
+            select_slow(v, leaf_ids, keys, cand_keys, cand_ids, sk, si, CAP);
         }
         __syncthreads();  // the LDS buffers are reused by the next visit
     }
 }
 
 hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
-                            const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, hipStream_t s) {
+                            const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, uint32_t max_leaf_len,
+                            hipStream_t s) {
     if (!n_visits) return hipSuccess;
     if (n_visits > 0x7FFFFFFFull) return hipErrorInvalidValue;
     uint64_t chunk = (n_visits + 16383) / 16384;  // >= 16k blocks before a block takes a second visit
     if (chunk > 256) chunk = 256;
     const uint64_t blocks = (n_visits + chunk - 1) / chunk;  // <= 2^23: 2^31 threads
-    hipLaunchKernelGGL(select_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, dLeafIds,
-                       dKeys, dCandKeys, dCandIds);
+    if (max_leaf_len <= 1024)
+        hipLaunchKernelGGL(select_kernel<1024>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
+                           dLeafIds, dKeys, dCandKeys, dCandIds);
+    else
+        hipLaunchKernelGGL(select_kernel<ZH_SORT_N>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
+                           dLeafIds, dKeys, dCandKeys, dCandIds);
     return hipGetLastError();
 }
 
