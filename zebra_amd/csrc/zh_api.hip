@@ -985,7 +985,8 @@ static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     if (vpp <= 0) vpp = (size_t)ix->opt.max_node_size < 2 * k + 2 ? 1000.0 : 2.0;
     const double pairs = (double)B * ix->n_trees;
     const double t_chain = std::max(1.4e-6 * 5.0 * vpp, pairs / 4.0 * 2.3 * vpp * 0.7e-6 * (d / 384.0) / 1024.0);
-    const double t_dense = (double)ix->n_planes * per_plane / 9e13;
+    // the dense kernel: MFMA-bound for real batches, a plane-streaming GEMV (HBM-bound) for a handful of queries
+    const double t_dense = std::max((double)ix->n_planes * per_plane / 9e13, (double)ix->n_planes * d * 4.0 / 5e12);
     const double bits_bytes = (double)ix->n_planes * (double)B / 8.0;
     if (t_dense < t_chain && bits_bytes < 2e9) return ix->n_planes;  // (every context in flight holds its own sign bits)
     return top;
