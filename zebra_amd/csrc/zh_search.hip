@@ -489,7 +489,13 @@ __device__ __forceinline__ int4 sel4(bool c, const int4 &a, const int4 &b) {
 // record waits on the LDS stack), so a step's only exposed miss is the plane row of an on-demand hash.
 // E = elements per lane per pass of an on-demand chain; NP = passes whose query block stays in registers for the whole
 // walk (d <= NP * 16 * E), 0 = the query block is re-read with every plane (very long vectors)
-template <bool EMIT, int E, int NP>
+// ALLDENSE: every sign is precomputed -- one pair per wave, no chains; the DFS state is wave-uniform and is kept in
+// scalar registers (readfirstlane after every load), so the loop runs on scalar branches instead of exec masks
+__device__ __forceinline__ int4 uni4(int4 v) {
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
+template <bool EMIT, int E, int NP, bool ALLDENSE>
 __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__restrict__ Q, uint32_t B, uint32_t d,
                                                    int32_t n, const uint32_t *__restrict__ bits, uint32_t wpq,
                                                    uint32_t P_dense, ZhPairCounts *__restrict__ counts,
@@ -501,7 +507,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                                                    const uint32_t *__restrict__ groupBase,
                                                    const uint64_t *__restrict__ groupRowBase,
                                                    ZhGroup *__restrict__ groups, uint64_t *__restrict__ groupRowOff,
-                                                   uint32_t ppw, ZhWalkLog wlog) {
+                                                   ZhWalkLog wlog) {
+    constexpr uint32_t ppw = ALLDENSE ? 1 : 4;
+#define ZH_U(x) (ALLDENSE ? __builtin_amdgcn_readfirstlane(x) : (x))
+#define ZH_U4(x) (ALLDENSE ? uni4(x) : (x))
     __shared__ int4 st_rec[4][WALK_STACK];
     __shared__ int2 st_nn[4][WALK_STACK];  // {node, n}
     // a row's latest visits {node, leaf offset, leaf length, take} and their row / candidate offsets, written out
@@ -538,8 +547,8 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
             if (p == 0 || (uint32_t)p * 16u * E < d) load_row_block<E>(q, (uint32_t)p * 16u * E, d, l16, vec4, full, qreg[p]);
     }
     int sp = 0;
-    int32_t cur = active ? (int32_t)f.roots[t] : 0, ncur = n;
-    int4 rec = active ? f.node_pack[cur] : make_int4(-1, 0, 0, 0);
+    int32_t cur = ZH_U(active ? (int32_t)f.roots[t] : 0), ncur = n;
+    int4 rec = ZH_U4(active ? f.node_pack[cur] : make_int4(-1, 0, 0, 0));
     uint32_t nv = 0;
     uint64_t nrows = 0, ntakes = 0;
     uint64_t vb = 0, rb = 0, cb = 0;
@@ -616,9 +625,9 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         if (active && !need) {
             for (;;) {
                 if (rec.x >= 0) {
-                    if ((uint32_t)rec.x >= P_dense) { need = true; break; }
-                    const int4 rl = f.node_pack[rec.y], rr = f.node_pack[rec.z];
-                    const bool above = (bits[(size_t)b * wpq + ((uint32_t)rec.x >> 5)] >> (rec.x & 31)) & 1u;
+                    if (!ALLDENSE && (uint32_t)rec.x >= P_dense) { need = true; break; }
+                    const int4 rl = ZH_U4(f.node_pack[rec.y]), rr = ZH_U4(f.node_pack[rec.z]);
+                    const bool above = (ZH_U((int)bits[(size_t)b * wpq + ((uint32_t)rec.x >> 5)]) >> (rec.x & 31)) & 1;
                     ZH_DESCEND(above, rl, rr)
                     continue;
                 }
@@ -637,10 +646,10 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 bool down = false;
                 while (sp > 0) {
                     sp--;
-                    if (sp < WALK_STACK && ret < st_nn[row][sp].y) {  // lsh.rs:341-343: k < n -> the backup's count alone
-                        cur = st_nn[row][sp].x;
-                        ncur = st_nn[row][sp].y - ret;
-                        rec = st_rec[row][sp];
+                    if (sp < WALK_STACK && ret < ZH_U(st_nn[row][sp].y)) {  // lsh.rs:341-343: k < n -> the backup's count alone
+                        cur = ZH_U(st_nn[row][sp].x);
+                        ncur = ZH_U(st_nn[row][sp].y) - ret;
+                        rec = ZH_U4(st_rec[row][sp]);
                         down = true;
                         break;
                     }
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 if (!down) { active = false; break; }
             }
         }
-        if (!__any(need)) break;  // no row waits for a sign: every row has finished
+        if (ALLDENSE || !__any(need)) break;  // no row waits for a sign: every row has finished
         // ---- phase B: the rows that need a sign hash their plane, four chains per wave ----
         int4 rl = make_int4(-1, 0, 0, 0), rr = rl;
         if (need) { rl = f.node_pack[rec.y]; rr = f.node_pack[rec.z]; }
@@ -677,6 +686,8 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         }
     }
 #undef ZH_DESCEND
+#undef ZH_U
+#undef ZH_U4
     if (nbuf) flush();
     if (!EMIT && pair < n_pairs && lr == 0) {
         ZhPairCounts c;
@@ -694,14 +705,15 @@ static void launch_walk(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, 
     const uint64_t pairs = (uint64_t)B * f.n_trees;
     const uint32_t ppw = P_dense >= f.n_planes ? 1u : 4u;
     const dim3 grid((uint32_t)((pairs + ppw - 1) / ppw));
-#define ZH_WALK(E_, NP_)                                                                                                    \
-    hipLaunchKernelGGL((walk_kernel<EMIT, E_, NP_>), grid, dim3(64), 0, s, f, dQ, B, d, n, dBits, wpq, P_dense, dCounts,     \
+#define ZH_WALK_(E_, NP_, AD_)                                                                                              \
+    hipLaunchKernelGGL((walk_kernel<EMIT, E_, NP_, AD_>), grid, dim3(64), 0, s, f, dQ, B, d, n, dBits, wpq, P_dense, dCounts, \
                        dInline, dRowBase, dCandBase, dVisitBase, dVisits, dLeafCount, dLeafFill, dGroupBase, dGroupRowBase, \
-                       dGroups, dGroupRowOff, ppw, log)
+                       dGroups, dGroupRowOff, log)
+#define ZH_WALK(E_, NP_) ZH_WALK_(E_, NP_, false)
     // registers: the query block kept in registers (NP > 0) costs occupancy -- worth it while every wave of the launch
     // is resident anyway (deep walks of few pairs); with more waves than that, or no chains at all, the lean variants
     const uint64_t waves = grid.x;
-    if (P_dense >= f.n_planes) ZH_WALK(4, 0);
+    if (P_dense >= f.n_planes) ZH_WALK_(4, 0, true);
     else if (waves > 2048) {
         if (d <= 64) ZH_WALK(4, 0);
         else if (d <= 128) ZH_WALK(8, 0);
@@ -714,6 +726,7 @@ static void launch_walk(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, 
     else if (d <= 32 * WALK_E) ZH_WALK(WALK_E, 2);
     else ZH_WALK(WALK_E, 0);
 #undef ZH_WALK
+#undef ZH_WALK_
 }
 
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
