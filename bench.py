@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zh_search_batch_device per step")
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight when pipelined")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined (2: one sweeping, one in its light phases; measured best at every shard size)")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority torch stream")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="debug: all ranks on cuda:0, exchange over gloo through host copies (RCCL needs one device per rank)")
