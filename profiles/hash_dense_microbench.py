@@ -7,14 +7,14 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zebra_amd as za  # noqa: E402
-from oracle import zebra_oracle as zo  # noqa: E402  (synthetic queries only)
+import numpy as np  # noqa: E402
 
 d = 768
 ix = za.LSHIndex(d, za.LSHIndexOptions(16, 1))
 ix.append_synthetic(200000)
 ix.build()
 P = ix.get_forest()["consts"].size
-Q = zo.synth_queries(2048, d, 200000)
+Q = np.random.default_rng(1).standard_normal((2048, d)).astype(np.float32)
 for _ in range(3):
     ix.hash_signs(Q)
 print("planes", P, "GFLOP per call", 2 * 2048 * P * d / 1e9)

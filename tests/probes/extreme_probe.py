@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import zebra_amd as za  # noqa: E402
 from oracle import zebra_oracle as zo  # noqa: E402
 
