@@ -1015,7 +1015,7 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
-    if (pairs > (1ull << 26)) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees > 2^26"); }
+    if (pairs >= (1ull << 26)) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees >= 2^26"); }
     c->P_dense = choose_dense_planes(ix, B, k);
     c->wpq = (c->P_dense + 63) / 64 * 2;
     const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
