@@ -104,3 +104,57 @@ def test_removed_vectors_and_malformed_values():
         deep = _inner([0.0, 0.0], 0.0, deep, _leaf([]))
     with pytest.raises(ZhError):
         rf.decode_trees([deep], 2, u)
+
+
+# ---- random trees (hypothesis): a reference-side encoder written here from the format description, independent of
+# ---- zh_ref_tree_encode, against the decoder; and decoder(encoder(x)) == x for arbitrary shapes
+from hypothesis import given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+
+def _random_tree(rng, d, n_rows, depth):
+    """nested ('L', ids) / ('I', w, c, left, right) with random shape; ids drawn without replacement per tree"""
+    pool = list(rng.permutation(n_rows))
+
+    def rec(level):
+        if level >= depth or rng.random() < 0.3 or not pool:
+            k = int(rng.integers(0, min(4, len(pool)) + 1))
+            return ("L", [int(pool.pop()) for _ in range(k)])
+        return ("I", rng.standard_normal(d).astype(np.float32), np.float32(rng.standard_normal()), rec(level + 1), rec(level + 1))
+    return rec(0)
+
+
+def _encode_py(t, u):
+    if t[0] == "L":
+        return _leaf([u[i] for i in t[1]])
+    return _inner(t[1], float(t[2]), _encode_py(t[3], u), _encode_py(t[4], u))
+
+
+def _leaves_py(t):
+    return [t[1]] if t[0] == "L" else _leaves_py(t[3]) + _leaves_py(t[4])
+
+
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), d=st.sampled_from([1, 3, 8, 33]), T=st.integers(1, 4), depth=st.integers(0, 9))
+def test_random_trees_decode_and_reencode(seed, d, T, depth):
+    rng = np.random.default_rng(seed)
+    n = 64
+    u = _uuids(n, seed=seed % 1000)
+    trees = [_random_tree(rng, d, n, depth) for _ in range(T)]
+    blobs = [_encode_py(t, u) for t in trees]
+    f, unknown = rf.decode_trees(blobs, d, u)
+    assert unknown == 0 and len(f["roots"]) == T
+    # leaves in pre-order carry the same ids in the same order
+    got = []
+    for t in range(T):
+        stack, out = [int(f["roots"][t])], []
+        while stack:
+            i = stack.pop()
+            if f["plane"][i] < 0:
+                out.append(f["leaf_ids"][f["left"][i]: f["left"][i] + f["right"][i]].tolist())
+            else:
+                stack.append(int(f["right"][i]))
+                stack.append(int(f["left"][i]))
+        got.append(out)
+    assert got == [_leaves_py(t) for t in trees]
+    assert rf.encode_trees(f, d, u) == blobs
