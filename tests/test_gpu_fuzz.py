@@ -68,3 +68,37 @@ def test_fuzz_config(seed):
     assert (counts == oc).all()
     for b in range(B):
         assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all()
+
+
+_mfirst, _mcount = (int(x) for x in os.environ.get("ZH_FUZZ_MEDIUM_SEEDS", "0:4").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_mfirst, _mfirst + _mcount))
+def test_fuzz_medium_wandering_walks(seed):
+    """Larger indices with small leaves: hundreds to thousands of leaf visits per (query, tree) pair, so the visit log
+    runs through many chunks and buffer flushes, the select kernel packs many tiny visits per block and the final
+    kernel streams with its threshold filter; random dense levels switch between on-demand chains and dense signs."""
+    import zebra_amd as za
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([8, 24, 64, 100, 384]))
+    n = int(rng.integers(20_000, 120_000))
+    M = int(rng.choice([2, 3, 5, 8, 17]))
+    T = int(rng.integers(1, 6))
+    k = int(rng.choice([1, 5, 10, 40, 200]))
+    B = int(rng.integers(1, 40))
+    kind = int(rng.choice([0, 1, 2]))
+    X = zo.synth_rows(n, d, seed=seed, kind=kind)
+    Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
+    ix.add(X)
+    f = zo.Forest.from_arrays(X, M, ix.get_forest())
+    for dense in (-1, int(rng.choice([0, 2, 5]))):
+        ix.set_dense_levels(dense)
+        m, om, omode = [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
+                        (za.ManhattanDistance(), zo.MANHATTAN, 0)][int(rng.integers(0, 3))]
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), (d, n, M, T, k, B, dense)
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), (d, n, M, T, k, B, dense, b)
