@@ -88,3 +88,11 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in open(os.path.join(dp, f), errors="replace").read().replace("the oracle", "").replace("oracle/zebra_oracle.c", "").replace("oracle zo_", ""), f
     for f in os.listdir(os.path.join(ROOT, "include")):
         assert "zebra_oracle" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side (Rust) binding: its extern "C" blocks name every function of the header"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = set(re.findall(r"pub fn (zh_\w+)", text))
+    assert sorted(set(declared_symbols()) - bound) == []
+    assert sorted(bound - set(declared_symbols())) == []
