@@ -68,10 +68,14 @@ def parse():
     ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zh_search_batch_device per step")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined (2: one sweeping, one in its light phases; measured best at every shard size)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight when pipelined; default 2 (one sweeping, one in its light phases)")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority torch stream")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="debug: all ranks on cuda:0, exchange over gloo through host copies (RCCL needs one device per rank)")
+    ap.add_argument("--debug-exchange-one-rank", action="store_true",
+                    help="debug: on ONE GPU, run the N > 1 exchange step (RCCL all-gather of the packed top-k + merge kernel) "
+                         "with a world of one rank inside the pipelined loop")
     ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
     return ap.parse_args()
 
@@ -156,9 +160,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    EX = world > 1 or args.debug_exchange_one_rank  # the exchange step (all-gather + merge) is part of a batch
+    if EX:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            for key, val in (("MASTER_PORT", "29642"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(key, val)
         if args.debug_single_device:
             dist.init_process_group("gloo")
         else:
@@ -204,7 +212,7 @@ def main():
     def make_exchange():
         ex = dict(packed=torch.empty(W, dtype=torch.int64, device=dev))
         ex["ids"], ex["keys"], ex["counts"] = sharding.packed_views(torch, ex["packed"], B, k)
-        if S > 1:
+        if EX:
             ex.update(g_packed=torch.empty((S, W), dtype=torch.int64, device=dev), m_ids=torch.empty((B, k), dtype=torch.int64, device=dev),
                       m_keys=torch.empty((B, k), dtype=torch.int64, device=dev), m_counts=torch.empty(B, dtype=torch.int32, device=dev))
         return ex
@@ -227,11 +235,11 @@ def main():
 
     def step(q):
         ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
-        if S > 1:
+        if EX:
             exchange(ex0, stream)
 
     def barrier():
-        if S > 1:
+        if EX:
             dist.barrier()
 
     # several batches in flight: slot = step mod NS, each slot has its own context, stream and result buffers
@@ -245,9 +253,11 @@ def main():
             _hs = torch.cuda.Stream(device=dev, priority=0)
             heavy = _hs.cuda_stream
         slots = []
-        NS = max(2, args.in_flight)
+        NS = max(2, args.in_flight) if args.in_flight else 2
         for _ in range(NS):
             sl = dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1))
+            if EX:  # the exchange of a slot's batch runs on its own stream: the slot's NEXT batch must not queue behind it
+                sl.update(xstream=torch.cuda.Stream(device=dev), ev_final=torch.cuda.Event(), ev_xdone=torch.cuda.Event(), xused=False)
             sl.update(make_exchange())
             slots.append(sl)
 
@@ -257,10 +267,16 @@ def main():
 
         def p_finish(i):
             sl = slots[i % NS]
+            if EX and sl["xused"]:  # the packed result buffer is free again once the slot's previous exchange has read it
+                sl["stream"].wait_event(sl["ev_xdone"])  # (long done: that batch finished NS batches ago)
             sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
-            if S > 1:
-                with torch.cuda.stream(sl["stream"]):
-                    exchange(sl, sl["stream"].cuda_stream)
+            if EX:
+                sl["ev_final"].record(sl["stream"])
+                with torch.cuda.stream(sl["xstream"]):
+                    sl["xstream"].wait_event(sl["ev_final"])
+                    exchange(sl, sl["xstream"].cuda_stream)
+                    sl["ev_xdone"].record(sl["xstream"])
+                sl["xused"] = True
 
         def run(first, n):
             # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long
@@ -272,6 +288,8 @@ def main():
             for sl in slots:
                 sl["ctx"].wait()
                 sl["stream"].synchronize()
+                if EX:
+                    sl["xstream"].synchronize()
     else:
         def run(first, n):
             for i in range(first, first + n):
@@ -297,7 +315,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if S > 1:
+    if EX:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_single_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -353,7 +371,7 @@ def main():
         def search_ids(m):
             ix.search_batch_device(queries[-1].data_ptr(), B, k, m, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
             out = ids.clone()
-            if S > 1:
+            if EX:
                 exchange(ex0, stream)
                 torch.cuda.synchronize()
                 out = ex0["m_ids"].clone()
@@ -411,7 +429,7 @@ def main():
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": S, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
-            "pipelined_batches_in_flight": max(2, args.in_flight) if pipelined else 1,
+            "pipelined_batches_in_flight": (max(2, args.in_flight) if args.in_flight else 2) if pipelined else 1,
             "config": {"workload": f"{name}: {wl['desc']}", "rows_total": n_total, "rows_per_gpu": rows_local,
                        "dim": d, "metric": wl["metric"] + ("(parity key)" if wl["metric"] == "cosine" else ""),
                        "top_k": k, "batch": B, "max_node_size": M_shard, "num_trees": T,
@@ -427,10 +445,17 @@ def main():
             "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
             "setup_s": {"fill": t_fill, "build": t_build},
         }
-        print(json.dumps(out))
-    if S > 1:
+    # RCCL writes a version banner through C stdio: every rank flushes it before the last barrier, so that rank 0's JSON
+    # line is the LAST line of the job's stdout
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if EX:
         dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def _planted_row(seed_q, b, n_rows):

@@ -1039,9 +1039,8 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
         if ((rc = c->wLogPool.ensure(std::max<size_t>(first, 1) * ZH_LOG_CHUNK * sizeof(uint2)))) return rc;
         c->log_chunks = std::max<size_t>(first, 1);
     }
-    HIPCHK(hipMemsetAsync(c->wLogCtl.p, 0, sizeof(ZhLogCtl), s));
-    HIPCHK(hipMemsetAsync(c->wLeafCount.p, 0, nn * 4, s));
-    HIPCHK(hipMemsetAsync(c->wLeafFill.p, 0, nn * 4, s));
+    HIPCHK(zh_launch_batch_init(c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), (uint32_t)nn, c->wLogCtl.as<ZhLogCtl>(),
+                                c->wTotals.as<ZhTotals>(), s));
     ZhForestDev f = forest_dev(ix);
     HIPCHK(hipEventRecord(c->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));

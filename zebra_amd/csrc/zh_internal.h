@@ -120,6 +120,9 @@ hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCoun
                             ZhVisit *dVisits, const uint32_t *dLeafCount, uint32_t *dLeafFill,
                             const uint32_t *dGroupBase, const uint64_t *dGroupRowBase, ZhGroup *dGroups,
                             uint64_t *dGroupRowOff, ZhWalkLog log, hipStream_t s);
+// zeroes what a batch starts from zero: leaf visit counts / fill cursors, the log allocator, the packed leaf counter
+hipError_t zh_launch_batch_init(uint32_t *dLeafCount, uint32_t *dLeafFill, uint32_t n_nodes, ZhLogCtl *dLogCtl,
+                                ZhTotals *dTotals, hipStream_t s);
 // per leaf node: visits -> groups; exclusive scans of groups and of groups * len over the nodes
 hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
                                uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s);

@@ -837,52 +837,80 @@ __global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const ui
     groupBase[i] = (uint32_t)(old >> 36);
     groupRowBase[i] = old & ((1ull << 36) - 1);
 }
-__global__ void leaf_totals_kernel(const unsigned long long *__restrict__ packed, ZhTotals *__restrict__ totals) {
-    totals->groups = *packed >> 36;
-    totals->group_rows = *packed & ((1ull << 36) - 1);
-}
 hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
                                uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s) {
-    // the packed counter lives in the totals' `flags` word (zeroed here, rewritten by pair_scan afterwards)
+    // the packed counter lives in the totals' `flags` word (zeroed by zh_launch_batch_init, read and rewritten by the
+    // pair scan, which runs next)
     unsigned long long *packed = reinterpret_cast<unsigned long long *>(&dTotals->flags);
-    hipError_t e = hipMemsetAsync(packed, 0, 8, s);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_alloc_kernel, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f, dLeafCount, dGroupBase,
                        dGroupRowBase, packed);
-    hipLaunchKernelGGL(leaf_totals_kernel, dim3(1), dim3(1), 0, s, packed, dTotals);
     return hipGetLastError();
 }
 
-// exclusive scans of the three per-pair counts (single block; pairs <= a few 100k)
+// everything a batch starts from zero, in one launch (separate memsets are separate kernels, each a scheduling
+// round trip on a busy GPU): per-leaf visit counts and fill cursors, the visit log's allocator, the packed
+// group / row counter of the leaf allocation
+__global__ __launch_bounds__(256) void batch_init_kernel(uint32_t *__restrict__ leafCount, uint32_t *__restrict__ leafFill,
+                                                          uint32_t n_nodes, ZhLogCtl *__restrict__ logCtl,
+                                                          ZhTotals *__restrict__ totals) {
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t i = i0; i < n_nodes; i += stride) { leafCount[i] = 0; leafFill[i] = 0; }
+    if (i0 == 0) { logCtl->next_chunk = 0; logCtl->overflow = 0; totals->flags = 0; }
+}
+hipError_t zh_launch_batch_init(uint32_t *dLeafCount, uint32_t *dLeafFill, uint32_t n_nodes, ZhLogCtl *dLogCtl,
+                                ZhTotals *dTotals, hipStream_t s) {
+    uint32_t blocks = (n_nodes + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(batch_init_kernel, dim3(blocks), dim3(256), 0, s, dLeafCount, dLeafFill, n_nodes, dLogCtl, dTotals);
+    return hipGetLastError();
+}
+
+// exclusive scans of the three per-pair counts: one block walks the pairs 1024 at a time (coalesced 16-byte loads and
+// 8-byte stores), wave scans by shuffle + one LDS hop across the 16 waves, a running total carried between chunks.
+// Also finishes the totals: groups / group rows out of the leaf allocation's packed counter, the log's overflow flag.
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__restrict__ counts, uint32_t n,
                                                           uint64_t *__restrict__ rowBase,
                                                           uint64_t *__restrict__ candBase,
                                                           uint64_t *__restrict__ visitBase,
                                                           ZhTotals *__restrict__ totals,
                                                           const ZhLogCtl *__restrict__ logCtl) {
-    __shared__ uint64_t sr[1024], sc[1024], sv[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = lo + per < n ? lo + per : n;
-    uint64_t r = 0, c = 0, v = 0;
-    for (uint32_t i = lo; i < hi; i++) { r += counts[i].rows; c += counts[i].takes; v += counts[i].visits; }
-    sr[tid] = r; sc[tid] = c; sv[tid] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint64_t ar = 0, ac = 0, av = 0;
-        if (tid >= off) { ar = sr[tid - off]; ac = sc[tid - off]; av = sv[tid - off]; }
+    __shared__ uint64_t wr[16], wc[16], wv[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint64_t run_r = 0, run_c = 0, run_v = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {  // block-uniform
+        const uint32_t i = base + tid;
+        ZhPairCounts pc;
+        pc.visits = 0; pc.rows = 0; pc.takes = 0; pc.pad = 0;
+        if (i < n) pc = counts[i];
+        uint64_t r = pc.rows, c = pc.takes, v = pc.visits;  // inclusive scans inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t a = __shfl_up(r, o), b2 = __shfl_up(c, o), d2 = __shfl_up(v, o);
+            if (lane >= (uint32_t)o) { r += a; c += b2; v += d2; }
+        }
+        if (lane == 63) { wr[w] = r; wc[w] = c; wv[w] = v; }
         __syncthreads();
-        sr[tid] += ar; sc[tid] += ac; sv[tid] += av;
+        uint64_t pr = 0, pcn = 0, pv = 0, tr = 0, tc = 0, tv = 0;  // totals of the waves before mine / of the chunk
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint64_t a = wr[j], b2 = wc[j], d2 = wv[j];
+            if (j < w) { pr += a; pcn += b2; pv += d2; }
+            tr += a; tc += b2; tv += d2;
+        }
+        if (i < n) {
+            rowBase[i] = run_r + pr + r - pc.rows;
+            candBase[i] = run_c + pcn + c - pc.takes;
+            visitBase[i] = run_v + pv + v - pc.visits;
+        }
+        run_r += tr; run_c += tc; run_v += tv;
         __syncthreads();
     }
-    uint64_t br = sr[tid] - r, bc = sc[tid] - c, bv = sv[tid] - v;
-    for (uint32_t i = lo; i < hi; i++) {
-        rowBase[i] = br; candBase[i] = bc; visitBase[i] = bv;
-        br += counts[i].rows; bc += counts[i].takes; bv += counts[i].visits;
-    }
-    if (tid == 1023) {
-        rowBase[n] = sr[1023]; candBase[n] = sc[1023]; visitBase[n] = sv[1023];
-        totals->rows = sr[1023]; totals->takes = sc[1023]; totals->visits = sv[1023];
+    if (tid == 0) {
+        rowBase[n] = run_r; candBase[n] = run_c; visitBase[n] = run_v;
+        const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(&totals->flags);
+        totals->groups = packed >> 36;
+        totals->group_rows = packed & ((1ull << 36) - 1);
+        totals->rows = run_r; totals->takes = run_c; totals->visits = run_v;
         totals->flags = logCtl->overflow ? 1u : 0u;
     }
 }
@@ -1561,10 +1589,63 @@ hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, ui
     return hipGetLastError();
 }
 
+// Shard merge for the usual sizes (S * k <= 1024 entries per query): ONE WAVE per query sorts the S lists in LDS
+// (bitonic by (key, id), 16 KB) and keeps the k smallest distinct ids.  The 256-thread final_kernel<MERGE> does the same
+// for longer lists, but its 50 KB of LDS per block made a 1024-query merge occupy the whole chip next to the sweep.
+#define MERGE_WAVE_N 1024
+__global__ __launch_bounds__(64) void merge_wave_kernel(uint32_t B, uint32_t S, uint32_t k, const uint64_t *__restrict__ keys,
+                                                         const uint64_t *__restrict__ ids, const uint32_t *__restrict__ counts,
+                                                         uint64_t *__restrict__ out_ids, uint64_t *__restrict__ out_keys,
+                                                         uint32_t *__restrict__ out_counts, uint64_t stride64, uint64_t stride32) {
+    __shared__ uint64_t sk[MERGE_WAVE_N], si[MERGE_WAVE_N];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x, n = S * k, np2 = next_pow2(n);
+    for (uint32_t e = lane; e < np2; e += 64) {
+        uint64_t key = ~0ull, id = ~0ull;
+        if (e < n) {
+            const uint32_t sh = e / k, j = e % k;
+            if (j < counts[(size_t)sh * stride32 + b]) {
+                const size_t src = (size_t)sh * stride64 + (size_t)b * k + j;
+                key = keys[src]; id = ids[src];
+            }
+        }
+        sk[e] = key; si[e] = id;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = lane; t < np2 / 2; t += 64) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t ka = sk[lo], kb = sk[hi], ia = si[lo], ib = si[hi];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == up) { sk[lo] = kb; sk[hi] = ka; si[lo] = ib; si[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    // first k distinct ids of the sorted run (invalid slots, all ones, sort last)
+    uint32_t have = 0;
+    for (uint32_t base = 0; base < n && have < k; base += 64) {  // wave-uniform
+        const uint32_t e = base + lane;
+        const bool keep = e < n && !(sk[e] == ~0ull && si[e] == ~0ull) && (e == 0 || si[e] != si[e - 1]);
+        const unsigned long long m = __ballot(keep);
+        const uint32_t pos = have + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (keep && pos < k) { out_ids[(size_t)b * k + pos] = si[e]; out_keys[(size_t)b * k + pos] = sk[e]; }
+        have += (uint32_t)__popcll(m);
+    }
+    if (have > k) have = k;
+    for (uint32_t i = have + lane; i < k; i += 64) { out_ids[(size_t)b * k + i] = ~0ull; out_keys[(size_t)b * k + i] = ~0ull; }
+    if (lane == 0) out_counts[b] = have;
+}
+
 hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *dIds, const uint64_t *dKeys,
                            const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
                            uint64_t stride64, uint64_t stride32, hipStream_t s) {
     if (!B) return hipSuccess;
+    if ((uint64_t)S * k <= MERGE_WAVE_N) {
+        hipLaunchKernelGGL(merge_wave_kernel, dim3(B), dim3(64), 0, s, B, S, k, dKeys, dIds, dCounts, dOutIds, dOutKeys, dOutCounts,
+                           stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, S, k, dKeys,
                        (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts,
                        stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B);
