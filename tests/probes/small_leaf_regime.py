@@ -10,14 +10,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import zebra_amd as za  # noqa: E402
 from oracle import zebra_oracle as zo  # noqa: E402
 
-n, d, B, k = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, 384, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 10
+n, d, B, k = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, int(os.environ.get("PROBE_DIM", "384")), int(sys.argv[2]) if len(sys.argv) > 2 else 64, 10
+COS = os.environ.get("PROBE_METRIC") == "cosine"  # the reference's image / audio databases: Database<768, CosineDistance>
 X = zo.synth_rows(n, d)
 Q = zo.synth_queries(B, d, n)
 ix = za.LSHIndex(d, za.LSHIndexOptions(5, 15))
 t0 = time.perf_counter()
 ix.add(X)
 print("build s", round(time.perf_counter() - t0, 2), "planes", ix.get_forest()["consts"].size)
-m = za.L2SquaredDistance()
+m = za.CosineDistance(parity=True) if COS else za.L2SquaredDistance()
 if os.environ.get("DENSE_LEVELS"):
     ix.set_dense_levels(int(os.environ["DENSE_LEVELS"]))
 ix.search_batch(Q, k, m)
@@ -32,6 +33,6 @@ print("ms/batch", round(dt * 1e3, 2), "qps", round(B / dt), {s: round(st["ms_" +
       "visits", st["visits"], "rows", st["rows_scored"], "cands", st["candidates"])
 f = zo.Forest.from_arrays(X, 5, ix.get_forest())
 for b in sorted({0, min(1, B - 1), B // 2, max(B - 2, 0), B - 1}):
-    oi, ok = f.search(Q[b], k, zo.L2SQ)
+    oi, ok = f.search(Q[b], k, zo.COSINE, zo.PARITY) if COS else f.search(Q[b], k, zo.L2SQ)
     assert (ids[b] == oi).all() and (keys[b] == ok).all()
 print("checked against the oracle")
