@@ -340,6 +340,7 @@ typedef struct zo_forest {
     uint32_t n_planes, cap_planes;
     uint32_t *leaf_ids;
     uint64_t n_leaf_ids, cap_leaf_ids;
+    int borrowed; /* the arrays belong to the caller (zo_forest_borrow_arrays): never reallocated or freed here */
 } zo_forest;
 
 static uint32_t new_node(zo_forest *f) {
@@ -600,8 +601,27 @@ ZO_EXPORT zo_forest *zo_forest_from_arrays(uint64_t n_rows, uint32_t d, uint32_t
     return f;
 }
 
+/* the same without copying: the forest of a full-size shard (GBs of leaf ids) exported by the HIP build stays in the
+ * caller's arrays, which must outlive the forest.  Read-only use (search, checks): insert / remove would realloc. */
+ZO_EXPORT zo_forest *zo_forest_borrow_arrays(uint64_t n_rows, uint32_t d, uint32_t M, uint32_t T, uint32_t n_nodes,
+                                             const int32_t *plane, const int32_t *left, const int32_t *right,
+                                             const uint32_t *roots, uint32_t n_planes, const float *planes,
+                                             const float *consts, uint64_t n_leaf_ids, const uint32_t *leaf_ids) {
+    zo_forest *f = calloc(1, sizeof *f);
+    f->n_rows = n_rows; f->d = d; f->M = M; f->T = T; f->borrowed = 1;
+    f->n_nodes = f->cap_nodes = n_nodes;
+    f->plane = (int32_t *)plane; f->left = (int32_t *)left; f->right = (int32_t *)right;
+    f->roots = (uint32_t *)roots;
+    f->n_planes = f->cap_planes = n_planes;
+    f->planes = (float *)planes; f->consts = (float *)consts;
+    f->n_leaf_ids = f->cap_leaf_ids = n_leaf_ids;
+    f->leaf_ids = (uint32_t *)leaf_ids;
+    return f;
+}
+
 ZO_EXPORT void zo_forest_free(zo_forest *f) {
     if (!f) return;
+    if (f->borrowed) { free(f->depth); free(f); return; }
     free(f->plane); free(f->left); free(f->right); free(f->depth); free(f->roots);
     free(f->planes); free(f->consts); free(f->leaf_ids); free(f);
 }
@@ -638,23 +658,48 @@ typedef struct {
     const float *X, *q;
     int metric, mode;
     float qq; /* sum_prod(q,q): the query-side norm, same value for every stored row */
-    uint32_t *stamp, epoch; /* candidate set (DashSet, lsh.rs:550) */
-    uint32_t *cand; uint64_t n_cand;
-    zo_pair *buf; /* leaf scoring buffer, >= max leaf length */
+    /* stored rows that are not in memory: row id -> counter generator (seed, first_row + id, kind), regenerated into
+     * `rowbuf` on demand -- what lets the oracle check a 10M..125M-row shard it could never hold (X == NULL) */
+    uint64_t synth_seed, synth_row0; int synth_kind; float *rowbuf;
+    uint32_t *stamp, epoch; /* candidate set (DashSet, lsh.rs:550); NULL: cand is a list, de-duplicated by sorting */
+    uint32_t *cand; uint64_t n_cand, cap_cand;
+    zo_pair *buf; uint64_t cap_buf; /* leaf scoring / rerank buffer, grown on demand */
     /* optional visit trace: (leaf offset, leaf length, n taken) triples */
     uint64_t *visits; uint64_t n_visits, cap_visits;
     uint64_t rows_scored, planes_evaluated, leaves_visited;
 } zo_ctx;
 
+static inline const float *ctx_row(zo_ctx *c, uint32_t id) {
+    if (c->X) return c->X + (size_t)id * c->f->d;
+    for (uint32_t col = 0; col < c->f->d; col++) c->rowbuf[col] = synth_elem(c->synth_seed, c->synth_row0 + id, col, c->f->d, c->synth_kind);
+    return c->rowbuf;
+}
+static inline void ctx_reserve_buf(zo_ctx *c, uint64_t n) {
+    if (n <= c->cap_buf) return;
+    c->cap_buf = n + n / 2 + 64;
+    c->buf = realloc(c->buf, c->cap_buf * sizeof(zo_pair));
+}
 static inline uint64_t ctx_key(zo_ctx *c, uint32_t id) {
-    const float *a = c->X + (size_t)id * c->f->d;
+    const float *a = ctx_row(c, id);
     if (c->metric >= ZO_CHEBYSHEV) return key_generic(c->metric, c->mode, sums_generic(c->metric, c->mode, a, c->q, c->f->d));
     if (c->metric == ZO_COSINE)
         return key_from_sums(c->metric, c->mode, sum_prod(a, c->q, c->f->d), sum_prod(a, a, c->f->d), c->qq, 0.0f);
     return key_from_sums(c->metric, c->mode, 0, 0, 0, sum_l2sq(a, c->q, c->f->d));
 }
 static inline void cand_insert(zo_ctx *c, uint32_t id) {
-    if (c->stamp[id] != c->epoch) { c->stamp[id] = c->epoch; c->cand[c->n_cand++] = id; }
+    if (c->stamp) {
+        if (c->stamp[id] != c->epoch) { c->stamp[id] = c->epoch; c->cand[c->n_cand++] = id; }
+        return;
+    }
+    if (c->n_cand == c->cap_cand) {
+        c->cap_cand = c->cap_cand ? c->cap_cand * 2 : 1024;
+        c->cand = realloc(c->cand, c->cap_cand * sizeof(uint32_t));
+    }
+    c->cand[c->n_cand++] = id;
+}
+static int u32_cmp(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : (x > y);
 }
 
 static int32_t walk(zo_ctx *c, int32_t node, int32_t n) {
@@ -668,6 +713,7 @@ static int32_t walk(zo_ctx *c, int32_t node, int32_t n) {
             for (uint32_t i = 0; i < len; i++) cand_insert(c, ids[i]);
             ret = (int32_t)len;
         } else { /* lsh.rs:308-329: score all, sort ascending by key, take n */
+            ctx_reserve_buf(c, len);
             for (uint32_t i = 0; i < len; i++) { c->buf[i].id = ids[i]; c->buf[i].key = ctx_key(c, ids[i]); }
             c->rows_scored += len;
             qsort(c->buf, len, sizeof(zo_pair), pair_cmp);
@@ -695,21 +741,21 @@ typedef struct {
     uint64_t rows_scored, planes_evaluated, leaves_visited, candidates;
 } zo_stats;
 
-static uint32_t max_leaf_len(const zo_forest *f) {
-    uint32_t m = 1;
-    for (uint32_t i = 0; i < f->n_nodes; i++)
-        if (f->plane[i] < 0 && (uint32_t)f->right[i] > m) m = (uint32_t)f->right[i];
-    return m;
-}
-
 static void ctx_init(zo_ctx *c, const zo_forest *f, const float *X, int metric, int mode) {
     memset(c, 0, sizeof *c);
     c->f = f; c->X = X; c->metric = metric; c->mode = mode;
     c->stamp = calloc(f->n_rows ? f->n_rows : 1, sizeof(uint32_t));
-    c->cand = malloc((f->n_rows ? f->n_rows : 1) * sizeof(uint32_t));
-    c->buf = malloc(((size_t)max_leaf_len(f) + f->n_rows + 1) * sizeof(zo_pair));
+    c->cap_cand = f->n_rows ? f->n_rows : 1;
+    c->cand = malloc(c->cap_cand * sizeof(uint32_t));
 }
-static void ctx_free(zo_ctx *c) { free(c->stamp); free(c->cand); free(c->buf); }
+/* rows from the counter generator instead of memory; candidate set kept as a list (no n_rows-sized arrays) */
+static void ctx_init_synth(zo_ctx *c, const zo_forest *f, uint64_t seed, uint64_t row0, int kind, int metric, int mode) {
+    memset(c, 0, sizeof *c);
+    c->f = f; c->metric = metric; c->mode = mode;
+    c->synth_seed = seed; c->synth_row0 = row0; c->synth_kind = kind;
+    c->rowbuf = malloc((f->d ? f->d : 1) * sizeof(float));
+}
+static void ctx_free(zo_ctx *c) { free(c->stamp); free(c->cand); free(c->buf); free(c->rowbuf); }
 
 /* lsh.rs:544-565 search: every tree with n = top_k; union; RE-score every candidate; sort; take k */
 static uint32_t search_one(zo_ctx *c, const float *q, uint32_t k, uint64_t *out_ids, uint64_t *out_keys) {
@@ -718,6 +764,13 @@ static uint32_t search_one(zo_ctx *c, const float *q, uint32_t k, uint64_t *out_
     c->qq = c->metric == ZO_COSINE ? sum_prod(q, q, f->d) : 0.0f;
     if (f->n_rows == 0) return 0; /* core.rs:295-297 */
     for (uint32_t t = 0; t < f->T; t++) walk(c, (int32_t)f->roots[t], (int32_t)k);
+    if (!c->stamp && c->n_cand > 1) { /* the union of the trees' candidates as a set (lsh.rs:550 DashSet) */
+        qsort(c->cand, c->n_cand, sizeof(uint32_t), u32_cmp);
+        uint64_t m = 1;
+        for (uint64_t i = 1; i < c->n_cand; i++) if (c->cand[i] != c->cand[m - 1]) c->cand[m++] = c->cand[i];
+        c->n_cand = m;
+    }
+    ctx_reserve_buf(c, c->n_cand);
     zo_pair *r = c->buf;
     for (uint64_t i = 0; i < c->n_cand; i++) { r[i].id = c->cand[i]; r[i].key = ctx_key(c, c->cand[i]); }
     c->rows_scored += c->n_cand;
@@ -760,6 +813,136 @@ ZO_EXPORT void zo_search_batch(const zo_forest *f, const float *X, const float *
         ctx_free(&c);
     }
     if (st) { st->rows_scored = rs; st->planes_evaluated = pe; st->leaves_visited = lv; st->candidates = cd; }
+}
+
+/* The same search with the stored rows REGENERATED from the counter generator (row id -> zo_synth_rows(seed,
+ * first_row + id, kind)) instead of read from memory: the full-size configurations (10M x 768 = 31 GB, a 125M x 128
+ * shard = 64 GB) are then checked exactly -- ids, keys, counts -- against a forest exported by the HIP build, with
+ * no host copy of the rows.  Output ids are LOCAL row ids (add the shard's id_base). */
+ZO_EXPORT void zo_search_batch_synth(const zo_forest *f, uint64_t seed_rows, uint64_t first_row, int kind, const float *Q,
+                                     uint64_t b, uint32_t k, int metric, int mode, uint64_t *out_ids, uint64_t *out_keys,
+                                     uint32_t *out_counts, int nthreads, zo_stats *st) {
+    uint64_t rs = 0, pe = 0, lv = 0, cd = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel reduction(+ : rs, pe, lv, cd)
+#endif
+    {
+        zo_ctx c; ctx_init_synth(&c, f, seed_rows, first_row, kind, metric, mode);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (uint64_t i = 0; i < b; i++) {
+            out_counts[i] = search_one(&c, Q + i * f->d, k, out_ids + i * k, out_keys + i * k);
+            cd += c.n_cand;
+        }
+        rs += c.rows_scored; pe += c.planes_evaluated; lv += c.leaves_visited;
+        ctx_free(&c);
+    }
+    if (st) { st->rows_scored = rs; st->planes_evaluated = pe; st->leaves_visited = lv; st->candidates = cd; }
+}
+
+/* Structural check of a forest built elsewhere (the HIP build at full size, where zo_forest_build would take hours)
+ * against the build rules, rows from the counter generator.  Returns 0 when everything holds, else a code:
+ *   1  a tree's leaves are not a partition of the live rows [0, n_rows)          (build_index, lsh.rs:411-429)
+ *   2  a leaf holds >= M rows above the depth guard, or an inner node < M        (build_a_tree, lsh.rs:251-252)
+ *   3  a sampled row does not sit in the leaf it hashes to                        (lsh.rs:233-247 + 39-43)
+ *   4  a plane on a sampled row's path is not make_hyperplane of the node's sample pair (lsh.rs:197-231)
+ * n_sample rows (evenly spread) are descended through every tree; every plane on their paths is re-derived. */
+ZO_EXPORT int zo_check_forest_synth(const zo_forest *f, uint64_t index_seed, uint64_t seed_rows, uint64_t first_row,
+                                    int kind, uint64_t n_sample, uint64_t *out_planes_checked) {
+    const uint32_t d = f->d;
+    int bad = 0;
+    uint64_t planes_checked = 0;
+    /* 1 + 2: per tree, the leaves partition [0, n_rows); subtree sizes obey the M rule (trees in parallel) */
+    int bad1 = 0, bad2 = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad1, bad2)
+#endif
+    for (uint32_t t = 0; t < f->T; t++) {
+        uint8_t *seen = calloc(f->n_rows ? f->n_rows : 1, 1);
+        /* nodes of this tree in pre-order, with their depth; sizes accumulate in a reverse pass over that order */
+        uint32_t cap = 1024, n_order = 0, sp = 0, cap_st = 256;
+        uint32_t *order = malloc(cap * sizeof(uint32_t)), *stack = malloc(cap_st * sizeof(uint32_t));
+        uint8_t *dep = malloc(cap), *dstack = malloc(cap_st);
+        uint64_t total = 0;
+        stack[sp] = f->roots[t]; dstack[sp++] = 0;
+        while (sp) {
+            const uint32_t n = stack[--sp];
+            const uint8_t dn = dstack[sp];
+            if (n_order == cap) { cap *= 2; order = realloc(order, cap * sizeof(uint32_t)); dep = realloc(dep, cap); }
+            order[n_order] = n; dep[n_order++] = dn;
+            if (f->plane[n] < 0) {
+                const uint32_t off = (uint32_t)f->left[n], len = (uint32_t)f->right[n];
+                for (uint32_t i = 0; i < len; i++) {
+                    const uint32_t id = f->leaf_ids[(size_t)off + i];
+                    if (id >= f->n_rows || seen[id]) { bad1 = 1; break; }
+                    seen[id] = 1;
+                }
+                total += len;
+                if (len >= f->M && dn < ZO_MAX_DEPTH) bad2 = 1;
+            } else {
+                if (sp + 2 > cap_st) { cap_st *= 2; stack = realloc(stack, cap_st * sizeof(uint32_t)); dstack = realloc(dstack, cap_st); }
+                stack[sp] = (uint32_t)f->left[n]; dstack[sp++] = (uint8_t)(dn + 1);
+                stack[sp] = (uint32_t)f->right[n]; dstack[sp++] = (uint8_t)(dn + 1);
+            }
+            if (bad1 || n_order > f->n_nodes) { bad1 = 1; break; }
+        }
+        if (total != f->n_rows) bad1 = 1;
+        if (!bad1) { /* subtree sizes: in pre-order every subtree is a contiguous run, children after the parent */
+            /* reverse pass with an explicit stack of completed subtree sizes */
+            uint64_t *done = malloc(((size_t)n_order + 1) * sizeof(uint64_t));
+            uint32_t nd = 0;
+            for (uint32_t i = n_order; i-- > 0;) {
+                const uint32_t n = order[i];
+                if (f->plane[n] < 0) done[nd++] = (uint32_t)f->right[n];
+                else { /* its two children's subtrees are the last two completed ones */
+                    const uint64_t sz = done[nd - 1] + done[nd - 2];
+                    nd -= 2;
+                    if (sz < f->M) bad2 = 1;
+                    done[nd++] = sz;
+                }
+            }
+            free(done);
+        }
+        free(seen); free(order); free(stack); free(dep); free(dstack);
+    }
+    bad = bad1 ? 1 : (bad2 ? 2 : 0);
+    if (bad) { if (out_planes_checked) *out_planes_checked = 0; return bad; }
+    /* 3 + 4: sampled rows */
+    int bad3 = 0, bad4 = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : planes_checked) reduction(| : bad3, bad4)
+#endif
+    for (uint64_t s = 0; s < n_sample; s++) {
+        float *x = malloc(d * sizeof(float)), *a = malloc(d * sizeof(float)), *bb = malloc(d * sizeof(float)), *w = malloc(d * sizeof(float));
+        const uint64_t id = n_sample > 1 ? (uint64_t)((double)s * (double)(f->n_rows - 1) / (double)(n_sample - 1)) : 0;
+        for (uint32_t c = 0; c < d; c++) x[c] = synth_elem(seed_rows, first_row + id, c, d, kind);
+        for (uint32_t t = 0; t < f->T; t++) {
+            uint32_t node = f->roots[t];
+            uint64_t path = 1;
+            while (f->plane[node] >= 0) {
+                const int32_t p = f->plane[node];
+                uint64_t si, sj;
+                float cc;
+                zo_sample_pair(index_seed, t, path, f->n_rows, &si, &sj);
+                for (uint32_t c = 0; c < d; c++) { a[c] = synth_elem(seed_rows, first_row + si, c, d, kind); bb[c] = synth_elem(seed_rows, first_row + sj, c, d, kind); }
+                zo_make_hyperplane(a, bb, d, w, &cc);
+                if (memcmp(w, f->planes + (size_t)p * d, d * sizeof(float)) != 0 || memcmp(&cc, &f->consts[p], 4) != 0) bad4 = 1;
+                planes_checked++;
+                const int above = zo_point_is_above(f->planes + (size_t)p * d, f->consts[p], x, d);
+                node = (uint32_t)(above ? f->right[node] : f->left[node]);
+                path = 2 * path + (above ? 1 : 0);
+            }
+            const uint32_t off = (uint32_t)f->left[node], len = (uint32_t)f->right[node];
+            int found = 0;
+            for (uint32_t i = 0; i < len; i++) if (f->leaf_ids[(size_t)off + i] == id) { found = 1; break; }
+            if (!found) bad3 = 1;
+        }
+        free(x); free(a); free(bb); free(w);
+    }
+    if (out_planes_checked) *out_planes_checked = planes_checked;
+    return bad4 ? 4 : (bad3 ? 3 : 0);
 }
 
 /* one tree_result call, exposing the return value, the candidate ids (insertion order) and the

@@ -68,6 +68,11 @@ def lib():
         L.zo_search.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, vp, vp, vp]
         L.zo_search.restype = u32
         L.zo_search_batch.argtypes = [vp, vp, vp, u64, u32, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+        L.zo_forest_borrow_arrays.argtypes = [u64, u32, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, u64, vp]
+        L.zo_forest_borrow_arrays.restype = vp
+        L.zo_search_batch_synth.argtypes = [vp, u64, u64, C.c_int, vp, u64, u32, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+        L.zo_check_forest_synth.argtypes = [vp, u64, u64, u64, C.c_int, u64, vp]
+        L.zo_check_forest_synth.restype = C.c_int
         L.zo_tree_result.argtypes = [vp, vp, u32, vp, i32, C.c_int, C.c_int, vp, vp, vp, u64, vp]
         L.zo_tree_result.restype = i32
         L.zo_hash_signs.argtypes = [vp, vp, vp, vp]
@@ -177,6 +182,45 @@ class Forest:
         h = lib().zo_forest_from_arrays(n, d, M, roots.size, plane.size, _p(plane), _p(left), _p(right), _p(roots),
                                         consts.size, _p(planes), _p(consts), leaf_ids.size, _p(leaf_ids))
         return cls(h, X, n, d, M, roots.size)
+
+    @classmethod
+    def borrow_synth(cls, n_rows, d, M, arrays, seed_rows=SEED_ROWS, first_row=0, kind=0):
+        """A forest exported by the HIP build (LSHIndex.get_forest()) over rows that exist only as the counter
+        generator (seed_rows, first_row + id, kind): no copy of the arrays (GBs of leaf ids at full size), no X.
+        Only search_batch_synth / check_synth may be used on it."""
+        a = dict(plane=np.ascontiguousarray(arrays["plane"], np.int32), left=np.ascontiguousarray(arrays["left"], np.int32),
+                 right=np.ascontiguousarray(arrays["right"], np.int32), roots=np.ascontiguousarray(arrays["roots"], np.uint32),
+                 planes=np.ascontiguousarray(arrays["planes"], np.float32).reshape(-1, d),
+                 consts=np.ascontiguousarray(arrays["consts"], np.float32),
+                 leaf_ids=np.ascontiguousarray(arrays["leaf_ids"], np.uint32))
+        h = lib().zo_forest_borrow_arrays(n_rows, d, M, a["roots"].size, a["plane"].size, _p(a["plane"]), _p(a["left"]),
+                                          _p(a["right"]), _p(a["roots"]), a["consts"].size, _p(a["planes"]), _p(a["consts"]),
+                                          a["leaf_ids"].size, _p(a["leaf_ids"]))
+        f = cls(h, None, n_rows, d, M, a["roots"].size)
+        f._keep = a  # the borrowed arrays must outlive the forest
+        f._synth = (seed_rows, first_row, kind)
+        return f
+
+    def search_batch_synth(self, Q, k, metric, mode=PARITY, nthreads=0, stats=False):
+        """LSHIndex::search for every query with the stored rows regenerated on demand -> LOCAL ids, keys, counts"""
+        Q = _f32(Q)
+        b = Q.shape[0]
+        ids, keys = np.zeros((b, k), np.uint64), np.zeros((b, k), np.uint64)
+        counts = np.zeros(b, np.uint32)
+        st = Stats()
+        seed, row0, kind = self._synth
+        lib().zo_search_batch_synth(self._h, seed, row0, kind, _p(Q), b, k, metric, mode, _p(ids), _p(keys), _p(counts),
+                                    nthreads, C.byref(st))
+        if stats:
+            return ids, keys, counts, st
+        return ids, keys, counts
+
+    def check_synth(self, index_seed=SEED_INDEX, n_sample=64):
+        """build rules of lsh.rs:192-267,411-429 on a forest built elsewhere: 0 = holds; (code, planes re-derived)"""
+        seed, row0, kind = self._synth
+        n = C.c_uint64()
+        rc = lib().zo_check_forest_synth(self._h, index_seed, seed, row0, kind, n_sample, C.byref(n))
+        return rc, n.value
 
     def insert(self, X_all, n_prev):
         """LSHIndex::add on an index that already has trees (lsh.rs:445-462): X_all = old rows + new rows"""
