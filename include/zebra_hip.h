@@ -18,7 +18,10 @@
  *   zh_index_count / zh_index_num_trees  LSHIndex::no_vectors / no_trees / is_empty  lsh.rs:389-409
  *   zh_index_clear                       LSHIndex::clear          src/database/index/lsh.rs:506-529
  *   zh_index_remove / zh_index_deduplicate  LSHIndex::remove / deduplicate  src/database/index/lsh.rs:473-503, 270-288
- *   zh_merge_topk_device                 (new) shard merge after the RCCL all-gather
+ *   zh_shard_group_* / zh_shard_search_* (new) the loop of Database::query_vectors (src/database/core.rs:299-303) over an index
+ *                                        whose rows are sharded across GPUs (README.md:31 "can be sharded"): local search on
+ *                                        this rank's shard, ONE RCCL all-gather of the packed top-k, merge on every rank
+ *   zh_merge_topk_device                 (new) the shard merge alone
  *
  * Conventions
  *   - Every function returns ZH_OK (0) or a negative zh_status; zh_last_error() gives the message
@@ -176,6 +179,8 @@ ZH_API int zh_index_get_forest(zh_index *idx, int32_t *plane, int32_t *left, int
 ZH_API uint64_t zh_index_count(const zh_index *idx);     /* stored vectors (0 <=> no_vectors) */
 ZH_API uint32_t zh_index_num_trees(const zh_index *idx); /* built trees    (0 <=> no_trees)   */
 ZH_API uint32_t zh_index_dim(const zh_index *idx);
+ZH_API int32_t zh_index_device(const zh_index *idx);     /* HIP device ordinal the index lives on */
+ZH_API uint64_t zh_index_id_base(const zh_index *idx);
 ZH_API const float *zh_index_rows_device(const zh_index *idx); /* device pointer to the stored rows (read-only) */
 /* copy n stored rows starting at local row `first` back to host memory (KeyValue::embedding, lsh.rs:107-119) */
 ZH_API int zh_index_read_rows(zh_index *idx, uint64_t first, size_t n, float *out);
@@ -234,6 +239,48 @@ ZH_API int zh_merge_topk_device(int device, uint32_t n_shards, size_t b, size_t 
 ZH_API size_t zh_packed_result_words(size_t b, size_t k);
 ZH_API int zh_merge_topk_packed_device(int device, uint32_t n_shards, size_t b, size_t k, const uint64_t *d_packed,
                                 uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
+
+/* ---- sharded search: rows partitioned over GPUs, one RCCL all-gather per batch ---------------------------------
+ * One process per GPU (the harness' model) -- or several groups in one process, one per device.  Every rank owns an
+ * ordinary zh_index over its rows (its own forest, options.id_base = global id of its first row) and joins a group;
+ * a search on the group is then ONE call per batch on every rank, with the same queries everywhere:
+ *     local zh_search on this rank's shard -> ncclAllGather of the packed [ids | keys | counts] result (in place,
+ *     b*k*16 + b*4 bytes per rank) -> merge_wave_kernel on every rank -> every rank holds the global top-k.
+ * top-k(union of the shards' top-k) == top-k(union of the shards' candidates), so the result is bit-identical to the
+ * reference searching S independent LSHIndex instances and merging by (key, id).
+ * The library links librccl itself; the caller only moves the 128-byte unique id from rank 0 to the other ranks
+ * (any host channel: a file, MPI, a torch.distributed store).
+ * Calls on one group must come from one thread at a time and in the same order on every rank (they are collectives). */
+typedef struct zh_shard_group zh_shard_group;
+#define ZH_UNIQUE_ID_BYTES 128
+ZH_API int zh_shard_unique_id(uint8_t out_id[ZH_UNIQUE_ID_BYTES]); /* rank 0: ncclGetUniqueId */
+/* collective over the n_ranks callers (ncclCommInitRank on the shard's device).  The group borrows `shard`, which must
+ * outlive it; rows may still be added to the shard between searches. */
+ZH_API int zh_shard_group_create(zh_index *shard, const uint8_t id[ZH_UNIQUE_ID_BYTES], uint32_t n_ranks, uint32_t rank,
+                                 zh_shard_group **out);
+ZH_API void zh_shard_group_destroy(zh_shard_group *grp);
+ZH_API uint32_t zh_shard_group_ranks(const zh_shard_group *grp); /* ncclCommCount: the ranks RCCL actually connected */
+ZH_API uint32_t zh_shard_group_rank(const zh_shard_group *grp);
+/* Blocking search over the whole sharded index; queries / results in device memory on every rank (d_out_* receive the
+ * MERGED global top-k, same layout as zh_search_batch_device). */
+ZH_API int zh_shard_search_batch_device(zh_shard_group *grp, const float *d_q, size_t b, size_t k, int metric, int cosine_mode,
+                                        uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts);
+/* The same from / to host memory (what a Rust Database::query_vectors over a sharded index calls). */
+ZH_API int zh_shard_search_batch(zh_shard_group *grp, const float *q, size_t b, size_t k, int metric, int cosine_mode,
+                                 uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts);
+/* Pipelined form, as zh_search_begin / finish / wait: a context is one batch in flight with its own streams (light
+ * kernels: high priority; exchange + merge: normal priority, beside the next batch's sweep on the index's sweep stream).
+ * finish enqueues sweep, select, final, the all-gather and the merge and returns; wait blocks until the merged results
+ * are complete.  zh_shard_ctx_stream is the stream they complete on (enqueue result copies behind it). */
+typedef struct zh_shard_ctx zh_shard_ctx;
+ZH_API int zh_shard_ctx_create(zh_shard_group *grp, zh_shard_ctx **out);
+ZH_API void zh_shard_ctx_destroy(zh_shard_ctx *ctx);
+ZH_API int zh_shard_search_begin(zh_shard_ctx *ctx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode);
+ZH_API int zh_shard_search_finish(zh_shard_ctx *ctx, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts);
+ZH_API int zh_shard_search_wait(zh_shard_ctx *ctx);
+ZH_API void *zh_shard_ctx_stream(const zh_shard_ctx *ctx);
+/* this rank's own (unmerged) packed result of the context's last finished batch: zh_packed_result_words(b, k) words */
+ZH_API const uint64_t *zh_shard_ctx_local_result(const zh_shard_ctx *ctx);
 
 /* synthetic queries on the device (bit-identical to oracle zo_synth_queries) */
 ZH_API int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,

@@ -50,12 +50,14 @@ def _exact_vs_oracle(ix, n, d, M, Q, sel, k, om, omode, ids, keys, counts, rows0
     return oi + base, ok, oc, st
 
 
-def _check(za, n, d, metric_name, k, B, M, T, kind=0, n_exact=8, planted_min=0.5, rows0=0):
-    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), reserve_rows=n)
+def _check(za, n, d, metric_name, k, B, M, T, kind=0, n_exact=8, planted_min=0.5, rows0=0, n_total=None):
+    """n rows [rows0, rows0 + n) of a set of n_total rows (a shard when n_total > n; ids are global)"""
+    n_total = n_total or n
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=rows0, reserve_rows=n)
     ix.append_synthetic(n, first_row=rows0, kind=kind)
     ix.build()
     assert len(ix) == n and not ix.is_empty()
-    Q = zo.synth_queries(B, d, n, kind=kind)
+    Q = zo.synth_queries(B, d, n_total, kind=kind)
     m, om, omode = _metrics(za)[metric_name]
     ids, keys, counts = ix.search_batch(Q, k, m)
     assert (counts == k).all()
@@ -81,9 +83,12 @@ def _check(za, n, d, metric_name, k, B, M, T, kind=0, n_exact=8, planted_min=0.5
         assert (i3 == ids[:64]).all() and (k3 == keys[:64]).all()
     ix.set_dense_levels(-1)
     # planted neighbours
-    planted = np.array([zo.synth_query_row(b, n) for b in range(B)], dtype=np.uint64)
-    hit = float((ids == planted[:, None]).any(1).mean())
+    planted = np.array([zo.synth_query_row(b, n_total) for b in range(B)], dtype=np.uint64)
+    here = (planted >= rows0) & (planted < rows0 + n)  # queries whose planted row lives in this shard
+    assert here.sum() >= B // 16
+    hit = float((ids[here] == planted[here, None]).any(1).mean())
     assert hit >= planted_min, hit
+    assert not (ids[~here] == planted[~here, None]).any()
     s = ix.stats()
     assert s["rows_scored"] >= B * T * k and s["rows_swept"] <= s["rows_scored"]
     ix.close()
@@ -199,7 +204,8 @@ def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
 def test_cfg5_full_shard_125m_128d_sift_l2_top10_batch4096():
     import zebra_amd as za
     # one whole shard of the 1B set (rank 5 of 8: rows [625M, 750M)): 64 GB of integer-valued rows -> exact L2
-    _check(za, 125_000_000, 128, "l2", 10, 4096, 8192, 15, kind=1, planted_min=0.3, n_exact=8, rows0=625_000_000)
+    _check(za, 125_000_000, 128, "l2", 10, 4096, 8192, 15, kind=1, planted_min=0.3, n_exact=8, rows0=625_000_000,
+           n_total=1_000_000_000)
 
 
 def test_reference_default_options_at_batch_size_more_than_2_24_visits():

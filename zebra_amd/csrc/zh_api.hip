@@ -286,6 +286,8 @@ extern "C" int zh_index_clear(zh_index *ix) {
 extern "C" uint64_t zh_index_count(const zh_index *ix) { return ix ? ix->n_rows - ix->n_dead : 0; }
 extern "C" uint32_t zh_index_num_trees(const zh_index *ix) { return ix ? ix->n_trees : 0; }
 extern "C" uint32_t zh_index_dim(const zh_index *ix) { return ix ? ix->opt.dim : 0; }
+extern "C" int32_t zh_index_device(const zh_index *ix) { return ix ? ix->device : -1; }
+extern "C" uint64_t zh_index_id_base(const zh_index *ix) { return ix ? ix->opt.id_base : 0; }
 extern "C" const float *zh_index_rows_device(const zh_index *ix) { return ix ? ix->X.as<float>() : nullptr; }
 extern "C" void *zh_index_sweep_stream(const zh_index *ix) { return ix ? (void *)ix->sweep_stream : nullptr; }
 
