@@ -4,27 +4,36 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of B synthetic queries through zh_search_batch_device (hash -> walk -> sweep ->
-select -> final), plus, for N > 1, the RCCL all-gather of every rank's top-k and the merge kernel.
-Queries and stored vectors are resident in HBM before the timed region starts.
+One "step" = one batch of B synthetic queries through the library: hash -> walk -> sweep -> select -> final, plus,
+for N > 1, the RCCL all-gather of every rank's packed top-k and the merge kernel (zh_shard_search_*: the exchange is
+inside libzebra_hip.so, which links librccl; torch.distributed is used only to launch, to hand rank 0's 128-byte
+unique id to the other ranks and for the timing barriers -- on the CPU/gloo side).  Queries and stored vectors are
+resident in HBM before the timed region starts; the timed span ends with every batch's results in (pinned) HOST memory.
 
 Workloads (BASELINE.json `configs`; index options from BASELINE.md s3):
-  N = 1  -> cfg3: 10M x 768 f32, L2 top-100, batch 1024, max_node_size 4096, num_trees 15.  The metric's own
-            config (cfg4, 100M x 768) is 307 GB and does not fit one 288 GB GPU, so the largest single-GPU
-            config is used, as the bench contract prescribes.
-  N > 1  -> the SAME config (the other configs are parity-test cases, not bench lines), strong scaling: the 10M
-            rows sharded N ways (global ids), one forest per shard, queries replicated, per-shard
-            max_node_size = 4096 / N so that the rows scored per query -- the work of a batch -- is the same at
-            every N; one all-gather of every rank's top-k + merge kernel per batch.
-            `--workload cfg4` runs the metric's own 100M x 768 cosine config the same way (needs N >= 2;
-            per-shard max_node_size 32768 / N = 4096 at N = 8 as in BASELINE.md).
-Batches are software-pipelined two deep (zh_search_begin / finish on two contexts and streams): the small
-latency-bound kernels of batch i+1 run beside the HBM-bound sweep of batch i.  --no-pipeline times the blocking call.
-Prints ONE JSON line on rank 0.
+  N = 1  -> cfg3: 10M x 768 f32, L2 top-100, batch 1024, max_node_size 4096, num_trees 15.  The metric's own config
+            (cfg4, 100M x 768) is 307 GB and does not fit one 288 GB GPU, so the largest single-GPU config is the bench
+            line.  The same run then measures, untimed relative to `value`, the other configurations on this GPU
+            (`other_configs`: cfg2, one cfg4 shard, one cfg5 shard, the reference-default-options regime, and the N = 1
+            point of the multi-GPU series) -- each with its own roofline block.
+  N > 1  -> scale64m: 64M x 768 cosine top-10, batch 1024 (the metric's shape at the largest N that fits ONE GPU with
+            headroom), strong scaling: rows sharded N ways (global ids), one forest per shard, queries
+            replicated, per-shard max_node_size = 32768 / N (4096 at N = 8, BASELINE.md's cfg4 value; leaves stay far
+            above top_k at every N, so every point is in the one-leaf-per-tree regime and the rows scored per query --
+            the work of a batch -- is the same at every N).  Its N = 1 point is `other_configs.scale64m_n1` of the
+            N = 1 run.  `--workload cfg4` runs the metric's own 100M x 768 config the same way (N >= 2);
+            `--workload cfg3` the round-1 series (10M rows, 4096 / N).
+  --emulate-ranks N on ONE GPU: rank 0's shard of an N-rank run (rows / N, max_node_size / N) with the exchange step
+            on a one-rank RCCL communicator in the loop: the per-rank work of a series point ("per-rank, emulated").
+Batches are software-pipelined two deep: the small latency-bound kernels of batch i+1 run beside the HBM-bound sweep of
+batch i.  --no-pipeline times the blocking call.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SEED_ROWS, SEED_Q, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
 
 WORKLOADS = {
-    # name: rows (total), dim, metric, k, batch, max_node_size (total budget), trees, kind
+    # name: rows (total), dim, metric, k, batch, max_node_size (total budget over the shards), trees, kind
     "cfg1": dict(rows=10_000, dim=384, metric="cosine", k=10, batch=1, M=5, T=15, kind=0,
                  desc="10k x 384-d f32 vectors, cosine top-10, single query, reference default options (max_node_size 5)"),
     "cfg2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, batch=256, M=1024, T=15, kind=0,
@@ -49,9 +58,18 @@ WORKLOADS = {
                  desc="100M x 768-d cosine top-10, batch=1024, vectors sharded across GPUs + RCCL top-k merge"),
     "cfg5": dict(rows=1_000_000_000, dim=128, metric="l2", k=10, batch=4096, M=65536, T=15, kind=1,
                  desc="1B x 128-d SIFT-style L2 top-10, batch=4096, 8 GPUs"),
+    "scale64m": dict(rows=64_000_000, dim=768, metric="cosine", k=10, batch=1024, M=32768, T=15, kind=0,
+                     desc="64M x 768-d cosine top-10, batch=1024 (the metric's shape at the largest N that fits one GPU), "
+                          "rows sharded across GPUs + RCCL top-k merge"),
+    "refdefault": dict(rows=1_000_000, dim=384, metric="l2sq", k=10, batch=256, M=5, T=15, kind=0,
+                       desc="1M x 384-d L2^2 top-10, batch=256, the reference's DEFAULT options (max_node_size 5, lsh.rs:131-138): "
+                            "the wandering walk of DefaultTextDatabase"),
     "tiny": dict(rows=200_000, dim=768, metric="l2", k=100, batch=256, M=1024, T=15, kind=0,
                  desc="200k x 768-d L2 top-100 (debug)"),
 }
+# what the N = 1 run measures besides `value`: (key, workload, shards it is one of, steps)
+OTHER_CONFIGS = [("cfg2", "cfg2", 1, 20), ("cfg4_one_of_8_shards", "cfg4", 8, 5), ("cfg5_one_of_8_shards", "cfg5", 8, 5),
+                 ("reference_default_options", "refdefault", 1, 5), ("scale64m_n1", "scale64m", 1, 5)]
 
 
 def parse():
@@ -62,20 +80,19 @@ def parse():
     ap.add_argument("--workload", default=None, help="override: " + ",".join(WORKLOADS))
     ap.add_argument("--rows", type=int, default=None, help="override total rows (debug)")
     ap.add_argument("--max-node-size", type=int, default=None, help="override max_node_size (debug)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--batch", type=int, default=None, help="override the query batch (debug)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH CPU baseline leg (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: only the bench line's own workload")
+    ap.add_argument("--only-other", default=None, help="debug: comma list of other_configs keys to run")
     ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
-    ap.add_argument("--no-pipeline", action="store_true", help="one blocking zh_search_batch_device per step")
-    ap.add_argument("--in-flight", type=int, default=0,
-                    help="batches in flight when pipelined; default 2 (one sweeping, one in its light phases)")
-    ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority torch stream")
-    ap.add_argument("--debug-single-device", action="store_true",
-                    help="debug: all ranks on cuda:0, exchange over gloo through host copies (RCCL needs one device per rank)")
-    ap.add_argument("--debug-exchange-one-rank", action="store_true",
-                    help="debug: on ONE GPU, run the N > 1 exchange step (RCCL all-gather of the packed top-k + merge kernel) "
-                         "with a world of one rank inside the pipelined loop")
+    ap.add_argument("--no-pipeline", action="store_true", help="one blocking search call per step")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
+    ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority stream (N = 1)")
     ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
     return ap.parse_args()
 
@@ -106,228 +123,207 @@ def exact_topk(torch, X, q, k, metric, chunk=1 << 20):
     return best_i
 
 
-def cpu_baseline(wl, M_shard, seconds, za, torch, device):
-    """The oracle (a CPU *port* of the reference algorithm: the Rust crate cannot be built here) timed on
-    this box's host cores, on a bounded sample: the same dim / metric / k / max_node_size / num_trees, a
-    smaller stored set (so it fits host RAM and builds quickly) and as many 16-query batches as fit the time
-    budget.  In the one-leaf-per-tree regime the rows scored per query (~0.68 * M * T) do not depend on the
-    number of stored rows, so the per-query cost is representative."""
-    from oracle import zebra_oracle as zo
-    d, T, k = wl["dim"], wl["T"], wl["k"]
-    n_cpu = int(min(wl["rows_local"], max(8 * M_shard, 262144)))
-    X = zo.synth_rows(n_cpu, d, kind=wl["kind"])
-    # forest of the sample: built by the HIP path (bit-identical to the oracle's build, tests/test_gpu_parity.py)
-    ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX, device=device)
-    ix.append(X)
-    ix.build()
-    f = zo.Forest.from_arrays(X, M_shard, ix.get_forest())
-    ix.close()
-    om = {"cosine": zo.COSINE, "l2": zo.L2, "l2sq": zo.L2SQ}[wl["metric"]]
-    cores = zo.num_threads()
-    bq, done, t0, b0 = 16 * max(1, cores // 8), 0, time.perf_counter(), 0
-    f.search_batch(zo.synth_queries(cores, d, n_cpu, kind=wl["kind"]), k, om, zo.PARITY, nthreads=cores)  # warm
-    t0 = time.perf_counter()
-    rows = 0
-    while True:
-        Q = zo.synth_queries(bq, d, n_cpu, b0=b0, kind=wl["kind"])
-        _, _, _, st = f.search_batch(Q, k, om, zo.PARITY, nthreads=cores, stats=True)
-        rows += st.rows_scored
-        done += bq
-        b0 += bq
-        el = time.perf_counter() - t0
-        if el >= seconds or done >= 4096:
-            break
-    return {"value": done / el, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{done} queries against {n_cpu} x {d} stored rows (same metric, k={k}, max_node_size={M_shard}, "
-                      f"num_trees={T}; {rows / done:.0f} rows scored per query), {el:.1f} s on {cores} OpenMP threads"}
+def _git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return None
 
 
-def main():
-    args = parse()
-    import torch
-    import zebra_amd as za
-    from zebra_amd import sharding
+class Env:
+    """process-wide state: torch, the library mirror, rank / world, the control-plane process group"""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+    def __init__(self, args):
+        import torch
+        import zebra_amd as za
+        from zebra_amd import sharding
+        self.torch, self.za, self.sharding, self.args = torch, za, sharding, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world == 1 and args.gpus > 1:
             print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
             sys.exit(2)
-    if args.debug_single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    EX = world > 1 or args.debug_exchange_one_rank  # the exchange step (all-gather + merge) is part of a batch
-    if EX:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:
-            for key, val in (("MASTER_PORT", "29642"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
-                os.environ.setdefault(key, val)
-        if args.debug_single_device:
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # control plane only (unique id, barriers, max-over-ranks of the elapsed time): gloo on the CPU.  The data
+            # path's one collective is the ncclAllGather inside libzebra_hip.so.
             dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+            self.dist = dist
 
-    name = args.workload or "cfg3"
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def unique_id(self):
+        """rank 0's RCCL unique id, on every rank"""
+        uid = [self.za.shard_unique_id() if self.rank == 0 else None]
+        if self.dist:
+            self.dist.broadcast_object_list(uid, src=0)
+        return uid[0]
+
+
+def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_override=None, rows_override=None,
+                 batch_override=None, kind_override=None):
+    """Build rank `rank`'s shard of an S-way sharding of workload `name` on this GPU, time `steps` batches, and return
+    the result fields.  exchange: a ShardGroup is created (world ranks when S == world > 1, else ONE rank) and every
+    batch goes through zh_shard_search_* (local search + all-gather + merge)."""
+    torch, za, sharding, args, dev = env.torch, env.za, env.sharding, env.args, env.dev
     wl = dict(WORKLOADS[name])
-    if args.rows:
-        wl["rows"] = args.rows
-    if args.max_node_size:
-        wl["M"] = args.max_node_size
-    if args.data == "clustered" and wl["kind"] == 0:
-        wl["kind"] = 2
-    S = world
+    if rows_override:
+        wl["rows"] = rows_override
+    if M_override:
+        wl["M"] = M_override
+    if batch_override:
+        wl["batch"] = batch_override
+    if kind_override is not None:
+        wl["kind"] = kind_override
     first_row, rows_local = sharding.shard_rows(wl["rows"], S, rank)
-    wl["rows_local"] = rows_local
     M_shard = sharding.per_shard_max_node_size(wl["M"], S, wl["k"]) if S > 1 else wl["M"]
     d, T, k, B = wl["dim"], wl["T"], wl["k"], wl["batch"]
     metric = make_metric(za, wl["metric"], parity=True)
-    stream = torch.cuda.current_stream().cuda_stream
+    n_total = wl["rows"]
 
-    # ---- setup (untimed): synthetic rows on the device, GPU forest build -------------------------------
+    # ---- setup (untimed): synthetic rows on the device, GPU forest build ------------------------------------------
     t_setup = time.perf_counter()
-    ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=local_rank,
-                     id_base=first_row, reserve_rows=rows_local)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=env.local_rank, id_base=first_row,
+                     reserve_rows=rows_local)
     ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=first_row, kind=wl["kind"])
     t_fill = time.perf_counter() - t_setup
     ix.build()
     t_build = time.perf_counter() - t_setup - t_fill
-    n_total = wl["rows"]
+    group = None
+    if exchange:
+        real = env.world > 1 and S == env.world
+        uid = env.unique_id() if real else za.shard_unique_id()
+        group = za.ShardGroup(ix, uid, env.world if real else 1, env.rank if real else 0)
 
-    n_batches = args.steps + args.warmup
+    n_batches = steps + warmup
     queries = []
     for i in range(n_batches):
         q = torch.empty((B, d), dtype=torch.float32, device=dev)
-        za.synth_queries_device(local_rank, q.data_ptr(), n_total, B, d, b0=i * B, seed_rows=SEED_ROWS, seed_q=SEED_Q,
+        za.synth_queries_device(env.local_rank, q.data_ptr(), n_total, B, d, b0=i * B, seed_rows=SEED_ROWS, seed_q=SEED_Q,
                                 kind=wl["kind"])
         queries.append(q)
-    # one result buffer per in-flight batch: [ids B*k | keys B*k | counts B] packed so that the N > 1 exchange is ONE
-    # all-gather (B*k*16 + B*4 bytes per rank: latency-bound), merged by zh_merge_topk_packed_device on every rank
-    W = za.packed_result_words(B, k)
 
-    def make_exchange():
-        ex = dict(packed=torch.empty(W, dtype=torch.int64, device=dev))
-        ex["ids"], ex["keys"], ex["counts"] = sharding.packed_views(torch, ex["packed"], B, k)
-        if EX:
-            ex.update(g_packed=torch.empty((S, W), dtype=torch.int64, device=dev), m_ids=torch.empty((B, k), dtype=torch.int64, device=dev),
-                      m_keys=torch.empty((B, k), dtype=torch.int64, device=dev), m_counts=torch.empty(B, dtype=torch.int32, device=dev))
-        return ex
+    def make_results():
+        r = dict(ids=torch.empty((B, k), dtype=torch.int64, device=dev), keys=torch.empty((B, k), dtype=torch.int64, device=dev),
+                 counts=torch.empty(B, dtype=torch.int32, device=dev))
+        r.update(h_ids=torch.empty((B, k), dtype=torch.int64).pin_memory(), h_keys=torch.empty((B, k), dtype=torch.int64).pin_memory(),
+                 h_counts=torch.empty(B, dtype=torch.int32).pin_memory())
+        return r
 
-    def exchange(ex, stream_ptr):
-        """the one exchange step of the path: every rank's packed top-k to every rank, then the merge kernel"""
-        if args.debug_single_device:  # gloo: through the host
-            torch.cuda.synchronize()
-            hp, hg = ex["packed"].cpu(), torch.empty(ex["g_packed"].shape, dtype=torch.int64)
-            sharding.all_gather_packed(dist, hp, hg)
-            ex["g_packed"].copy_(hg)
-            torch.cuda.synchronize()
-        else:
-            sharding.all_gather_packed(dist, ex["packed"], ex["g_packed"])
-        za.merge_topk_packed_device(local_rank, S, B, k, ex["g_packed"].data_ptr(), ex["m_ids"].data_ptr(), ex["m_keys"].data_ptr(),
-                                    ex["m_counts"].data_ptr(), stream_ptr)
+    def to_host(r, stream):
+        """the span ends with the merged top-k ON THE HOST: async copies behind the last kernel"""
+        with torch.cuda.stream(stream):
+            r["h_ids"].copy_(r["ids"], non_blocking=True)
+            r["h_keys"].copy_(r["keys"], non_blocking=True)
+            r["h_counts"].copy_(r["counts"], non_blocking=True)
 
-    ex0 = make_exchange()
-    ids, keys, counts = ex0["ids"], ex0["keys"], ex0["counts"]
-
-    def step(q):
-        ix.search_batch_device(q.data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
-        if EX:
-            exchange(ex0, stream)
-
-    def barrier():
-        if EX:
-            dist.barrier()
-
-    # several batches in flight: slot = step mod NS, each slot has its own context, stream and result buffers
     pipelined = not args.no_pipeline
-    if pipelined:
-        # every batch's sweep back to back on the index's lowest-priority stream; the light work of each slot on a
-        # high-priority stream; torch's and RCCL's own streams are normal priority: three hardware-queue pools,
-        # so neither the light kernels nor the collectives are queued behind sweep launches
+    NS = max(2, args.in_flight)
+    r0 = make_results()
+    cur = torch.cuda.current_stream()
+    if group is None:
         heavy = ix.sweep_stream()
         if args.debug_normal_priority_sweeps:
             _hs = torch.cuda.Stream(device=dev, priority=0)
             heavy = _hs.cuda_stream
-        slots = []
-        NS = max(2, args.in_flight) if args.in_flight else 2
-        for _ in range(NS):
-            sl = dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1))
-            if EX:  # the exchange of a slot's batch runs on its own stream: the slot's NEXT batch must not queue behind it
-                sl.update(xstream=torch.cuda.Stream(device=dev), ev_final=torch.cuda.Event(), ev_xdone=torch.cuda.Event(), xused=False)
-            sl.update(make_exchange())
-            slots.append(sl)
+        slots = [dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1), **make_results()) for _ in range(NS)] if pipelined else []
 
-        def p_begin(i):
-            sl = slots[i % NS]
+        def begin(sl, i):
             sl["ctx"].begin(queries[i].data_ptr(), B, k, metric, sl["stream"].cuda_stream)
 
-        def p_finish(i):
-            sl = slots[i % NS]
-            if EX and sl["xused"]:  # the packed result buffer is free again once the slot's previous exchange has read it
-                sl["stream"].wait_event(sl["ev_xdone"])  # (long done: that batch finished NS batches ago)
+        def finish(sl):
             sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
-            if EX:
-                sl["ev_final"].record(sl["stream"])
-                with torch.cuda.stream(sl["xstream"]):
-                    sl["xstream"].wait_event(sl["ev_final"])
-                    exchange(sl, sl["xstream"].cuda_stream)
-                    sl["ev_xdone"].record(sl["xstream"])
-                sl["xused"] = True
+            to_host(sl, sl["stream"])
 
-        def run(first, n):
-            # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long
-            # done), finish blocks the host only until batch i's own counting pass has run -- beside the sweep of
-            # batch i-1, which is still on the GPU -- and leaves batch i's sweep queued behind it
-            for i in range(first, first + n):
-                p_begin(i)
-                p_finish(i)
-            for sl in slots:
-                sl["ctx"].wait()
-                sl["stream"].synchronize()
-                if EX:
-                    sl["xstream"].synchronize()
+        def drain(sl):
+            sl["ctx"].wait()
+            sl["stream"].synchronize()
+
+        def blocking(i):
+            ix.search_batch_device(queries[i].data_ptr(), B, k, metric, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
+                                   r0["counts"].data_ptr(), cur.cuda_stream)
+            to_host(r0, cur)
     else:
-        def run(first, n):
+        slots = []
+        for _ in range(NS if pipelined else 0):
+            sl = dict(ctx=group.search_context(), **make_results())
+            sl["stream"] = torch.cuda.ExternalStream(sl["ctx"].stream(), device=dev)  # where the merged results complete
+            slots.append(sl)
+
+        def begin(sl, i):
+            sl["ctx"].begin(queries[i].data_ptr(), B, k, metric)
+
+        def finish(sl):
+            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr())
+            to_host(sl, sl["stream"])
+
+        def drain(sl):
+            sl["ctx"].wait()
+            sl["stream"].synchronize()
+
+        def blocking(i):
+            group.search_batch_device(queries[i].data_ptr(), B, k, metric, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
+                                      r0["counts"].data_ptr())
+            to_host(r0, cur)
+
+    def run(first, n):
+        if not pipelined:
             for i in range(first, first + n):
-                step(queries[i])
+                blocking(i)
             torch.cuda.synchronize()
+            return
+        # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long done),
+        # finish blocks the host only until batch i's own counting pass has run -- beside the sweep of batch i-1, which
+        # is still on the GPU -- and leaves batch i's sweep queued behind it
+        for i in range(first, first + n):
+            sl = slots[i % NS]
+            begin(sl, i)
+            finish(sl)
+        for sl in slots:
+            drain(sl)
 
     torch.cuda.synchronize()
-    if pipelined:  # every slot allocates its scratch once, whatever --warmup is (not counted as warmup)
-        for sl in slots:
-            sl["ctx"].begin(queries[0].data_ptr(), B, k, metric, sl["stream"].cuda_stream)
-            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
-            sl["ctx"].wait()
-    if args.warmup:
-        run(0, args.warmup)
+    for sl in slots:  # every slot allocates its scratch once, whatever --warmup is (not counted as warmup)
+        begin(sl, 0)
+        finish(sl)
+        drain(sl)
+    if not pipelined:
+        blocking(0)
+    if warmup:
+        run(0, warmup)
     ix.set_profiling(1)  # hipEvents around every stage, on the stream the kernels run on
     ix.stats(reset=True)
     torch.cuda.synchronize()
-    barrier()
+    env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(warmup, steps)
     torch.cuda.synchronize()
-    barrier()
+    env.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if EX:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_single_device else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if env.dist and exchange:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ix.stats()
+    last = slots[(warmup + steps - 1) % NS] if pipelined else r0
+    last_host = (last["h_ids"].numpy().copy(), last["h_counts"].numpy().copy())
 
-    # ---- untimed: R_unique of the timed batches, recall, sanity of the last result ---------------------
+    # ---- untimed: R_unique of the timed batches -------------------------------------------------------------------
     ix.set_profiling(2)
     uniq = tot = 0
-    for i in range(min(args.steps, 4)):
+    for i in range(min(steps, 4)):
         ix.stats(reset=True)
-        ix.search_batch_device(queries[args.warmup + i].data_ptr(), B, k, metric, ids.data_ptr(), keys.data_ptr(),
-                               counts.data_ptr(), stream)
+        ix.search_batch_device(queries[warmup + i].data_ptr(), B, k, metric, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
+                               r0["counts"].data_ptr(), cur.cuda_stream)
         s2 = ix.stats()
         uniq += s2["rows_unique"]
         tot += s2["rows_scored"]
@@ -339,122 +335,251 @@ def main():
     rows_per_launch = st["sweep_rows_accum"] / n_launch
     sweep_ms = st["ms_sweep"] / n_launch
     launches_per_batch = n_launch / max(st["timed_batches"], 1)
-    # algorithmic bytes of one sweep launch (DESIGN.md "Kernels"): every distinct stored row crosses HBM once
-    # (4*d bytes), every scored row reads a 4-byte leaf id and writes an 8-byte key, plus the query batch
+    # algorithmic bytes of one sweep launch (DESIGN.md "Kernels"): every distinct stored row crosses HBM once (4*d bytes),
+    # every scored row reads a 4-byte leaf id and writes an 8-byte key, plus the query batch
     bytes_alg = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
     bytes_nosharing = (4.0 * d + 12.0) * rows_per_launch
     achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-
-    # roofline.traffic: HBM bytes per sweep launch from the rocprofv3 PMC passes of THIS command (separate
-    # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), summarised under profiles/ by
-    # profiles/summarize.py; bench.py cannot collect counters on itself, so it quotes the committed summary.
-    traffic, traffic_src = None, None
-    import glob
-    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
     kname = "sweep_kernel<%d, %d," % (d, 1 if wl["metric"] == "cosine" else 0)  # <D, KIND (0 = L2, 1 = cosine), ...>
-    if cands and name == "cfg3" and S == 1 and not args.rows:
-        try:
-            pm = json.load(open(cands[-1]))
-            traffic = [v for k_, v in pm.items() if k_.startswith(kname)][0]["hbm_bytes_per_launch"]
-            if abs(traffic / bytes_alg - 1) > 0.5:
-                traffic = None  # the committed summary is from a different launch granularity
-            traffic_src = os.path.relpath(cands[-1], ROOT)
-        except Exception:
-            traffic = None
+    roof = {"bound": "hbm", "kernel": kname + " ...>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch,
+            "unique_row_fraction": uniq_frac, "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch,
+            "launches_per_batch": launches_per_batch, "bytes_per_launch": bytes_alg,
+            "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0}
 
-    recall = recall_parity = planted = None
-    if not args.no_recall and args.recall_queries > 0:
+    out = {
+        "qps": B * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+        "config": {"workload": f"{name}: {wl['desc']}", "rows_total": n_total, "rows_per_gpu": rows_local, "dim": d,
+                   "metric": wl["metric"] + ("(parity key)" if wl["metric"] == "cosine" else ""), "top_k": k, "batch": B,
+                   "max_node_size": M_shard, "num_trees": T,
+                   "parallelism": (f"rows sharded x{S}, queries replicated, one RCCL all-gather of the packed top-k + merge per batch"
+                                   if S > 1 else "1 GPU")},
+        "roofline": roof,
+        "stage_ms_per_batch": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
+        "visits_per_batch": st["visits"], "rows_scored_per_batch": st["rows_scored"],
+        "setup_s": {"fill": t_fill, "build": t_build},
+    }
+    if group is not None:
+        out["ranks_seen"] = group.ranks()  # ncclCommCount of the communicator the exchange ran on
+
+    if recall and args.recall_queries > 0:
         nq = min(args.recall_queries, B)
         q = queries[-1][:nq]
-        got_parity = None
-        rec_metric = metric if wl["metric"] != "cosine" else make_metric(za, "cosine", parity=False)
-        def search_ids(m):
-            ix.search_batch_device(queries[-1].data_ptr(), B, k, m, ids.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
-            out = ids.clone()
-            if EX:
-                exchange(ex0, stream)
-                torch.cuda.synchronize()
-                out = ex0["m_ids"].clone()
-            return out[:nq]
 
+        def search_ids(m):
+            if group is None:
+                ix.search_batch_device(queries[-1].data_ptr(), B, k, m, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
+                                       r0["counts"].data_ptr(), cur.cuda_stream)
+            else:
+                group.search_batch_device(queries[-1].data_ptr(), B, k, m, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
+                                          r0["counts"].data_ptr())
+            torch.cuda.synchronize()
+            return r0["ids"][:nq].clone()
+
+        rec_metric = metric if wl["metric"] != "cosine" else make_metric(za, "cosine", parity=False)
         got = search_ids(rec_metric)
-        if wl["metric"] == "cosine":
-            got_parity = search_ids(metric)
-        # exact neighbours over the whole (sharded) set: local exact top-k, gathered, merged by distance
+        got_parity = search_ids(metric) if wl["metric"] == "cosine" else None
+        # exact neighbours over the whole (sharded) set: local exact top-k, gathered, re-ranked by true distance
         Xt = _wrap_rows(torch, ix, rows_local, d, dev)
-        true_local = exact_topk(torch, Xt, q, k, wl["metric"]) + first_row
-        if S > 1:
-            # re-rank the union of the shards' exact top-k by true distance
-            xdev = "cpu" if args.debug_single_device else dev
-            all_true = [torch.empty_like(true_local, device=xdev) for _ in range(S)]
-            dist.all_gather(all_true, true_local.to(xdev))
+        true_local = exact_topk(torch, Xt, q, k, "cosine" if wl["metric"] == "cosine" else "l2") + first_row
+        if env.dist and S == env.world:
+            all_true = [torch.empty_like(true_local, device="cpu") for _ in range(S)]
+            env.dist.all_gather(all_true, true_local.cpu())
             cand = torch.cat(all_true, 1).to(dev)
-            dl = _true_dist(torch, Xt, q, cand - first_row, rows_local, wl["metric"]).to(xdev)
-            dist.all_reduce(dl, op=dist.ReduceOp.MIN)
-            dl = dl.to(dev)
-            true_ids = torch.gather(cand, 1, torch.topk(dl, k, dim=1, largest=False).indices)
+            dl = _true_dist(torch, Xt, q, cand - first_row, rows_local, wl["metric"]).cpu()
+            env.dist.all_reduce(dl, op=env.dist.ReduceOp.MIN)
+            true_ids = torch.gather(cand, 1, torch.topk(dl.to(dev), k, dim=1, largest=False).indices)
         else:
             true_ids = true_local
 
         def rec(g):
-            hit = 0
             gt, tt = g.cpu().numpy(), true_ids.cpu().numpy()
-            for b in range(nq):
-                hit += len(set(gt[b].tolist()) & set(tt[b].tolist()))
-            return hit / (nq * k)
+            return sum(len(set(gt[b].tolist()) & set(tt[b].tolist())) for b in range(nq)) / (nq * k)
 
         # the planted neighbour (query = stored row + 0.3 * noise): is it among the returned ids?
         pl = np.array([_planted_row(SEED_Q, (n_batches - 1) * B + b, n_total) for b in range(nq)], dtype=np.int64)
-        planted = float((got.cpu().numpy() == pl[:, None]).any(1).mean())
-        recall = rec(got)
-        recall_parity = rec(got_parity) if got_parity is not None else recall
+        here = (pl >= first_row) & (pl < first_row + rows_local) if group is None or group.ranks() < S else np.ones(nq, bool)
+        out["planted_neighbour_hit_rate"] = float((got.cpu().numpy()[here] == pl[here, None]).any(1).mean()) if here.any() else None
+        out[f"recall_at_{k}"] = rec(got)
+        out[f"recall_at_{k}_reference_key"] = rec(got_parity) if got_parity is not None else out[f"recall_at_{k}"]
+        if S > 1 and (group is None or group.ranks() < S):
+            out["recall_note"] = "one shard of %d: recall is against this shard's rows only" % S
 
-    # PCIe-inclusive rate through the host-buffer entry point (zh_search_batch): reported beside, never as, `value`
-    host_qps = None
-    if S == 1:
-        qh = [queries[args.warmup + i % max(args.steps, 1)].cpu().numpy() for i in range(3)]
+    # sanity of the last timed batch as it arrived on the host
+    assert (last_host[1] <= k).all() and (last_host[1] > 0).all(), "empty results in the last timed batch"
+    # PCIe-inclusive rate through the host-buffer entry point: reported beside, never as, `value`
+    if group is None and S == 1:
+        qh = [queries[warmup + i % max(steps, 1)].cpu().numpy() for i in range(3)]
         ix.search_batch(qh[0], k, metric)
         th = time.perf_counter()
         for q_ in qh:
             ix.search_batch(q_, k, metric)
-        host_qps = 3 * B / (time.perf_counter() - th)
+        out["host_buffers_qps"] = 3 * B / (time.perf_counter() - th)
+    return out, ix, group, wl, M_shard
 
+
+def cpu_baselines(env, ix, wl, M_shard, seconds):
+    """The reference CPU path beside the GPU number, two legs on this box's host cores, on a bounded sample of the SAME
+    workload: the FULL stored set (rows copied back from the GPU: bit-identical to what the GPU searched) and its forest
+    (built by the HIP path, checked equal to the oracle's build in tests/), as many queries as fit `seconds`.
+      port-bitexact: the oracle itself (the checker: 256 scalar accumulators + butterfly per row, qsort per leaf, a
+                     second scoring pass) -- the algorithm with the GPU's summation order
+      port-fast:     the same algorithm written for speed (oracle/zebra_cpu_fast.cpp: SIMD dot / L2 in free summation
+                     order, nth_element, no re-score), the closer stand-in for the Rust crate + simsimd
+    Vectors and trees are held in RAM (no fjall, no bincode), which favours the CPU relative to the real reference."""
+    from oracle import zebra_cpu_fast as zf
+    from oracle import zebra_oracle as zo
+    import psutil
+    d, T, k, n = wl["dim"], wl["T"], wl["k"], len(ix)
+    own = None
+    if n * d * 4 * 1.5 > psutil.virtual_memory().available:  # a small host: a reduced stored set, stated in `sample`
+        n = int(min(n, max(8 * M_shard, 262144)))
+        own = env.za.LSHIndex(d, env.za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX, device=env.local_rank)
+        own.append_synthetic(n, seed=SEED_ROWS, first_row=0, kind=wl["kind"])
+        own.build()
+        ix = own
+    X = np.empty((n, d), np.float32)
+    step = 1 << 20
+    for s in range(0, n, step):
+        X[s:s + step] = ix.read_rows(s, min(step, n - s))
+    g = ix.get_forest()
+    if own is not None:
+        own.close()
+    full = "the full" if own is None else "a REDUCED set of"
+    n_plant = wl["rows"] if own is None else n
+    cores = zo.num_threads()
+    om = {"cosine": zo.COSINE, "l2": zo.L2, "l2sq": zo.L2SQ}[wl["metric"]]
+    legs = []
+
+    def leg(kind, search, note):
+        bq, done, b0, rows = max(cores, 16), 0, 1 << 20, 0
+        search(zo.synth_queries(cores, d, n_plant, b0=b0 - cores, kind=wl["kind"]))  # warm (threads, page faults)
+        t0 = time.perf_counter()
+        while True:
+            r = search(zo.synth_queries(bq, d, n_plant, b0=b0, kind=wl["kind"]))
+            rows += r
+            done += bq
+            b0 += bq
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 16384:
+                break
+            bq = min(bq * 2, 4096)
+        legs.append({"value": done / el, "unit": "queries/s", "cores": cores, "kind": "port", "variant": kind,
+                     "sample": f"{done} queries against {full} {n} x {d} stored rows (same metric, k={k}, max_node_size={M_shard}, "
+                               f"num_trees={T}; {rows / max(done, 1):.0f} rows scored per query), {el:.1f} s on {cores} OpenMP threads; {note}"})
+
+    f = zo.Forest.from_arrays(X, M_shard, g)
+    leg("port-bitexact", lambda Q: f.search_batch(Q, k, om, zo.PARITY, nthreads=cores, stats=True)[3].rows_scored,
+        "the oracle: GPU summation order emulated, qsort per leaf, second scoring pass")
+    ff = zf.FastForest(X, g)
+    leg("port-fast", lambda Q: ff.search_batch(Q, k, om, zo.PARITY, nthreads=cores)[3],
+        f"free summation order ({zf.isa()} build), nth_element, no second scoring pass")
+    return legs
+
+
+def pmc_traffic(args, name, S, roof):
+    """roofline.traffic: HBM bytes per sweep launch from the rocprofv3 PMC passes of THIS command (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), summarised under profiles/ by profiles/summarize.py.
+    bench.py cannot collect counters on itself: it quotes the newest committed summary, and only when that summary was
+    taken at the same launch granularity (rows per launch within 10 %); the summary's own commit travels with it."""
+    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.json")))
+    if not cands or name != "cfg3" or S != 1 or args.rows:
+        return
+    try:
+        pm = json.load(open(cands[-1]))
+        kn = roof["kernel"].split(" ...")[0]
+        ent = [v for k_, v in pm.items() if k_.startswith(kn)][0]
+        meta = pm.get("_meta", {})
+        traffic = ent["hbm_bytes_per_launch"]
+        if abs(traffic / roof["bytes_per_launch"] - 1) > 0.10:
+            return
+        roof["traffic"] = traffic
+        roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
+                                  "note": "committed PMC summary of this command (not collected by this run)"}
+    except Exception:
+        return
+
+
+def main():
+    args = parse()
+    env = Env(args)
+    torch = env.torch
+    emu = args.emulate_ranks if env.world == 1 else 0
+    S = emu or env.world
+    name = args.workload or ("cfg3" if S == 1 else "scale64m")
+    kind = 2 if args.data == "clustered" and WORKLOADS[name]["kind"] == 0 else None
+    res, ix, group, wl, M_shard = run_workload(env, name, S, env.rank if not emu else 0, args.steps, args.warmup, exchange=S > 1,
+                                               recall=not args.no_recall, M_override=args.max_node_size,
+                                               rows_override=args.rows, batch_override=args.batch, kind_override=kind)
+    pmc_traffic(args, name, S, res["roofline"])
     cpu = None
-    if rank == 0 and S == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(wl, M_shard, args.cpu_seconds, za, torch, local_rank)
+    if env.rank == 0 and S == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baselines(env, ix, wl, M_shard, args.cpu_seconds)
+    if group is not None:
+        group.close()
+    ix.close()
+    del ix
+    torch.cuda.empty_cache()
 
-    if rank == 0:
-        qps = B * args.steps / elapsed
+    other = None
+    if S == 1 and env.world == 1 and not args.no_other_configs and name == "cfg3" and not args.rows:
+        other = {}
+        only = set(args.only_other.split(",")) if args.only_other else None
+        for key, wname, shards, steps in OTHER_CONFIGS:
+            if only and key not in only:
+                continue
+            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=False)
+            ix2.close()
+            del ix2
+            torch.cuda.empty_cache()
+            other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
+                          "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
+                                                              ("kernel", "achieved", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch")},
+                          "stage_ms_per_batch": r["stage_ms_per_batch"], "visits_per_batch": r["visits_per_batch"],
+                          "rows_scored_per_batch": r["rows_scored_per_batch"]}
+        if not only or "recall_clustered" in only:
+            # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative
+            r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=2)
+            ix2.close()
+            other["recall_clustered"] = {"workload": "cfg3 shape, clustered rows", "queries_per_s_this_gpu": r["qps"],
+                                         "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")}
+
+    if env.rank == 0:
+        k = wl["k"]
         out = {
-            "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": S, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
-            "pipelined_batches_in_flight": (max(2, args.in_flight) if args.in_flight else 2) if pipelined else 1,
-            "config": {"workload": f"{name}: {wl['desc']}", "rows_total": n_total, "rows_per_gpu": rows_local,
-                       "dim": d, "metric": wl["metric"] + ("(parity key)" if wl["metric"] == "cosine" else ""),
-                       "top_k": k, "batch": B, "max_node_size": M_shard, "num_trees": T,
-                       "parallelism": f"rows sharded x{S}, queries replicated, all-gather top-k merge" if S > 1 else "1 GPU"},
-            f"recall_at_{k}": recall, f"recall_at_{k}_reference_key": recall_parity, "planted_neighbour_hit_rate": planted,
-            "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
-                         "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
-                         "bytes_per_launch": bytes_alg, "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0},
-            "cpu_baseline": cpu, "host_buffers_qps": host_qps,
-            "stage_ms_per_batch": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
+            "metric": "queries/sec", "value": res["qps"], "unit": "queries/s", "n_gpus": env.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
+            "pipelined_batches_in_flight": max(2, args.in_flight) if not args.no_pipeline else 1,
+            "timed_span": "queries resident in HBM -> merged top-k in pinned host memory (D2H inside the span)",
+            "config": res["config"],
+            f"recall_at_{k}": res.get(f"recall_at_{k}"), f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
+            "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
+            "roofline": res["roofline"], "cpu_baseline": cpu[1] if cpu else None, "cpu_baseline_bitexact": cpu[0] if cpu else None,
+            "host_buffers_qps": res.get("host_buffers_qps"), "stage_ms_per_batch": res["stage_ms_per_batch"],
             "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
-            "setup_s": {"fill": t_fill, "build": t_build},
+            "setup_s": res["setup_s"], "git_head": _git_head(),
         }
+        if "ranks_seen" in res:
+            out["ranks_seen"] = res["ranks_seen"]
+        if emu:
+            out["emulated"] = f"rank 0 of {emu}, per-rank work only; exchange on a one-rank RCCL communicator"
+            out["n_gpus"] = 1
+        if S > 1:
+            out["series_note"] = ("N > 1 default series = scale64m (64M x 768 cosine top-10, strong scaling); its N = 1 point is "
+                                  "other_configs.scale64m_n1 of the N = 1 run (whose `value` is cfg3, the largest single-GPU BASELINE config)")
+        if other is not None:
+            out["other_configs"] = other
     # RCCL writes a version banner through C stdio: every rank flushes it before the last barrier, so that rank 0's JSON
     # line is the LAST line of the job's stdout
-    import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    if EX:
-        dist.barrier()
-        dist.destroy_process_group()
+    if env.dist:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
-    if rank == 0:
+    if env.rank == 0:
         print(json.dumps(out), flush=True)
 
 

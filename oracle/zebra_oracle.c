@@ -744,6 +744,7 @@ typedef struct {
 static void ctx_init(zo_ctx *c, const zo_forest *f, const float *X, int metric, int mode) {
     memset(c, 0, sizeof *c);
     c->f = f; c->X = X; c->metric = metric; c->mode = mode;
+    if (f->n_rows > (1u << 21)) return; /* large stored sets: the candidate set as a list (no n_rows-sized arrays per thread) */
     c->stamp = calloc(f->n_rows ? f->n_rows : 1, sizeof(uint32_t));
     c->cap_cand = f->n_rows ? f->n_rows : 1;
     c->cand = malloc(c->cap_cand * sizeof(uint32_t));

@@ -1,0 +1,115 @@
+"""The multi-GPU exchange behind the C ABI (zh_shard_group_* / zh_shard_search_*: libzebra_hip.so links librccl and
+issues the ncclAllGather itself) on the one GPU of the test box: a communicator of ONE rank exercises the real RCCL
+calls (ncclGetUniqueId, ncclCommInitRank, the in-place ncclAllGather on the exchange stream, ncclCommCount) and the
+merge kernel on the gathered buffer; the multi-rank merge itself is covered by test_shard_merge_device, by the
+time-multiplexed cfg4 test (tests/test_gpu_fullsize.py) and, on the host side, by the gloo test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zebra_oracle as zo  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def za():
+    import zebra_amd
+    return zebra_amd
+
+
+def _index(za, n=6000, d=64, M=60, T=5, id_base=1_000_000):
+    X = zo.synth_rows(n, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=id_base)
+    ix.add(X)
+    return ix, X
+
+
+def test_one_rank_group_equals_local_search_and_oracle(za):
+    ix, X = _index(za)
+    g = za.ShardGroup(ix, za.shard_unique_id(), 1, 0)
+    assert g.ranks() == 1 and g.rank() == 0
+    Q = zo.synth_queries(40, 64, 6000)
+    f = zo.Forest.from_arrays(X, 60, ix.get_forest())
+    for m, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(parity=True), zo.COSINE, zo.PARITY)):
+        for k in (1, 10, 100):
+            ids, keys, counts = g.search_batch(Q, k, m)
+            li, lk, lc = ix.search_batch(Q, k, m)
+            assert (ids == li).all() and (keys == lk).all() and (counts == lc).all()
+            oi, ok, oc = f.search_batch(Q, k, om, omode)
+            assert (counts == oc).all()
+            for b in range(40):
+                c = int(oc[b])
+                assert (ids[b, :c] == oi[b, :c] + np.uint64(1_000_000)).all() and (keys[b, :c] == ok[b, :c]).all()
+                assert (ids[b, c:] == np.uint64(2**64 - 1)).all()
+    g.close()
+    ix.close()
+
+
+def test_pipelined_shard_contexts_equal_blocking_calls(za):
+    import torch
+    ix, X = _index(za, n=20000, d=128, M=256, T=6, id_base=0)
+    g = za.ShardGroup(ix, za.shard_unique_id(), 1, 0)
+    dev = torch.device("cuda", 0)
+    B, k, m = 64, 10, za.L2Distance()
+    NB, NS = 12, 3
+    Qs = [torch.from_numpy(zo.synth_queries(B, 128, 20000, b0=i * B)).to(dev) for i in range(NB)]
+    want = []
+    ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+    keys = torch.empty_like(ids)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    for q in Qs:
+        g.search_batch_device(q.data_ptr(), B, k, m, ids.data_ptr(), keys.data_ptr(), counts.data_ptr())
+        want.append((ids.cpu().numpy().copy(), keys.cpu().numpy().copy(), counts.cpu().numpy().copy()))
+    slots = [dict(ctx=g.search_context(), ids=torch.empty_like(ids), keys=torch.empty_like(keys), counts=torch.empty_like(counts)) for _ in range(NS)]
+    got = [None] * NB
+    W = za.packed_result_words(B, k)
+    for i in range(NB + NS):
+        sl = slots[i % NS]
+        if i >= NS:  # retire the batch this slot held
+            sl["ctx"].wait()
+            torch.cuda.synchronize()
+            got[i - NS] = (sl["ids"].cpu().numpy().copy(), sl["keys"].cpu().numpy().copy(), sl["counts"].cpu().numpy().copy())
+        if i < NB:
+            sl["ctx"].begin(Qs[i].data_ptr(), B, k, m)
+            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr())
+    for i in range(NB):
+        for a, b_ in zip(got[i], want[i]):
+            assert (a == b_).all(), i
+    # one rank: the rank's own packed slot holds exactly the merged answer
+    sl = slots[(NB - 1) % NS]
+    class _E:
+        pass
+    e = _E()
+    e.__cuda_array_interface__ = {"shape": (W,), "typestr": "<i8", "data": (sl["ctx"].local_result_ptr(), True), "version": 3, "strides": None}
+    packed = torch.as_tensor(e, device=dev).cpu().numpy()
+    assert (packed[:B * k].reshape(B, k) == want[NB - 1][0]).all() and (packed[B * k:2 * B * k].reshape(B, k) == want[NB - 1][1]).all()
+    for sl in slots:
+        sl["ctx"].close()
+    g.close()
+    ix.close()
+
+
+def test_group_survives_changing_batch_shapes_and_an_empty_shard(za):
+    ix, X = _index(za, n=3000, d=32, M=40, T=4, id_base=7)
+    g = za.ShardGroup(ix, za.shard_unique_id(), 1, 0)
+    m = za.L2SquaredDistance()
+    f = zo.Forest.from_arrays(X, 40, ix.get_forest())
+    for B, k in ((3, 5), (200, 50), (1, 1), (64, 200), (5, 5)):
+        Q = zo.synth_queries(B, 32, 3000, b0=B)
+        ids, keys, counts = g.search_batch(Q, k, m)
+        oi, ok, oc = f.search_batch(Q, k, zo.L2SQ)
+        assert (counts == oc).all()
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c] + np.uint64(7)).all() and (keys[b, :c] == ok[b, :c]).all()
+    g.close()
+    ix.close()
+    # a rank whose shard holds no rows still takes part in the exchange and returns no neighbours (core.rs:295-297)
+    empty = za.LSHIndex(32, za.LSHIndexOptions(40, 4))
+    g = za.ShardGroup(empty, za.shard_unique_id(), 1, 0)
+    ids, keys, counts = g.search_batch(zo.synth_queries(4, 32, 3000), 5, m)
+    assert (counts == 0).all() and (ids == np.uint64(2**64 - 1)).all()
+    with pytest.raises(za.ZhError):
+        g.search_batch(zo.synth_queries(4, 32, 3000), 5000, m)  # top_k > ZH_MAX_TOPK
+    g.close()
+    empty.close()

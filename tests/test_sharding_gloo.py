@@ -1,8 +1,10 @@
-"""The N > 1 path on CPU: two processes over the gloo backend run the same sharding / all-gather
-plumbing bench.py uses (zebra_amd/sharding.py).  No GPU here, so each rank's shard engine is the
-oracle (the checker standing in for zh_search_batch_device); what is under test is the host logic:
-row ranges, id_base, the rank-major [S,B,k] layout of the exchange, and that merging the gathered
-per-shard top-k equals the S-shard oracle run in one process (SURVEY s8e 'parity definition')."""
+"""The N > 1 path's HOST logic on CPU, two processes over the gloo backend: row ranges and id_base (zebra_amd/sharding.py),
+the packed [ids | keys | counts] buffer of zh_packed_result_words words per rank and its rank-major layout after an
+all-gather (what zh_shard_search_finish hands to the merge kernel), the control-plane calls bench.py makes
+(broadcast of the 128-byte unique id, barrier, max-over-ranks of a float64), and that merging the gathered per-shard
+top-k equals the S-shard oracle run in one process (SURVEY s8e 'parity definition').  No GPU here: each rank's shard
+engine is the oracle standing in for the local search, and gloo's all_gather stands in for the ncclAllGather that
+libzebra_hip.so issues itself on the GPU (tests/test_gpu_shard.py exercises that one with a one-rank communicator)."""
 import os
 import socket
 
@@ -48,14 +50,23 @@ def _worker(rank, world, port, out):
     g_ids = torch.empty((world, B, K), dtype=torch.int64)
     g_keys = torch.empty((world, B, K), dtype=torch.int64)
     g_counts = torch.empty((world, B), dtype=torch.int32)
-    sharding.all_gather_topk(dist, t_ids, t_keys, t_counts, g_ids, g_keys, g_counts)
-    # the packed form bench.py uses: one buffer per rank, ONE all-gather
-    W = 2 * B * K + (B + 1) // 2
+    dist.all_gather_into_tensor(g_ids.view(-1), t_ids.view(-1))
+    dist.all_gather_into_tensor(g_keys.view(-1), t_keys.view(-1))
+    dist.all_gather_into_tensor(g_counts.view(-1), t_counts.view(-1))
+    # the packed form the library exchanges: one buffer per rank, ONE all-gather (zh_packed_result_words is pure
+    # arithmetic: callable without a GPU)
+    from zebra_amd import _ffi
+    W = int(_ffi.lib().zh_packed_result_words(B, K))
+    assert W == 2 * B * K + (B + 1) // 2
+    # control plane, as bench.py: rank 0's unique id (here: any 128 bytes) reaches every rank
+    uid = [bytes(range(128)) if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    assert uid[0] == bytes(range(128))
     packed = torch.zeros(W, dtype=torch.int64)
     p_ids, p_keys, p_counts = sharding.packed_views(torch, packed, B, K)
     p_ids.copy_(t_ids), p_keys.copy_(t_keys), p_counts.copy_(t_counts)
     g_packed = torch.empty((world, W), dtype=torch.int64)
-    sharding.all_gather_packed(dist, packed, g_packed)
+    dist.all_gather_into_tensor(g_packed.view(-1), packed.view(-1))
     for r in range(world):
         a, b_, c = sharding.packed_views(torch, g_packed[r], B, K)
         assert torch.equal(a, g_ids[r]) and torch.equal(b_, g_keys[r]) and torch.equal(c, g_counts[r])

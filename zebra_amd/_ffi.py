@@ -68,6 +68,8 @@ SYMBOLS = [
     ("zh_index_count", _u64, [_vp]),
     ("zh_index_num_trees", _u32, [_vp]),
     ("zh_index_dim", _u32, [_vp]),
+    ("zh_index_device", C.c_int32, [_vp]),
+    ("zh_index_id_base", _u64, [_vp]),
     ("zh_index_rows_device", _vp, [_vp]),
     ("zh_index_sweep_stream", _vp, [_vp]),
     ("zh_index_read_rows", _i, [_vp, _u64, _sz, _vp]),
@@ -84,6 +86,20 @@ SYMBOLS = [
     ("zh_merge_topk_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("zh_packed_result_words", _sz, [_sz, _sz]),
     ("zh_merge_topk_packed_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    ("zh_shard_unique_id", _i, [_vp]),
+    ("zh_shard_group_create", _i, [_vp, _vp, _u32, _u32, _vp]),
+    ("zh_shard_group_destroy", None, [_vp]),
+    ("zh_shard_group_ranks", _u32, [_vp]),
+    ("zh_shard_group_rank", _u32, [_vp]),
+    ("zh_shard_search_batch_device", _i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _vp]),
+    ("zh_shard_search_batch", _i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _vp]),
+    ("zh_shard_ctx_create", _i, [_vp, _vp]),
+    ("zh_shard_ctx_destroy", None, [_vp]),
+    ("zh_shard_search_begin", _i, [_vp, _vp, _sz, _sz, _i, _i]),
+    ("zh_shard_search_finish", _i, [_vp, _vp, _vp, _vp]),
+    ("zh_shard_search_wait", _i, [_vp]),
+    ("zh_shard_ctx_stream", _vp, [_vp]),
+    ("zh_shard_ctx_local_result", _vp, [_vp]),
     ("zh_synth_queries_device", _i, [_i, _vp, _u64, _u64, _u64, _u64, _sz, _u32, _i, _vp]),
     ("zh_ref_forest_decode", _i, [_u32, _sz, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("zh_ref_forest_view", _i, [_vp, _vp]),

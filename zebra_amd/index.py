@@ -309,6 +309,90 @@ class SearchContext:
     __del__ = close
 
 
+UNIQUE_ID_BYTES = 128
+
+
+def shard_unique_id():
+    """rank 0: the 128-byte id every rank passes to ShardGroup (ncclGetUniqueId inside the library)"""
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    check(lib().zh_shard_unique_id(buf))
+    return bytes(buf)
+
+
+class ShardGroup:
+    """This rank's shard (an LSHIndex over its rows, id_base = its first global row) joined with the other ranks'
+    through RCCL inside libzebra_hip.so: search_batch over the WHOLE sharded index is one call per batch on every rank
+    (local search -> one all-gather of the packed top-k -> merge), the loop of core.rs:299-303 for sharded rows."""
+
+    def __init__(self, index, unique_id, n_ranks, rank):
+        self.index = index  # borrowed by the group: keep it alive
+        self._h = C.c_void_p()
+        uid = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().zh_shard_group_create(index._h, uid, n_ranks, rank, C.byref(self._h)))
+
+    def ranks(self):
+        return int(lib().zh_shard_group_ranks(self._h))
+
+    def rank(self):
+        return int(lib().zh_shard_group_rank(self._h))
+
+    def search_batch(self, queries, top_k, metric):
+        """merged global top-k of every query: (ids [b,k] u64, keys [b,k] u64, counts [b] u32)"""
+        q = _f32(queries, self.index.dim)
+        b = q.shape[0]
+        ids = np.empty((b, top_k), np.uint64)
+        keys = np.empty((b, top_k), np.uint64)
+        counts = np.zeros(b, np.uint32)
+        check(lib().zh_shard_search_batch(self._h, _p(q), b, top_k, metric.metric, metric.mode, _p(ids), _p(keys), _p(counts)))
+        return ids, keys, counts
+
+    def search_batch_device(self, d_q_ptr, b, top_k, metric, d_ids_ptr, d_keys_ptr, d_counts_ptr):
+        check(lib().zh_shard_search_batch_device(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode, d_ids_ptr,
+                                                 d_keys_ptr, d_counts_ptr))
+
+    def search_context(self):
+        return ShardContext(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zh_shard_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class ShardContext:
+    """one sharded batch in flight (zh_shard_search_begin / finish / wait) on raw device pointers"""
+
+    def __init__(self, group):
+        self._group = group
+        self._h = C.c_void_p()
+        check(lib().zh_shard_ctx_create(group._h, C.byref(self._h)))
+
+    def begin(self, d_q_ptr, b, top_k, metric):
+        check(lib().zh_shard_search_begin(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode))
+
+    def finish(self, d_ids_ptr, d_keys_ptr, d_counts_ptr):
+        check(lib().zh_shard_search_finish(self._h, d_ids_ptr, d_keys_ptr, d_counts_ptr))
+
+    def wait(self):
+        check(lib().zh_shard_search_wait(self._h))
+
+    def stream(self):
+        """raw hipStream_t the merged results complete on"""
+        return lib().zh_shard_ctx_stream(self._h)
+
+    def local_result_ptr(self):
+        return lib().zh_shard_ctx_local_result(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zh_shard_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 def merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys, d_out_counts, stream=None):
     check(lib().zh_merge_topk_device(device, n_shards, b, k, d_ids, d_keys, d_counts, d_out_ids, d_out_keys,
                                      d_out_counts, stream))

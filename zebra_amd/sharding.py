@@ -1,8 +1,8 @@
-"""Host-side logic of the multi-GPU path: one process per GPU, stored rows sharded by
-contiguous row range, one independent LSHIndex per shard (exactly how a user of the reference would
-shard, README.md:31), queries replicated, per-rank top-k exchanged with ONE all-gather (a packed
-[ids | keys | counts] buffer per rank) and merged by (key, id).  torch.distributed is plumbing only: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo"
-in the CPU tests.  The merge itself is zh_merge_topk_device (a kernel) on the GPU path."""
+"""Row-range arithmetic of the multi-GPU path: one process per GPU, stored rows sharded by contiguous row
+range, one independent LSHIndex per shard (exactly how a user of the reference would shard, README.md:31), queries
+replicated.  The exchange itself -- ONE ncclAllGather of every rank's packed [ids | keys | counts] buffer, then the
+merge kernel -- lives inside libzebra_hip.so (zh_shard_group_* / zh_shard_search_*, zebra_amd.ShardGroup); nothing here
+talks to a collective library."""
 
 
 def shard_rows(total_rows, world, rank):
@@ -21,14 +21,6 @@ def per_shard_max_node_size(total_budget, world, top_k):
     return max(total_budget // world, 2 * top_k + 2)
 
 
-def all_gather_topk(dist, ids, keys, counts, g_ids, g_keys, g_counts):
-    """ids/keys [B,k] int64, counts [B] int32 of this rank -> [S,B,k] / [S,B] of all ranks, rank-major.
-    Three small collectives (B*k*16 bytes + B*4 per rank: latency-bound on xGMI, not bandwidth-bound)."""
-    dist.all_gather_into_tensor(g_ids.view(-1), ids.view(-1))
-    dist.all_gather_into_tensor(g_keys.view(-1), keys.view(-1))
-    dist.all_gather_into_tensor(g_counts.view(-1), counts.view(-1))
-
-
 def packed_views(torch, packed, b, k):
     """packed: int64 tensor of packed_result_words(b, k) words -> (ids [b,k] i64, keys [b,k] i64, counts [b] i32) views,
     the three sections a rank's search writes into so that ONE all-gather of `packed` carries everything"""
@@ -36,8 +28,3 @@ def packed_views(torch, packed, b, k):
     keys = packed[b * k: 2 * b * k].view(b, k)
     counts = packed[2 * b * k:].view(torch.int32)[:b]
     return ids, keys, counts
-
-
-def all_gather_packed(dist, packed, g_packed):
-    """packed [W] int64 of this rank -> g_packed [S, W] of all ranks, rank-major: the batch's one exchange step"""
-    dist.all_gather_into_tensor(g_packed.view(-1), packed.view(-1))
