@@ -33,7 +33,6 @@ import ctypes
 import glob
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -121,13 +120,6 @@ def exact_topk(torch, X, q, k, metric, chunk=1 << 20):
         o = torch.topk(cv, k, dim=1, largest=False)
         best_v, best_i = o.values, torch.gather(ci, 1, o.indices)
     return best_i
-
-
-def _git_head():
-    try:
-        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
-    except Exception:
-        return None
 
 
 class Env:
@@ -251,22 +243,27 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                    r0["counts"].data_ptr(), cur.cuda_stream)
             to_host(r0, cur)
     else:
-        slots = []
-        for _ in range(NS if pipelined else 0):
-            sl = dict(ctx=group.search_context(), **make_results())
-            sl["stream"] = torch.cuda.ExternalStream(sl["ctx"].stream(), device=dev)  # where the merged results complete
-            slots.append(sl)
+        # The merged results complete on a stream the LIBRARY owns (zh_shard_ctx_stream).  The D2H copies go behind it with
+        # hipMemcpyAsync on the raw handle -- not through a torch stream wrapper: torch's pinned-memory allocator records
+        # events on every stream a pinned block was used on when the block is freed, i.e. after the library destroyed it.
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        slots = [dict(ctx=group.search_context(), **make_results()) for _ in range(NS if pipelined else 0)]
 
         def begin(sl, i):
             sl["ctx"].begin(queries[i].data_ptr(), B, k, metric)
 
         def finish(sl):
             sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr())
-            to_host(sl, sl["stream"])
+            xs = sl["ctx"].stream()
+            for h, dsrc in ((sl["h_ids"], sl["ids"]), (sl["h_keys"], sl["keys"]), (sl["h_counts"], sl["counts"])):
+                rc = hip.hipMemcpyAsync(h.data_ptr(), dsrc.data_ptr(), h.numel() * h.element_size(), 2, xs)  # hipMemcpyDeviceToHost
+                assert rc == 0, rc
 
         def drain(sl):
             sl["ctx"].wait()
-            sl["stream"].synchronize()
+            assert hip.hipStreamSynchronize(sl["ctx"].stream()) == 0
 
         def blocking(i):
             group.search_batch_device(queries[i].data_ptr(), B, k, metric, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
@@ -559,7 +556,7 @@ def main():
             "roofline": res["roofline"], "cpu_baseline": cpu[1] if cpu else None, "cpu_baseline_bitexact": cpu[0] if cpu else None,
             "host_buffers_qps": res.get("host_buffers_qps"), "stage_ms_per_batch": res["stage_ms_per_batch"],
             "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
-            "setup_s": res["setup_s"], "git_head": _git_head(),
+            "setup_s": res["setup_s"],
         }
         if "ranks_seen" in res:
             out["ranks_seen"] = res["ranks_seen"]

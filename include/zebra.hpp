@@ -1,7 +1,7 @@
 // zebra.hpp -- C++17 host-side mirror of the reference crate's interface for the hot path, over the C ABI
 // of zebra_hip.h.  The reference is Rust; no Rust toolchain exists in the build image, so the host layer
 // above the ABI is written in C++ with the crate's names, argument meaning and error behaviour
-// (anyhow::Result<T> -> zebra::Error thrown; query_vectors swallowing search errors is kept, core.rs:303).
+// (anyhow::Result<T> -> zebra::Error thrown).
 //
 //   reference                                   here
 //   Embedding<N>            src/lib.rs:15-46                     zebra::Embedding<N>
@@ -234,18 +234,15 @@ class Database {
         index.clear();
         documents_.clear();
     }
-    // core.rs:290-313: query index -> {id -> document}; order and distances are dropped (core.rs:304-305);
-    // a failing search yields an empty entry (unwrap_or_default, core.rs:303)
+    // core.rs:290-313: query index -> {id -> document}; order and distances are dropped (core.rs:304-305).
+    // core.rs:303's unwrap_or_default turns a PER-QUERY search failure into an empty entry; here a batch is one call that
+    // has no per-query failure mode (over-long batches are split inside zh_search_batch), so a library error -- out of
+    // memory, no device, top_k > ZH_MAX_TOPK -- is thrown like in the Python mirror, never reported as "no neighbours"
     std::map<std::size_t, std::map<Id, std::string>> query_vectors(const std::vector<Embedding<N>> &vectors,
                                                                    std::size_t number_of_results) const {
         std::map<std::size_t, std::map<Id, std::string>> results;
         if (index.no_vectors()) return results;  // core.rs:295-297
-        std::vector<std::vector<std::pair<Id, DistanceUnit>>> nb;
-        try {
-            nb = index.search_batch(vectors, number_of_results, metric_);
-        } catch (const Error &) {
-            nb.assign(vectors.size(), {});
-        }
+        const auto nb = index.search_batch(vectors, number_of_results, metric_);
         for (std::size_t i = 0; i < nb.size(); i++) {
             auto &m = results[i];
             for (auto &p : nb[i]) {

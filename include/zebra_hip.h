@@ -91,6 +91,7 @@ typedef enum zh_cosine_mode { ZH_COSINE_PARITY = 0, ZH_COSINE_CORRECTED = 1 } zh
 
 #define ZH_MAX_TOPK 1024u
 #define ZH_MAX_DEPTH 60u /* the reference recurses without bound on an unsplittable node */
+#define ZH_MAX_DIM (1u << 20) /* zh_options.dim beyond this is refused with ZH_ELIMIT (row offsets stay far below 2^63) */
 
 typedef struct zh_options {
     uint32_t dim;           /* N of Embedding<N>, lib.rs:18 */

@@ -80,7 +80,7 @@ def test_pipelined_shard_contexts_equal_blocking_calls(za):
     class _E:
         pass
     e = _E()
-    e.__cuda_array_interface__ = {"shape": (W,), "typestr": "<i8", "data": (sl["ctx"].local_result_ptr(), True), "version": 3, "strides": None}
+    e.__cuda_array_interface__ = {"shape": (W,), "typestr": "<i8", "data": (sl["ctx"].local_result_ptr(), False), "version": 3, "strides": None}
     packed = torch.as_tensor(e, device=dev).cpu().numpy()
     assert (packed[:B * k].reshape(B, k) == want[NB - 1][0]).all() and (packed[B * k:2 * B * k].reshape(B, k) == want[NB - 1][1]).all()
     for sl in slots:

@@ -142,6 +142,7 @@ struct zh_index {
     zh_search_ctx dctx;
     DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
 
+    bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
@@ -199,6 +200,7 @@ extern "C" void zh_options_default(zh_options *o) {
 extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
     if (!opt || !out) return fail(ZH_EINVAL, "zh_index_create: null argument");
     if (opt->dim == 0) return fail(ZH_EINVAL, "zh_index_create: dim must be > 0");
+    if (opt->dim > ZH_MAX_DIM) return fail(ZH_ELIMIT, "zh_index_create: dim %u > ZH_MAX_DIM (%u)", opt->dim, ZH_MAX_DIM);
     if (opt->num_trees > 4096) return fail(ZH_ELIMIT, "zh_index_create: num_trees > 4096");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -277,6 +279,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     if (rc) return rc;
     hipStreamSynchronize(ix->stream);
     free_forest(ix);
+    ix->broken = false;
     ix->n_rows = 0;
     ix->h_dead.clear();
     ix->n_dead = 0;
@@ -300,9 +303,7 @@ static int grow_rows(zh_index *ix, size_t n_more) {
     return ix->X.ensure(need, true, ix->stream);
 }
 
-extern "C" int zh_index_append(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
-    if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_append: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+static int append_locked(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
     int rc = set_device(ix);
     if (rc) return rc;
     if ((rc = grow_rows(ix, n))) return rc;
@@ -314,6 +315,11 @@ extern "C" int zh_index_append(zh_index *ix, const float *rows, size_t n, uint64
     if (out_ids) for (size_t i = 0; i < n; i++) out_ids[i] = ix->opt.id_base + ix->n_rows + i;
     ix->n_rows += n;
     return ZH_OK;
+}
+extern "C" int zh_index_append(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
+    if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_append: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return append_locked(ix, rows, n, out_ids);
 }
 
 extern "C" int zh_index_read_rows(zh_index *ix, uint64_t first, size_t n, float *out) {
@@ -605,6 +611,7 @@ static int build_forest_locked(zh_index *ix) {
     int rc;
     hipStreamSynchronize(ix->stream);
     free_forest(ix);
+    ix->broken = false;
     if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
     const uint64_t NL = N - ix->n_dead;  // removed rows stay out of a rebuild (their vectors may still be sampled)
     const uint64_t total = (uint64_t)T * NL;
@@ -754,16 +761,27 @@ extern "C" int zh_index_build(zh_index *ix) {
 }
 
 extern "C" int zh_index_add(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
-    if (!ix) return fail(ZH_EINVAL, "null index");
+    if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_add: null argument");
     if (ix->opt.max_node_size == 0) return fail(ZH_EINVAL, "max_node_size must be >= 1");
+    std::lock_guard<std::mutex> lk(ix->mu);  // one critical section: state is read, rows stored and trees updated under it
+    if (ix->broken) return fail(ZH_ESTATE, "an earlier add failed half way: call zh_index_build before adding or searching");
     const bool had_trees = ix->n_trees != 0;  // lsh.rs:441: no_trees() decides between build_index and insert
     const uint64_t n_prev = ix->n_rows;
-    int rc = zh_index_append(ix, rows, n, out_ids);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if ((rc = set_device(ix))) return rc;
-    if (!had_trees) return build_forest_locked(ix);  // lsh.rs:441-443
-    return insert_rows_locked(ix, n_prev, n);        // lsh.rs:445-462
+    // capacity checks BEFORE anything is mutated: the rows, and (incremental path) the leaf entries of the new rows
+    if (n_prev + n > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "more than 2^32-1 rows in one index (shard it)");
+    if ((uint64_t)ix->opt.num_trees * (n_prev + n) > 0xFFFFFFFFull)
+        return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
+    if (had_trees && n * (uint64_t)ix->n_trees > 0x7FFFFFFFull) return fail(ZH_ELIMIT, "too many rows in one add call");
+    int rc = append_locked(ix, rows, n, out_ids);
+    if (rc) return rc;  // nothing changed
+    if (!had_trees) return build_forest_locked(ix);  // lsh.rs:441-443; on failure: rows stored, no trees (a consistent state)
+    rc = insert_rows_locked(ix, n_prev, n);          // lsh.rs:445-462
+    if (rc) {
+        // the host mirrors of the trees may be ahead of the device copy: the rows stay stored (their ids were handed out),
+        // the forest is declared stale until zh_index_build rebuilds it; searches say so instead of missing rows silently
+        ix->broken = true;
+    }
+    return rc;
 }
 
 // LSHIndex::remove (lsh.rs:473-503) as it is meant: the reference only edits trees whose root is a leaf, so an id
@@ -1011,6 +1029,7 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
     int rc;
     if (c->state == 1) return fail(ZH_ESTATE, "zh_search_begin: the context already has a batch begun; finish it first");
+    if (ix->broken) return fail(ZH_ESTATE, "an earlier zh_index_add failed half way: call zh_index_build before searching");
     if (c->state == 2 && (rc = ctx_wait(c))) return rc;  // the previous batch was never waited for: retire it
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
@@ -1187,12 +1206,39 @@ int ctx_wait(zh_search_ctx *c) {
     return ZH_OK;
 }
 
-static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
-                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+static int search_once(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
+                       uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
     int rc = ctx_begin(&ix->dctx, dQ, B, k, metric, mode, s);
     if (rc) return rc;
     if ((rc = ctx_finish(&ix->dctx, dOutIds, dOutKeys, dOutCounts, nullptr))) return rc;
     return ctx_wait(&ix->dctx);
+}
+
+// The blocking entry points take any batch: a batch that would pass a per-launch limit (batch * num_trees < 2^26 pairs,
+// <= 2^28 - 1 leaf visits, < 2^36 scored rows -- reached by a few thousand queries under the reference's default options,
+// where a query visits ~10^4..10^5 leaves) is split into sub-batches whose outputs land side by side.  The
+// first split is sized from the visits per pair seen so far; a sub-batch that still overflows is halved and retried.
+static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
+                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    const uint32_t T = ix->n_trees, d = ix->opt.dim;
+    if (B == 0 || T == 0) return search_once(ix, dQ, B, k, metric, mode, dOutIds, dOutKeys, dOutCounts, s);
+    size_t chunk = std::min<size_t>(B, ((1ull << 26) - 1) / T);
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        if (ix->visits_per_pair > 0) {
+            const double per_query = ix->visits_per_pair * T;
+            chunk = std::min<size_t>(chunk, (size_t)std::max(1.0, (double)(1ull << 27) / per_query));  // half the cap: headroom
+        }
+    }
+    if (chunk == 0) chunk = 1;
+    for (size_t b0 = 0; b0 < B;) {
+        const size_t nb = std::min(chunk, B - b0);
+        const int rc = search_once(ix, dQ + b0 * d, nb, k, metric, mode, dOutIds + b0 * k, dOutKeys + b0 * k, dOutCounts + b0, s);
+        if (rc == ZH_ELIMIT && nb > 1) { chunk = (nb + 1) / 2; continue; }  // the context is idle again: retry smaller
+        if (rc) return rc;
+        b0 += nb;
+    }
+    return ZH_OK;
 }
 
 static int check_metric(int metric, int mode) {

@@ -111,34 +111,39 @@ hipError_t zh_launch_iota_perm(uint32_t *dPerm, uint64_t N, uint32_t T, hipStrea
         hipLaunchKernelGGL(KERNEL, dim3((uint32_t)nb_), dim3(THREADS), SHMEM, STREAM, __VA_ARGS__, (uint32_t)b0_); \
     }
 
-// lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 (sequential fma chain)
+// lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 (sequential fma chain).  The vector is
+// staged through LDS MP_TILE elements at a time (a fixed 32 KB, any dimension): the block fills a tile, thread 0 runs
+// the next MP_TILE links of the chain.
+#define MP_TILE 4096
 __global__ __launch_bounds__(256) void make_planes_kernel(const float *__restrict__ X, uint32_t d,
                                                            const ZhBuildNode *__restrict__ nodes,
                                                            float *__restrict__ planes, float *__restrict__ consts,
                                                            uint32_t block0) {
-    extern __shared__ float sm[];  // w[d], p[d]
-    float *w = sm, *p = sm + d;
+    __shared__ float w[MP_TILE], p[MP_TILE];
     const ZhBuildNode nd = nodes[blockIdx.x + block0];
     const float *a = nd.sample_a == ~0ull ? nullptr : X + (size_t)nd.sample_a * d;
     const float *b = nd.sample_b == ~0ull ? nullptr : X + (size_t)nd.sample_b * d;
-    for (uint32_t k = threadIdx.x; k < d; k += blockDim.x) {
-        float av = a ? a[k] : 0.0f, bv = b ? b[k] : 0.0f;
-        float wk = bv - av;
-        w[k] = wk;
-        p[k] = (av + bv) / 2.0f;
-        planes[(size_t)nd.plane * d + k] = wk;
+    float acc = 0.0f;
+    for (uint32_t k0 = 0; k0 < d; k0 += MP_TILE) {  // block-uniform
+        const uint32_t kc = d - k0 < MP_TILE ? d - k0 : MP_TILE;
+        for (uint32_t k = threadIdx.x; k < kc; k += blockDim.x) {
+            float av = a ? a[k0 + k] : 0.0f, bv = b ? b[k0 + k] : 0.0f;
+            float wk = bv - av;
+            w[k] = wk;
+            p[k] = (av + bv) / 2.0f;
+            planes[(size_t)nd.plane * d + k0 + k] = wk;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t k = 0; k < kc; k++) acc = __builtin_fmaf(w[k], p[k], acc);
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < d; k++) acc = __builtin_fmaf(w[k], p[k], acc);
-        consts[nd.plane] = -acc;
-    }
+    if (threadIdx.x == 0) consts[nd.plane] = -acc;
 }
 hipError_t zh_launch_make_planes(const float *dX, uint32_t d, const ZhBuildNode *dNodes, uint32_t n_nodes,
                                  float *dPlanes, float *dConsts, hipStream_t s) {
     if (!n_nodes) return hipSuccess;
-    ZH_SLICED(make_planes_kernel, n_nodes, 256, 2 * d * sizeof(float), s, dX, d, dNodes, dPlanes, dConsts)
+    ZH_SLICED(make_planes_kernel, n_nodes, 256, 0, s, dX, d, dNodes, dPlanes, dConsts)
     return hipGetLastError();
 }
 
