@@ -89,6 +89,8 @@ def parse():
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking search call per step")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined")
+    ap.add_argument("--window", type=int, default=1,
+                    help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority stream (N = 1)")
@@ -218,6 +220,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     pipelined = not args.no_pipeline
     NS = max(2, args.in_flight)
+    WIN = max(1, args.window) if pipelined else 1
     r0 = make_results()
     cur = torch.cuda.current_stream()
     if group is None:
@@ -225,14 +228,19 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         if args.debug_normal_priority_sweeps:
             _hs = torch.cuda.Stream(device=dev, priority=0)
             heavy = _hs.cuda_stream
-        slots = [dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1), **make_results()) for _ in range(NS)] if pipelined else []
+        slots = [dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1), res=[make_results() for _ in range(WIN)])
+                 for _ in range(NS)] if pipelined else []
 
-        def begin(sl, i):
-            sl["ctx"].begin(queries[i].data_ptr(), B, k, metric, sl["stream"].cuda_stream)
+        def begin(sl, i, nw):
+            sl["nw"] = nw
+            sl["ctx"].begin_window([queries[i + j].data_ptr() for j in range(nw)], B, k, metric, sl["stream"].cuda_stream)
 
         def finish(sl):
-            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr(), heavy)
-            to_host(sl, sl["stream"])
+            rs = sl["res"][:sl["nw"]]
+            sl["ctx"].finish_window([r["ids"].data_ptr() for r in rs], [r["keys"].data_ptr() for r in rs],
+                                    [r["counts"].data_ptr() for r in rs], heavy)
+            for r in rs:
+                to_host(r, sl["stream"])
 
         def drain(sl):
             sl["ctx"].wait()
@@ -249,17 +257,21 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         hip = ctypes.CDLL("libamdhip64.so.7")
         hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
-        slots = [dict(ctx=group.search_context(), **make_results()) for _ in range(NS if pipelined else 0)]
+        slots = [dict(ctx=group.search_context(), res=[make_results() for _ in range(WIN)]) for _ in range(NS if pipelined else 0)]
 
-        def begin(sl, i):
-            sl["ctx"].begin(queries[i].data_ptr(), B, k, metric)
+        def begin(sl, i, nw):
+            sl["nw"] = nw
+            sl["ctx"].begin_window([queries[i + j].data_ptr() for j in range(nw)], B, k, metric)
 
         def finish(sl):
-            sl["ctx"].finish(sl["ids"].data_ptr(), sl["keys"].data_ptr(), sl["counts"].data_ptr())
+            rs = sl["res"][:sl["nw"]]
+            sl["ctx"].finish_window([r["ids"].data_ptr() for r in rs], [r["keys"].data_ptr() for r in rs],
+                                    [r["counts"].data_ptr() for r in rs])
             xs = sl["ctx"].stream()
-            for h, dsrc in ((sl["h_ids"], sl["ids"]), (sl["h_keys"], sl["keys"]), (sl["h_counts"], sl["counts"])):
-                rc = hip.hipMemcpyAsync(h.data_ptr(), dsrc.data_ptr(), h.numel() * h.element_size(), 2, xs)  # hipMemcpyDeviceToHost
-                assert rc == 0, rc
+            for r in rs:
+                for h, dsrc in ((r["h_ids"], r["ids"]), (r["h_keys"], r["keys"]), (r["h_counts"], r["counts"])):
+                    rc = hip.hipMemcpyAsync(h.data_ptr(), dsrc.data_ptr(), h.numel() * h.element_size(), 2, xs)  # hipMemcpyDeviceToHost
+                    assert rc == 0, rc
 
         def drain(sl):
             sl["ctx"].wait()
@@ -279,16 +291,20 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long done),
         # finish blocks the host only until batch i's own counting pass has run -- beside the sweep of batch i-1, which
         # is still on the GPU -- and leaves batch i's sweep queued behind it
-        for i in range(first, first + n):
-            sl = slots[i % NS]
-            begin(sl, i)
+        i, w = first, 0
+        while i < first + n:
+            sl = slots[w % NS]
+            nw = min(WIN, first + n - i)
+            begin(sl, i, nw)
             finish(sl)
+            i += nw
+            w += 1
         for sl in slots:
             drain(sl)
 
     torch.cuda.synchronize()
     for sl in slots:  # every slot allocates its scratch once, whatever --warmup is (not counted as warmup)
-        begin(sl, 0)
+        begin(sl, 0, min(WIN, n_batches))
         finish(sl)
         drain(sl)
     if not pipelined:
@@ -311,16 +327,22 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ix.stats()
-    last = slots[(warmup + steps - 1) % NS] if pipelined else r0
+    last = slots[((steps + WIN - 1) // WIN - 1) % NS]["res"][(steps - 1) % WIN] if pipelined else r0
     last_host = (last["h_ids"].numpy().copy(), last["h_counts"].numpy().copy())
 
-    # ---- untimed: R_unique of the timed batches -------------------------------------------------------------------
+    # ---- untimed: R_unique of the timed batches (per internal batch = per window: a row shared by two batches of a window
+    # counts once, so `achieved` never exceeds what the kernel really moved) ---------------------------------------
     ix.set_profiling(2)
     uniq = tot = 0
-    for i in range(min(steps, 4)):
+    for i in range(max(1, min(steps // WIN, 4))):
         ix.stats(reset=True)
-        ix.search_batch_device(queries[warmup + i].data_ptr(), B, k, metric, r0["ids"].data_ptr(), r0["keys"].data_ptr(),
-                               r0["counts"].data_ptr(), cur.cuda_stream)
+        if pipelined:
+            begin(slots[0], warmup + i * WIN, min(WIN, steps - i * WIN))
+            finish(slots[0])
+            drain(slots[0])
+        else:
+            blocking(warmup + i)
+            torch.cuda.synchronize()
         s2 = ix.stats()
         uniq += s2["rows_unique"]
         tot += s2["rows_scored"]
@@ -331,7 +353,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     n_launch = max(st["sweep_launches_accum"], 1)
     rows_per_launch = st["sweep_rows_accum"] / n_launch
     sweep_ms = st["ms_sweep"] / n_launch
-    launches_per_batch = n_launch / max(st["timed_batches"], 1)
+    n_timed = max(st["timed_batches"], 1) * (WIN if steps >= WIN else 1)  # the library counts internal batches = windows
+    launches_per_batch = n_launch / n_timed
     # algorithmic bytes of one sweep launch (DESIGN.md "Kernels"): every distinct stored row crosses HBM once (4*d bytes),
     # every scored row reads a 4-byte leaf id and writes an 8-byte key, plus the query batch
     bytes_alg = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
@@ -352,8 +375,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                    "parallelism": (f"rows sharded x{S}, queries replicated, one RCCL all-gather of the packed top-k + merge per batch"
                                    if S > 1 else "1 GPU")},
         "roofline": roof,
-        "stage_ms_per_batch": {s_: st["ms_" + s_] / max(st["timed_batches"], 1) for s_ in ("hash", "walk", "sweep", "select", "final")},
-        "visits_per_batch": st["visits"], "rows_scored_per_batch": st["rows_scored"],
+        "stage_ms_per_batch": {s_: st["ms_" + s_] / n_timed for s_ in ("hash", "walk", "sweep", "select", "final")},
+        "visits_per_batch": st["visits"] / max(st["window_batches"], 1), "rows_scored_per_batch": st["rows_scored"] / max(st["window_batches"], 1),
+        "window_batches": WIN,
         "setup_s": {"fill": t_fill, "build": t_build},
     }
     if group is not None:
@@ -479,7 +503,7 @@ def pmc_traffic(args, name, S, roof):
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), summarised under profiles/ by profiles/summarize.py.
     bench.py cannot collect counters on itself: it quotes the newest committed summary, and only when that summary was
     taken at the same launch granularity (rows per launch within 10 %); the summary's own commit travels with it."""
-    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.json")))
+    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3_pmc.json")))
     if not cands or name != "cfg3" or S != 1 or args.rows:
         return
     try:
@@ -488,11 +512,15 @@ def pmc_traffic(args, name, S, roof):
         ent = [v for k_, v in pm.items() if k_.startswith(kn)][0]
         meta = pm.get("_meta", {})
         traffic = ent["hbm_bytes_per_launch"]
+        # the PMC passes run the blocking call, where the last launch of a batch is partial: compare per ROW
+        prof_rows = ((meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}).get("rows_per_launch")
+        if prof_rows and abs(prof_rows / roof["rows_per_launch"] - 1) > 0.10:
+            return  # collected at another launch granularity
         if abs(traffic / roof["bytes_per_launch"] - 1) > 0.10:
             return
         roof["traffic"] = traffic
         roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
-                                  "note": "committed PMC summary of this command (not collected by this run)"}
+                                  "note": "committed PMC summary of this command (separate rocprofv3 --pmc passes; not collected by this run)"}
     except Exception:
         return
 

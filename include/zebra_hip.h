@@ -139,6 +139,7 @@ typedef struct zh_stats_t {
     uint64_t sweep_rows_accum;  /* rows_scored summed over the timed batches */
     uint64_t swept_rows_accum;  /* rows_swept summed over the timed batches */
     uint64_t sweep_launches_accum; /* sweep_kernel launches over the timed batches (a batch is several launches) */
+    uint64_t window_batches;    /* API batches handled together in the most recent internal batch (zh_search_begin_window) */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -220,6 +221,17 @@ ZH_API void *zh_index_sweep_stream(const zh_index *idx);
 ZH_API int zh_search_finish(zh_search_ctx *ctx, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts,
                      void *sweep_stream);
 ZH_API int zh_search_wait(zh_search_ctx *ctx);
+/* A WINDOW: n_batches batches (same b, k and metric; queries at n_batches device pointers) handled as ONE internal batch.
+ * The walk, the leaf groups and the sweep span the whole window, so a stored row crosses HBM once per group of queries of
+ * the WINDOW that score it -- with b << leaves per tree, two batches share rows a single batch cannot -- and the light
+ * kernels are launched once per window.  Results are delivered per batch (n_batches output pointers each), bit-identical
+ * to n_batches separate calls; the price is latency: no batch of the window completes before the whole window has.
+ * zh_search_wait as for a single batch.  The counters of zh_stats then describe the window (batch = n_batches * b). */
+#define ZH_MAX_WINDOW 64u
+ZH_API int zh_search_begin_window(zh_search_ctx *ctx, const float *const *d_q, size_t n_batches, size_t b, size_t k, int metric,
+                                  int cosine_mode, void *stream);
+ZH_API int zh_search_finish_window(zh_search_ctx *ctx, uint64_t *const *d_out_ids, uint64_t *const *d_out_keys,
+                                   uint32_t *const *d_out_counts, void *sweep_stream);
 
 /* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers). */
 ZH_API int zh_distance_batch(int metric, int cosine_mode, const float *a, const float *q, size_t n, size_t dim,
@@ -279,6 +291,11 @@ ZH_API void zh_shard_ctx_destroy(zh_shard_ctx *ctx);
 ZH_API int zh_shard_search_begin(zh_shard_ctx *ctx, const float *d_q, size_t b, size_t k, int metric, int cosine_mode);
 ZH_API int zh_shard_search_finish(zh_shard_ctx *ctx, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts);
 ZH_API int zh_shard_search_wait(zh_shard_ctx *ctx);
+/* windows, as zh_search_begin_window / zh_search_finish_window: one all-gather and one merge per window */
+ZH_API int zh_shard_search_begin_window(zh_shard_ctx *ctx, const float *const *d_q, size_t n_batches, size_t b, size_t k,
+                                        int metric, int cosine_mode);
+ZH_API int zh_shard_search_finish_window(zh_shard_ctx *ctx, uint64_t *const *d_out_ids, uint64_t *const *d_out_keys,
+                                         uint32_t *const *d_out_counts);
 ZH_API void *zh_shard_ctx_stream(const zh_shard_ctx *ctx);
 /* this rank's own (unmerged) packed result of the context's last finished batch: zh_packed_result_words(b, k) words */
 ZH_API const uint64_t *zh_shard_ctx_local_result(const zh_shard_ctx *ctx);

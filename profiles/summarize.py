@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs that gpurun merged into gpurun_out/ into the small summaries committed here.
+"""Turns rocprofv3 outputs into the small summaries committed under profiles/.
 
-  python profiles/summarize.py r01 gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
-
-Commands that produced the inputs (on the MI355X box, one per pass, as MI355X_MICROARCH.md prescribes):
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-recall
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-recall
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-recall
+  on the GPU box (called by profiles/collect.sh, per configuration):
+      python3 profiles/summarize.py --box gpurun_out/prof_r02/cfg3 gpurun_out/prof_r02/cfg3.summary.json
+  in the container, after gpurun merged gpurun_out/ back:
+      python profiles/summarize.py r02 <commit>
+  -> profiles/r02_<config>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the (pipelined) command
+     profiles/r02_<config>_pmc.json           per kernel: FETCH_SIZE / WRITE_SIZE (and SQ / MFMA counters where collected),
+                                              HBM bytes per launch, the command, and the commit they were collected at
 Units/corrections: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of a
 16-B-per-lane coalesced streaming read (MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024.
 """
@@ -18,45 +19,79 @@ import os
 import shutil
 import sys
 
-tag, d_stats, d_fetch, d_write = sys.argv[1:5]
-d_mfma = sys.argv[5] if len(sys.argv) > 5 else None
-here = os.path.dirname(os.path.abspath(__file__))
-stats = glob.glob(os.path.join(d_stats, "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
+
+def kname(s):
+    return s.split("(")[0].replace("void ", "")
 
 
-def agg(d):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-    a = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        a[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(
-            (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    return {k: {"launches": len(v), "avg_value_KiB": sum(x[0] for x in v) / len(v),
-                "avg_ns_under_pmc": sum(x[1] for x in v) / len(v)} for k, v in a.items()}
-
-
-fetch, write = agg(d_fetch), agg(d_write)
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    f, w = fetch.get(k), write.get(k)
-    out[k] = {"launches": (f or w)["launches"],
-              "FETCH_SIZE_KiB_raw": f and f["avg_value_KiB"], "WRITE_SIZE_KiB": w and w["avg_value_KiB"],
-              "read_bytes_corrected_x2": f and 2 * f["avg_value_KiB"] * 1024, "write_bytes": w and w["avg_value_KiB"] * 1024,
-              "hbm_bytes_per_launch": (2 * f["avg_value_KiB"] * 1024 if f else 0) + (w["avg_value_KiB"] * 1024 if w else 0),
-              "avg_ns_under_pmc": (f or w)["avg_ns_under_pmc"]}
-json.dump(out, open(os.path.join(here, f"{tag}_pmc_hbm_bytes.json"), "w"), indent=1)
-
-if d_mfma:  # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace ...
-    f = glob.glob(os.path.join(d_mfma, "**", "*counter_collection.csv"), recursive=True)[0]
+def agg_counters(d):
+    fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        return {}
     a = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    for r in csv.DictReader(open(fs[0])):
+        k = kname(r["Kernel_Name"])
         a[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        a[k]["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    m = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in a.items()}
-    json.dump(m, open(os.path.join(here, f"{tag}_pmc_mfma.json"), "w"), indent=1)
-    for k, v in m.items():
-        if "hash_dense" in k or "sweep" in k:
-            print("MFMA pass:", k, {c: round(x, 1) for c, x in v.items()})
-for k, v in out.items():
-    print(f"{k:45s} {v['launches']:4d} launches  {v['hbm_bytes_per_launch'] / 1e9:10.3f} GB/launch  {v['avg_ns_under_pmc'] / 1e6:9.3f} ms")
+        a[k]["_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {}
+    for k, cs in a.items():
+        n_counters = max(1, len([c for c in cs if c != "_ns"]))
+        out[k] = {c: sum(v) / len(v) for c, v in cs.items() if c != "_ns"}
+        out[k]["launches"] = len(cs["_ns"]) // n_counters
+        out[k]["avg_ns_under_pmc"] = sum(cs["_ns"]) / len(cs["_ns"])
+    return out
+
+
+def box(cfg_dir, out_json):
+    fetch, write = agg_counters(os.path.join(cfg_dir, "fetch")), agg_counters(os.path.join(cfg_dir, "write"))
+    sq, mfma = agg_counters(os.path.join(cfg_dir, "sq")), agg_counters(os.path.join(cfg_dir, "mfma"))
+    out = {}
+    for k in sorted(set(fetch) | set(write) | set(sq) | set(mfma)):
+        f, w = fetch.get(k), write.get(k)
+        e = {"launches": (f or w or sq.get(k) or mfma.get(k))["launches"]}
+        if f:
+            e.update(FETCH_SIZE_KiB_raw=f["FETCH_SIZE"], read_bytes_corrected_x2=2 * f["FETCH_SIZE"] * 1024, avg_ns_under_pmc=f["avg_ns_under_pmc"])
+        if w:
+            e.update(WRITE_SIZE_KiB=w["WRITE_SIZE"], write_bytes=w["WRITE_SIZE"] * 1024)
+        if f or w:
+            e["hbm_bytes_per_launch"] = (2 * f["FETCH_SIZE"] * 1024 if f else 0) + (w["WRITE_SIZE"] * 1024 if w else 0)
+        for src in (sq.get(k), mfma.get(k)):
+            if src:
+                e.update({c: v for c, v in src.items() if c not in ("launches",)})
+        out[k] = e
+    json.dump(out, open(out_json, "w"), indent=1)
+    for k, v in out.items():
+        if "hbm_bytes_per_launch" in v:
+            print(f"{k[:60]:60s} {v['launches']:5d} launches {v['hbm_bytes_per_launch'] / 1e9:10.3f} GB/launch {v.get('avg_ns_under_pmc', 0) / 1e6:9.3f} ms")
+
+
+def container(tag, commit):
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
+    for cmdf in sorted(glob.glob(os.path.join(root, "*.cmd"))):
+        cfg = os.path.basename(cmdf)[:-4]
+        st = glob.glob(os.path.join(root, cfg, "stats", "**", "*kernel_stats.csv"), recursive=True)
+        if st:
+            shutil.copy(st[0], os.path.join(here, f"{tag}_{cfg}_kernel_stats.csv"))
+        sj = os.path.join(root, f"{cfg}.summary.json")
+        pm = json.load(open(sj)) if os.path.exists(sj) else {}
+        if cfg == "hashbig":  # only the MFMA pass
+            pm = agg_counters(os.path.join(root, cfg, "mfma"))
+        log = os.path.join(root, f"{cfg}.stats.log")
+        line = None
+        if os.path.exists(log):
+            for ln in open(log):
+                if ln.startswith('{"metric"'):
+                    line = json.loads(ln)
+        pm["_meta"] = {"commit": commit, "command": "python3 " + open(cmdf).read().strip(),
+                       "pmc_passes": "the same command + --no-pipeline, one rocprofv3 --pmc pass per counter group",
+                       "bench_line_under_kernel_trace": line and {k: line[k] for k in ("value", "ms_per_step", "roofline", "stage_ms_per_batch", "config") if k in line}}
+        json.dump(pm, open(os.path.join(here, f"{tag}_{cfg}_pmc.json"), "w"), indent=1)
+        print("wrote", cfg)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--box":
+        box(sys.argv[2], sys.argv[3])
+    else:
+        container(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -113,3 +113,42 @@ def test_group_survives_changing_batch_shapes_and_an_empty_shard(za):
         g.search_batch(zo.synth_queries(4, 32, 3000), 5000, m)  # top_k > ZH_MAX_TOPK
     g.close()
     empty.close()
+
+
+def test_windows_equal_single_batches(za):
+    """zh_search_begin_window / zh_shard_search_begin_window: W batches as one internal batch give, batch for batch, the
+    answers of W separate calls (the grouping of leaf visits across the window changes who shares a row load, nothing else)"""
+    import torch
+    ix, X = _index(za, n=30000, d=96, M=128, T=7, id_base=5)
+    g = za.ShardGroup(ix, za.shard_unique_id(), 1, 0)
+    dev = torch.device("cuda", 0)
+    B, k = 48, 10
+    f = zo.Forest.from_arrays(X, 128, ix.get_forest())
+    for m, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(parity=False), zo.COSINE, zo.CORRECTED)):
+        for W in (1, 2, 5):
+            Qh = [zo.synth_queries(B, 96, 30000, b0=(W * 100 + j) * B) for j in range(W)]
+            Qs = [torch.from_numpy(q).to(dev) for q in Qh]
+            outs = [[torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.int64, device=dev),
+                     torch.empty(B, dtype=torch.int32, device=dev)] for _ in range(W)]
+            for make in (lambda: ix.search_context(), lambda: g.search_context()):
+                ctx = make()
+                for o in outs:
+                    for t in o:
+                        t.zero_()
+                if isinstance(ctx, za.ShardContext):
+                    ctx.begin_window([q.data_ptr() for q in Qs], B, k, m)
+                    ctx.finish_window([o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs], [o[2].data_ptr() for o in outs])
+                else:
+                    ctx.begin_window([q.data_ptr() for q in Qs], B, k, m, None)
+                    ctx.finish_window([o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs], [o[2].data_ptr() for o in outs], None)
+                ctx.wait()
+                torch.cuda.synchronize()
+                for j in range(W):
+                    oi, ok, oc = f.search_batch(Qh[j], k, om, omode)
+                    assert (outs[j][2].cpu().numpy().view(np.uint32) == oc).all()
+                    assert (outs[j][0].cpu().numpy().view(np.uint64) == oi + np.uint64(5)).all()
+                    assert (outs[j][1].cpu().numpy().view(np.uint64) == ok).all()
+                ctx.close()
+    assert ix.stats()["window_batches"] == 5
+    g.close()
+    ix.close()

@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("planes_total", C.c_uint64), ("sweep_bytes", C.c_uint64),
                 ("ms_hash", C.c_double), ("ms_walk", C.c_double), ("ms_sweep", C.c_double),
                 ("ms_select", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
-                ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64), ("swept_rows_accum", C.c_uint64), ("sweep_launches_accum", C.c_uint64)]
+                ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64), ("swept_rows_accum", C.c_uint64), ("sweep_launches_accum", C.c_uint64),
+                ("window_batches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -81,6 +82,8 @@ SYMBOLS = [
     ("zh_search_begin", _i, [_vp, _vp, _sz, _sz, _i, _i, _vp]),
     ("zh_search_finish", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("zh_search_wait", _i, [_vp]),
+    ("zh_search_begin_window", _i, [_vp, _vp, _sz, _sz, _sz, _i, _i, _vp]),
+    ("zh_search_finish_window", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("zh_distance_batch", _i, [_i, _i, _vp, _vp, _sz, _sz, _vp, _i]),
     ("zh_distance_pair", _i, [_i, _i, _vp, _vp, _sz, _vp, _i]),
     ("zh_merge_topk_device", _i, [_i, _u32, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -98,6 +101,8 @@ SYMBOLS = [
     ("zh_shard_search_begin", _i, [_vp, _vp, _sz, _sz, _i, _i]),
     ("zh_shard_search_finish", _i, [_vp, _vp, _vp, _vp]),
     ("zh_shard_search_wait", _i, [_vp]),
+    ("zh_shard_search_begin_window", _i, [_vp, _vp, _sz, _sz, _sz, _i, _i]),
+    ("zh_shard_search_finish_window", _i, [_vp, _vp, _vp, _vp]),
     ("zh_shard_ctx_stream", _vp, [_vp]),
     ("zh_shard_ctx_local_result", _vp, [_vp]),
     ("zh_synth_queries_device", _i, [_i, _vp, _u64, _u64, _u64, _u64, _sz, _u32, _i, _vp]),

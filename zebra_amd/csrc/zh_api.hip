@@ -100,7 +100,9 @@ struct zh_search_ctx {
     int state = 0;  // 0 idle, 1 begun (first half enqueued), 2 finished (second half enqueued, results pending)
     bool trivial = false;
     const float *dQ = nullptr;
-    size_t B = 0, k = 0;
+    size_t B = 0, k = 0;       // B = every query of the window
+    size_t nwin = 1, bwin = 0;  // a window = nwin API batches of bwin queries handled as ONE internal batch
+    DevBuf wQwin, wOutWin;      // the window's queries side by side / its results before they are handed out per batch
     int metric = 0, mode = 0;
     uint32_t P_dense = 0, wpq = 0;
     hipStream_t s = nullptr;
@@ -108,7 +110,7 @@ struct zh_search_ctx {
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                         &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff,
-                        &wLogPool, &wLogHead, &wLogCtl};
+                        &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
         if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
@@ -1024,14 +1026,18 @@ static ZhWalkLog walk_log(const zh_search_ctx *c) {
 }
 
 // first half of a batch: hash, the walk's counting pass, scans; the three totals travel to the host
-static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int metric, int mode, hipStream_t s) {
+static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, size_t bwin, size_t k, int metric, int mode,
+                     hipStream_t s) {
     zh_index *ix = c->ix;
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
+    const size_t B = nwin * bwin;
+    const float *dQ = dQs[0];
     int rc;
     if (c->state == 1) return fail(ZH_ESTATE, "zh_search_begin: the context already has a batch begun; finish it first");
     if (ix->broken) return fail(ZH_ESTATE, "an earlier zh_index_add failed half way: call zh_index_build before searching");
     if (c->state == 2 && (rc = ctx_wait(c))) return rc;  // the previous batch was never waited for: retire it
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
+    c->nwin = nwin; c->bwin = bwin;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
     c->state = 1;
     if (c->trivial) return ZH_OK;
@@ -1041,6 +1047,12 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
     c->wpq = (c->P_dense + 63) / 64 * 2;
     const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
     c->state = 0;  // a failure below leaves the context idle
+    if (nwin > 1) {  // the window's batches side by side: the kernels address query b of the window as Q + b * d
+        if ((rc = c->wQwin.ensure(B * d * 4))) return rc;
+        for (size_t j = 0; j < nwin; j++)
+            HIPCHK(hipMemcpyAsync(c->wQwin.as<float>() + j * bwin * d, dQs[j], bwin * d * 4, hipMemcpyDeviceToDevice, s));
+        c->dQ = dQ = c->wQwin.as<float>();
+    }
     if ((rc = c->wQQ.ensure(B * 4))) return rc;
     if ((rc = c->wBits.ensure(std::max<size_t>((size_t)B * c->wpq * 4, 4)))) return rc;
     if ((rc = c->wCounts.ensure(pairs * sizeof(ZhPairCounts)))) return rc;
@@ -1082,25 +1094,36 @@ static int ctx_begin(zh_search_ctx *c, const float *dQ, size_t B, size_t k, int 
 }
 
 // second half: waits (host side) for the totals only, sizes the scratch, enqueues emit -> sweep -> select -> final
-static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t heavy) {
+static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const *outKeys, uint32_t *const *outCounts,
+                      hipStream_t heavy) {
     zh_index *ix = c->ix;
     if (c->state != 1) return fail(ZH_ESTATE, "zh_search_finish without zh_search_begin");
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
-    const size_t B = c->B, k = c->k;
+    const size_t B = c->B, k = c->k, nwin = c->nwin, bwin = c->bwin;
     hipStream_t s = c->s;
     int rc;
     c->state = 0;
     if (c->trivial) {
-        if (B) {
-            HIPCHK(hipMemsetAsync(dOutCounts, 0, B * 4, s));
+        for (size_t j = 0; j < nwin && bwin; j++) {
+            HIPCHK(hipMemsetAsync(outCounts[j], 0, bwin * 4, s));
             if (k) {
-                HIPCHK(hipMemsetAsync(dOutIds, 0xFF, B * k * 8, s));
-                HIPCHK(hipMemsetAsync(dOutKeys, 0xFF, B * k * 8, s));
+                HIPCHK(hipMemsetAsync(outIds[j], 0xFF, bwin * k * 8, s));
+                HIPCHK(hipMemsetAsync(outKeys[j], 0xFF, bwin * k * 8, s));
             }
         }
         HIPCHK(hipEventRecord(c->ev[5], s));
         c->state = 2;
         return ZH_OK;
+    }
+    // one batch: the final kernel writes straight into the caller's buffers; a window: into the context's own, handed out
+    // per batch by small device copies afterwards
+    uint64_t *dOutIds = outIds[0], *dOutKeys = outKeys[0];
+    uint32_t *dOutCounts = outCounts[0];
+    if (nwin > 1) {
+        if ((rc = c->wOutWin.ensure(B * k * 16 + B * 4))) { return rc; }
+        dOutIds = c->wOutWin.as<uint64_t>();
+        dOutKeys = dOutIds + B * k;
+        dOutCounts = reinterpret_cast<uint32_t *>(dOutKeys + B * k);
     }
     HIPCHK(hipEventSynchronize(c->ev_totals));
     const ZhTotals tot = c->tot = *c->h_totals;
@@ -1158,6 +1181,11 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, u
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(zh_launch_final(c->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, c->wCandKeys.as<uint64_t>(),
                            c->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));
+    for (size_t j = 0; j < nwin && nwin > 1; j++) {
+        HIPCHK(hipMemcpyAsync(outIds[j], dOutIds + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(outKeys[j], dOutKeys + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(outCounts[j], dOutCounts + j * bwin, bwin * 4, hipMemcpyDeviceToDevice, s));
+    }
     HIPCHK(hipEventRecord(c->ev[5], s));
     c->state = 2;
     return ZH_OK;
@@ -1189,7 +1217,7 @@ int ctx_wait(zh_search_ctx *c) {
     }
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     zh_stats_t &st = ix->stats;
-    st.batch = c->B; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
+    st.batch = c->B; st.window_batches = c->nwin; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
     st.planes_dense = c->P_dense; st.planes_total = ix->n_planes;
     st.rows_swept = tot.group_rows;
     st.sweep_bytes = tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
@@ -1208,9 +1236,9 @@ int ctx_wait(zh_search_ctx *c) {
 
 static int search_once(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
                        uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
-    int rc = ctx_begin(&ix->dctx, dQ, B, k, metric, mode, s);
+    int rc = ctx_begin(&ix->dctx, &dQ, 1, B, k, metric, mode, s);
     if (rc) return rc;
-    if ((rc = ctx_finish(&ix->dctx, dOutIds, dOutKeys, dOutCounts, nullptr))) return rc;
+    if ((rc = ctx_finish(&ix->dctx, &dOutIds, &dOutKeys, &dOutCounts, nullptr))) return rc;
     return ctx_wait(&ix->dctx);
 }
 
@@ -1286,12 +1314,33 @@ extern "C" int zh_search_begin(zh_search_ctx *c, const float *d_q, size_t b, siz
     int rc = check_metric(metric, mode);
     if (rc) return rc;
     if ((rc = set_device(c->ix))) return rc;
-    return ctx_begin(c, d_q, b, k, metric, mode, stream ? (hipStream_t)stream : c->ix->stream);
+    return ctx_begin(c, &d_q, 1, b, k, metric, mode, stream ? (hipStream_t)stream : c->ix->stream);
+}
+extern "C" int zh_search_begin_window(zh_search_ctx *c, const float *const *d_q, size_t n_batches, size_t b, size_t k, int metric,
+                                      int mode, void *stream) {
+    if (!c || !d_q || n_batches == 0 || n_batches > ZH_MAX_WINDOW) return fail(ZH_EINVAL, "zh_search_begin_window: bad argument (1..%u batches)", ZH_MAX_WINDOW);
+    for (size_t j = 0; j < n_batches; j++)
+        if (b && !d_q[j]) return fail(ZH_EINVAL, "zh_search_begin_window: null query pointer");
+    if (k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k %zu > ZH_MAX_TOPK (%u)", k, ZH_MAX_TOPK);
+    int rc = check_metric(metric, mode);
+    if (rc) return rc;
+    if ((rc = set_device(c->ix))) return rc;
+    return ctx_begin(c, d_q, n_batches, b, k, metric, mode, stream ? (hipStream_t)stream : c->ix->stream);
 }
 extern "C" int zh_search_finish(zh_search_ctx *c, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts,
                                 void *sweep_stream) {
     if (!c) return fail(ZH_EINVAL, "zh_search_finish: null context");
     if (c->B && (!d_out_counts || (c->k && (!d_out_ids || !d_out_keys)))) return fail(ZH_EINVAL, "zh_search_finish: null output");
+    if (c->nwin != 1) return fail(ZH_ESTATE, "zh_search_finish: the context holds a window; use zh_search_finish_window");
+    int rc = set_device(c->ix);
+    if (rc) return rc;
+    return ctx_finish(c, &d_out_ids, &d_out_keys, &d_out_counts, (hipStream_t)sweep_stream);
+}
+extern "C" int zh_search_finish_window(zh_search_ctx *c, uint64_t *const *d_out_ids, uint64_t *const *d_out_keys,
+                                       uint32_t *const *d_out_counts, void *sweep_stream) {
+    if (!c || !d_out_ids || !d_out_keys || !d_out_counts) return fail(ZH_EINVAL, "zh_search_finish_window: null argument");
+    for (size_t j = 0; j < c->nwin && c->bwin; j++)
+        if (!d_out_counts[j] || (c->k && (!d_out_ids[j] || !d_out_keys[j]))) return fail(ZH_EINVAL, "zh_search_finish_window: null output");
     int rc = set_device(c->ix);
     if (rc) return rc;
     return ctx_finish(c, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)sweep_stream);

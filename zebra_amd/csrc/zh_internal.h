@@ -25,7 +25,9 @@ struct ZhVisit {
 
 // Visits of one leaf by different queries of the batch are swept together, ZH_GROUP at a time:
 // the leaf's rows cross HBM once per group instead of once per query.
-#define ZH_GROUP 2
+#ifndef ZH_GROUP
+#define ZH_GROUP 4
+#endif
 struct ZhGroup {
     uint32_t leaf_off, len, gsize, pad;
     uint32_t b[ZH_GROUP];

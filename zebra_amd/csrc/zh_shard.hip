@@ -46,7 +46,10 @@ struct zh_shard_ctx {
     hipStream_t xs = nullptr;      // all-gather + merge: normal priority (never behind a sweep launch)
     hipEvent_t ev_final = nullptr, ev_xdone = nullptr;
     uint64_t *gathered = nullptr;  // [n_ranks][W] packed results; slot `rank` is this rank's own (in-place all-gather)
-    size_t cap_words = 0, W = 0, B = 0, k = 0;
+    size_t cap_words = 0, W = 0, B = 0, k = 0;  // B = every query of the window
+    size_t nwin = 1, bwin = 0;
+    uint64_t *merged = nullptr;    // a window's merged results before they are handed out per batch
+    size_t cap_merged = 0;
     bool xused = false;
     int state = 0;  // 0 idle, 1 begun, 2 finished
 };
@@ -133,6 +136,7 @@ extern "C" void zh_shard_ctx_destroy(zh_shard_ctx *c) {
     if (c->light) hipStreamSynchronize(c->light);
     zh_search_ctx_destroy(c->sc);
     if (c->gathered) hipFree(c->gathered);
+    if (c->merged) hipFree(c->merged);
     if (c->ev_final) hipEventDestroy(c->ev_final);
     if (c->ev_xdone) hipEventDestroy(c->ev_xdone);
     if (c->xs) hipStreamDestroy(c->xs);
@@ -145,27 +149,37 @@ extern "C" const uint64_t *zh_shard_ctx_local_result(const zh_shard_ctx *c) {
     return (c && c->gathered) ? c->gathered + (size_t)c->g->rank * c->W : nullptr;
 }
 
-extern "C" int zh_shard_search_begin(zh_shard_ctx *c, const float *d_q, size_t b, size_t k, int metric, int mode) {
-    if (!c) return FAIL(ZH_EINVAL, "zh_shard_search_begin: null context");
+static int shard_begin(zh_shard_ctx *c, const float *const *d_q, size_t nwin, size_t b, size_t k, int metric, int mode) {
     if (c->state == 1) return FAIL(ZH_ESTATE, "zh_shard_search_begin: the context already has a batch begun");
     if (k == 0 || k > ZH_MAX_TOPK) return FAIL(ZH_ELIMIT, "top_k must be in 1..%u", ZH_MAX_TOPK);
     if (b == 0) return FAIL(ZH_EINVAL, "zh_shard_search_begin: empty batch");
     int rc = set_dev(c->g);
     if (rc) return rc;
     if (c->state == 2 && (rc = zh_shard_search_wait(c))) return rc;
-    if ((rc = zh_search_begin(c->sc, d_q, b, k, metric, mode, c->light))) return rc;
-    c->B = b; c->k = k;
+    if ((rc = zh_search_begin_window(c->sc, d_q, nwin, b, k, metric, mode, c->light))) return rc;
+    c->B = nwin * b; c->k = k; c->nwin = nwin; c->bwin = b;
     c->state = 1;
     return ZH_OK;
 }
+extern "C" int zh_shard_search_begin(zh_shard_ctx *c, const float *d_q, size_t b, size_t k, int metric, int mode) {
+    if (!c || !d_q) return FAIL(ZH_EINVAL, "zh_shard_search_begin: null argument");
+    return shard_begin(c, &d_q, 1, b, k, metric, mode);
+}
+extern "C" int zh_shard_search_begin_window(zh_shard_ctx *c, const float *const *d_q, size_t n_batches, size_t b, size_t k,
+                                            int metric, int mode) {
+    if (!c || !d_q || n_batches == 0 || n_batches > ZH_MAX_WINDOW) return FAIL(ZH_EINVAL, "zh_shard_search_begin_window: bad argument");
+    return shard_begin(c, d_q, n_batches, b, k, metric, mode);
+}
 
-extern "C" int zh_shard_search_finish(zh_shard_ctx *c, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts) {
-    if (!c || !d_out_ids || !d_out_keys || !d_out_counts) return FAIL(ZH_EINVAL, "zh_shard_search_finish: null argument");
+// local results of the whole window land in this rank's slot of the gather buffer ([ids B*k | keys B*k | counts B], B =
+// every query of the window), ONE all-gather and ONE merge per window; a window's merged results are handed out per batch
+static int shard_finish(zh_shard_ctx *c, uint64_t *const *out_ids, uint64_t *const *out_keys, uint32_t *const *out_counts) {
     if (c->state != 1) return FAIL(ZH_ESTATE, "zh_shard_search_finish without zh_shard_search_begin");
     zh_shard_group *g = c->g;
     int rc = set_dev(g);
     if (rc) return rc;
-    const size_t W = zh_packed_result_words(c->B, c->k), need = W * g->n_ranks;
+    const size_t B = c->B, k = c->k, nwin = c->nwin, b = c->bwin;
+    const size_t W = zh_packed_result_words(B, k), need = W * g->n_ranks;
     if (need > c->cap_words) {  // another batch shape: the previous exchange must have read the old buffer
         if (c->xused) HIPCHK(hipEventSynchronize(c->ev_xdone));
         if (c->gathered) hipFree(c->gathered);
@@ -176,25 +190,55 @@ extern "C" int zh_shard_search_finish(zh_shard_ctx *c, uint64_t *d_out_ids, uint
         // the buffer is free again once this context's previous exchange has read it (long done: a batch ago)
         HIPCHK(hipStreamWaitEvent(c->light, c->ev_xdone, 0));
     }
+    if (nwin > 1 && W > c->cap_merged) {
+        if (c->xused) HIPCHK(hipEventSynchronize(c->ev_xdone));
+        if (c->merged) hipFree(c->merged);
+        c->merged = nullptr; c->cap_merged = 0;
+        HIPCHK(hipMalloc((void **)&c->merged, W * 8));
+        c->cap_merged = W;
+    }
     c->W = W;
     uint64_t *mine = c->gathered + (size_t)g->rank * W;
+    uint64_t *l_ids[ZH_MAX_WINDOW], *l_keys[ZH_MAX_WINDOW];
+    uint32_t *l_counts[ZH_MAX_WINDOW];
+    for (size_t j = 0; j < nwin; j++) {
+        l_ids[j] = mine + j * b * k;
+        l_keys[j] = mine + B * k + j * b * k;
+        l_counts[j] = reinterpret_cast<uint32_t *>(mine + 2 * B * k) + j * b;
+    }
     c->state = 0;
-    if ((rc = zh_search_finish(c->sc, mine, mine + c->B * c->k, reinterpret_cast<uint32_t *>(mine + 2 * c->B * c->k),
-                               zh_index_sweep_stream(g->ix))))
-        return rc;
+    if ((rc = zh_search_finish_window(c->sc, l_ids, l_keys, l_counts, zh_index_sweep_stream(g->ix)))) return rc;
     HIPCHK(hipEventRecord(c->ev_final, c->light));
     {
         std::lock_guard<std::mutex> lk(g->mu);
         HIPCHK(hipStreamWaitEvent(c->xs, c->ev_final, 0));
         NCCLCHK(ncclAllGather(mine, c->gathered, W, ncclUint64, g->comm, c->xs));  // in place: send == recv + rank * W
-        if ((rc = zh_merge_topk_packed_device(g->device, g->n_ranks, c->B, c->k, c->gathered, d_out_ids, d_out_keys,
-                                              d_out_counts, c->xs)))
+        uint64_t *m_ids = nwin > 1 ? c->merged : out_ids[0], *m_keys = nwin > 1 ? c->merged + B * k : out_keys[0];
+        uint32_t *m_counts = nwin > 1 ? reinterpret_cast<uint32_t *>(c->merged + 2 * B * k) : out_counts[0];
+        if ((rc = zh_merge_topk_packed_device(g->device, g->n_ranks, B, k, c->gathered, m_ids, m_keys, m_counts, c->xs)))
             return rc;
+        for (size_t j = 0; j < nwin && nwin > 1; j++) {
+            HIPCHK(hipMemcpyAsync(out_ids[j], m_ids + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs));
+            HIPCHK(hipMemcpyAsync(out_keys[j], m_keys + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs));
+            HIPCHK(hipMemcpyAsync(out_counts[j], m_counts + j * b, b * 4, hipMemcpyDeviceToDevice, c->xs));
+        }
         HIPCHK(hipEventRecord(c->ev_xdone, c->xs));
     }
     c->xused = true;
     c->state = 2;
     return ZH_OK;
+}
+extern "C" int zh_shard_search_finish(zh_shard_ctx *c, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts) {
+    if (!c || !d_out_ids || !d_out_keys || !d_out_counts) return FAIL(ZH_EINVAL, "zh_shard_search_finish: null argument");
+    if (c->nwin != 1) return FAIL(ZH_ESTATE, "zh_shard_search_finish: the context holds a window; use zh_shard_search_finish_window");
+    return shard_finish(c, &d_out_ids, &d_out_keys, &d_out_counts);
+}
+extern "C" int zh_shard_search_finish_window(zh_shard_ctx *c, uint64_t *const *d_out_ids, uint64_t *const *d_out_keys,
+                                             uint32_t *const *d_out_counts) {
+    if (!c || !d_out_ids || !d_out_keys || !d_out_counts) return FAIL(ZH_EINVAL, "zh_shard_search_finish_window: null argument");
+    for (size_t j = 0; j < c->nwin; j++)
+        if (!d_out_ids[j] || !d_out_keys[j] || !d_out_counts[j]) return FAIL(ZH_EINVAL, "zh_shard_search_finish_window: null output");
+    return shard_finish(c, d_out_ids, d_out_keys, d_out_counts);
 }
 
 extern "C" int zh_shard_search_wait(zh_shard_ctx *c) {

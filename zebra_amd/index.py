@@ -298,6 +298,16 @@ class SearchContext:
     def finish(self, d_ids_ptr, d_keys_ptr, d_counts_ptr, sweep_stream=None):
         check(lib().zh_search_finish(self._h, d_ids_ptr, d_keys_ptr, d_counts_ptr, sweep_stream))
 
+    def begin_window(self, d_q_ptrs, b, top_k, metric, stream=None):
+        """len(d_q_ptrs) batches of b queries handled as one internal batch (zh_search_begin_window)"""
+        arr = (C.c_void_p * len(d_q_ptrs))(*d_q_ptrs)
+        check(lib().zh_search_begin_window(self._h, arr, len(d_q_ptrs), b, top_k, metric.metric, metric.mode, stream))
+
+    def finish_window(self, d_ids_ptrs, d_keys_ptrs, d_counts_ptrs, sweep_stream=None):
+        n = len(d_ids_ptrs)
+        a, b_, c = (C.c_void_p * n)(*d_ids_ptrs), (C.c_void_p * n)(*d_keys_ptrs), (C.c_void_p * n)(*d_counts_ptrs)
+        check(lib().zh_search_finish_window(self._h, a, b_, c, sweep_stream))
+
     def wait(self):
         check(lib().zh_search_wait(self._h))
 
@@ -374,6 +384,15 @@ class ShardContext:
 
     def finish(self, d_ids_ptr, d_keys_ptr, d_counts_ptr):
         check(lib().zh_shard_search_finish(self._h, d_ids_ptr, d_keys_ptr, d_counts_ptr))
+
+    def begin_window(self, d_q_ptrs, b, top_k, metric):
+        arr = (C.c_void_p * len(d_q_ptrs))(*d_q_ptrs)
+        check(lib().zh_shard_search_begin_window(self._h, arr, len(d_q_ptrs), b, top_k, metric.metric, metric.mode))
+
+    def finish_window(self, d_ids_ptrs, d_keys_ptrs, d_counts_ptrs):
+        n = len(d_ids_ptrs)
+        a, b_, c = (C.c_void_p * n)(*d_ids_ptrs), (C.c_void_p * n)(*d_keys_ptrs), (C.c_void_p * n)(*d_counts_ptrs)
+        check(lib().zh_shard_search_finish_window(self._h, a, b_, c))
 
     def wait(self):
         check(lib().zh_shard_search_wait(self._h))
