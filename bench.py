@@ -89,7 +89,7 @@ def parse():
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking search call per step")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined")
-    ap.add_argument("--window", type=int, default=1,
+    ap.add_argument("--window", type=int, default=2,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")

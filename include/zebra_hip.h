@@ -202,7 +202,11 @@ ZH_API int zh_search_batch_device(zh_index *idx, const float *d_q, size_t b, siz
                            uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts, void *stream);
 
 /* Pipelined form of zh_search_batch_device (new; the reference has one blocking search per query): a context
- * is one in-flight batch with its own scratch.  begin enqueues the hash and the walk's counting pass on
+ * is one in-flight batch with its own scratch.  The context calls do NOT take the index's internal lock (the blocking
+ * calls do): contexts of one index may be driven from several threads, one thread per context at a time, concurrently with
+ * each other and with blocking searches -- they share only read-only index state and the statistics of zh_stats (guarded
+ * separately) -- but never concurrently with add / build / set_forest / remove / clear / destroy on that index.
+ * begin enqueues the hash and the walk's counting pass on
  * `stream` and returns; finish waits (host side) only for three totals, then enqueues the distance sweep,
  * the selection and the final top-k and returns; wait blocks until the results are complete.  With two
  * contexts on two streams one host thread keeps the sweep of batch i and the small latency-bound kernels of
@@ -233,7 +237,8 @@ ZH_API int zh_search_begin_window(zh_search_ctx *ctx, const float *const *d_q, s
 ZH_API int zh_search_finish_window(zh_search_ctx *ctx, uint64_t *const *d_out_ids, uint64_t *const *d_out_keys,
                                    uint32_t *const *d_out_counts, void *sweep_stream);
 
-/* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers). */
+/* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers).  Device buffers are kept
+ * per calling thread between calls (a pair costs two small copies in, three small kernels, one copy out). */
 ZH_API int zh_distance_batch(int metric, int cosine_mode, const float *a, const float *q, size_t n, size_t dim,
                       uint64_t *out_keys, int device);
 ZH_API int zh_distance_pair(int metric, int cosine_mode, const float *a, const float *b, size_t dim, uint64_t *out_key,

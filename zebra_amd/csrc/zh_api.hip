@@ -139,6 +139,11 @@ struct zh_index {
     std::vector<uint8_t> h_dead;               // rows removed by zh_index_remove (their vectors stay in X)
     uint64_t n_dead = 0;
     uint32_t max_leaf_len = 0;
+    // blocked view of the forest (ZhBlocksDev) for all-dense walks: built on first use, dropped whenever the trees change
+    DevBuf blk_recs, blk_start, blk_upper, blk_roots;
+    uint32_t n_blocks = 0;
+    bool blocks_valid = false;
+    std::mutex blk_mu;
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
     zh_search_ctx dctx;
@@ -171,6 +176,7 @@ static ZhForestDev forest_dev(const zh_index *ix) {
     f.n_nodes = ix->n_nodes;
     f.n_planes = ix->n_planes;
     f.n_trees = ix->n_trees;
+    f.group = zh_group_size(ix->opt.dim);
     return f;
 }
 
@@ -247,6 +253,8 @@ extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
 static void free_forest(zh_index *ix) {
     ix->node_plane.release(); ix->node_left.release(); ix->node_right.release(); ix->node_pack.release(); ix->roots.release();
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
+    ix->blk_recs.release(); ix->blk_start.release(); ix->blk_upper.release(); ix->blk_roots.release();
+    ix->n_blocks = 0; ix->blocks_valid = false;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
     ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
@@ -387,6 +395,7 @@ static int upload_nodes(zh_index *ix) {
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
+    ix->blocks_valid = false;  // the trees changed
     ix->max_leaf_len = 0;
     for (size_t i = 0; i < nn; i++)
         if (ix->h_plane[i] < 0) ix->max_leaf_len = std::max(ix->max_leaf_len, (uint32_t)ix->h_right[i]);
@@ -983,6 +992,91 @@ extern "C" int zh_stats_reset(zh_index *ix) {
     return ZH_OK;
 }
 
+// Blocked view of the forest (zh_internal.h, ZhBlocksDev): every maximal subtree of at most ZH_BLOCK_NODES nodes becomes
+// one block with its nodes in pre-order; the nodes above keep pointer records whose child refs say "upper node" or
+// "block".  Host pass over the node mirrors (iterative: trees may be 60 levels deep), then four uploads.
+static int build_blocks(zh_index *ix) {
+    const size_t nn = ix->h_plane.size();
+    const uint32_t T = (uint32_t)ix->h_roots.size();
+    std::vector<uint32_t> size(nn, 0), order;
+    order.reserve(nn);
+    std::vector<uint32_t> st;
+    for (uint32_t t = 0; t < T; t++) {  // pre-order of every tree; subtree sizes in a reverse pass
+        const size_t o0 = order.size();
+        st.assign(1, ix->h_roots[t]);
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            order.push_back(n);
+            if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
+        }
+        for (size_t i = order.size(); i-- > o0;) {
+            const uint32_t n = order[i];
+            size[n] = 1 + (ix->h_plane[n] >= 0 ? size[(uint32_t)ix->h_left[n]] + size[(uint32_t)ix->h_right[n]] : 0);
+        }
+    }
+    std::vector<int4> recs, upper(std::max<size_t>(nn, 1), make_int4(-1, 0, 0, 0));
+    std::vector<uint32_t> start;
+    std::vector<int32_t> roots(std::max<uint32_t>(T, 1), 0);
+    recs.reserve(nn);
+    std::vector<float> hc(ix->n_planes);
+    if (ix->n_planes) HIPCHK(hipMemcpy(hc.data(), ix->consts.p, (size_t)ix->n_planes * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> nodes;
+    auto emit_block = [&](uint32_t root) -> int32_t {  // nodes of the subtree in pre-order, children as local indices
+        const uint32_t base = (uint32_t)recs.size();
+        start.push_back(base);
+        nodes.clear();
+        st.assign(1, root);
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            nodes.push_back(n);
+            if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
+        }
+        // in pre-order the left child of local i is i + 1 and the right child i + 1 + size(left)
+        for (uint32_t i = 0; i < nodes.size(); i++) {
+            const uint32_t n = nodes[i];
+            if (ix->h_plane[n] >= 0) {
+                const uint32_t l = i + 1, r = i + 1 + size[(uint32_t)ix->h_left[n]];
+                recs.push_back(make_int4(ix->h_plane[n], (int)(l | (r << 16)), 0, (int)n));
+            } else
+                recs.push_back(make_int4(-1, ix->h_left[n], ix->h_right[n], (int)n));
+        }
+        return -(int32_t)(start.size() - 1) - 1;
+    };
+    auto ref_of = [&](uint32_t n) -> int32_t { return size[n] <= ZH_BLOCK_NODES ? emit_block(n) : (int32_t)n; };
+    for (uint32_t t = 0; t < T; t++) {
+        st.assign(1, ix->h_roots[t]);
+        std::vector<uint32_t> up;  // upper nodes of this tree (subtree larger than a block), top-down
+        if (size[ix->h_roots[t]] <= ZH_BLOCK_NODES) { roots[t] = emit_block(ix->h_roots[t]); continue; }
+        roots[t] = (int32_t)ix->h_roots[t];
+        up.push_back(ix->h_roots[t]);
+        while (!up.empty()) {
+            const uint32_t n = up.back(); up.pop_back();
+            const uint32_t l = (uint32_t)ix->h_left[n], r = (uint32_t)ix->h_right[n];
+            const int32_t lr = ref_of(l), rr = ref_of(r);
+            float cf = hc[(uint32_t)ix->h_plane[n]];
+            int cb;
+            memcpy(&cb, &cf, 4);
+            upper[n] = make_int4(ix->h_plane[n], lr, rr, cb);
+            if (lr >= 0) up.push_back(l);
+            if (rr >= 0) up.push_back(r);
+        }
+    }
+    start.push_back((uint32_t)recs.size());
+    if (recs.size() > 0xFFFFFFF0ull || start.size() > 0x7FFFFFF0ull) return fail(ZH_ELIMIT, "forest too large for the blocked view");
+    int rc;
+    if ((rc = ix->blk_recs.ensure(std::max<size_t>(recs.size(), 1) * sizeof(int4)))) return rc;
+    if ((rc = ix->blk_start.ensure(start.size() * 4))) return rc;
+    if ((rc = ix->blk_upper.ensure(upper.size() * sizeof(int4)))) return rc;
+    if ((rc = ix->blk_roots.ensure(roots.size() * 4))) return rc;
+    if (!recs.empty()) HIPCHK(hipMemcpy(ix->blk_recs.p, recs.data(), recs.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->blk_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->blk_upper.p, upper.data(), upper.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->blk_roots.p, roots.data(), roots.size() * 4, hipMemcpyHostToDevice));
+    ix->n_blocks = (uint32_t)(start.size() - 1);
+    ix->blocks_valid = true;
+    return ZH_OK;
+}
+
 // number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
 static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     const auto &below = ix->planes_below_level;
@@ -1044,6 +1138,10 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     const uint64_t pairs = (uint64_t)B * T;
     if (pairs >= (1ull << 26)) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees >= 2^26"); }
     c->P_dense = choose_dense_planes(ix, B, k);
+    if (c->P_dense >= ix->n_planes && ix->n_planes && !ix->blocks_valid) {  // first all-dense batch since the trees changed
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if (!ix->blocks_valid && (rc = build_blocks(ix))) { c->state = 0; return rc; }
+    }
     c->wpq = (c->P_dense + 63) / 64 * 2;
     const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
     c->state = 0;  // a failure below leaves the context idle
@@ -1080,8 +1178,16 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     if (c->P_dense)
         HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, c->P_dense, d, c->wBits.as<uint32_t>(), c->wpq, nullptr, s));
     HIPCHK(hipEventRecord(c->ev[1], s));
-    HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
-                                c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
+    static const bool no_blocks = getenv("ZH_WALK_NO_BLOCKS") != nullptr;  // A/B: the pointer walk for all-dense signs too
+    if (c->P_dense >= ix->n_planes && ix->n_planes && ix->blocks_valid && !no_blocks) {
+        ZhBlocksDev bd;
+        bd.recs = ix->blk_recs.as<int4>(); bd.start = ix->blk_start.as<uint32_t>(); bd.upper = ix->blk_upper.as<int4>();
+        bd.root_ref = ix->blk_roots.as<int32_t>(); bd.n_blocks = ix->n_blocks;
+        HIPCHK(zh_launch_walk_blocked(f, bd, (uint32_t)B, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->wCounts.as<ZhPairCounts>(),
+                                      c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
+    } else
+        HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
+                                    c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
     HIPCHK(zh_launch_leaf_scan(f, c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
                                c->wGroupRowBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
     HIPCHK(zh_launch_pair_scan(c->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, c->wRowBase.as<uint64_t>(),
@@ -1172,7 +1278,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
     HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
                            c->wGroupRowOff.as<uint64_t>(), tot.groups, f.leaf_ids, tot.group_rows, c->metric, c->mode,
-                           c->wKeys.as<uint64_t>(), hs));
+                           c->wKeys.as<uint64_t>(), f.group, hs));
     HIPCHK(hipEventRecord(c->ev_sw1, hs));
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
     HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1424,6 +1530,16 @@ static int pick_device(int device) {
     return ZH_OK;
 }
 
+// Stand-alone metric calls keep their device buffers per calling thread (and device): Metric::distance is called pair by
+// pair from the crate's own code paths, and six hipMalloc / hipFree per call cost far more than the kernels.
+struct DistScratch {
+    int device = -1;
+    DevBuf in, keys, small;  // [rows | query] staged together, the keys, the sweep's one-group record
+    void drop() { in.release(); keys.release(); small.release(); device = -1; }
+    ~DistScratch() { drop(); }
+};
+static thread_local DistScratch g_dist;
+
 extern "C" int zh_distance_batch(int metric, int mode, const float *a, const float *q, size_t n, size_t dim,
                                  uint64_t *out_keys, int device) {
     if ((n && (!a || !out_keys)) || !q || !dim) return fail(ZH_EINVAL, "zh_distance_batch: null argument");
@@ -1432,15 +1548,18 @@ extern "C" int zh_distance_batch(int metric, int mode, const float *a, const flo
     if (rc) return rc;
     if ((rc = pick_device(device))) return rc;
     if (!n) return ZH_OK;
-    DevBuf da, dq, dk;
-    struct G { DevBuf *a, *b, *c; ~G() { a->release(); b->release(); c->release(); } } g{&da, &dq, &dk};
-    if ((rc = da.ensure(n * dim * 4))) return rc;
-    if ((rc = dq.ensure(dim * 4))) return rc;
-    if ((rc = dk.ensure(n * 8))) return rc;
-    HIPCHK(hipMemcpy(da.p, a, n * dim * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dq.p, q, dim * 4, hipMemcpyHostToDevice));
-    HIPCHK(zh_launch_distance_rows(da.as<float>(), n, (uint32_t)dim, dq.as<float>(), metric, mode, dk.as<uint64_t>(), nullptr));
-    HIPCHK(hipMemcpy(out_keys, dk.p, n * 8, hipMemcpyDeviceToHost));
+    int cur = 0;
+    HIPCHK(hipGetDevice(&cur));
+    DistScratch &sc = g_dist;
+    if (sc.device != cur) { sc.drop(); sc.device = cur; }
+    if ((rc = sc.in.ensure((n + 1) * dim * 4))) return rc;
+    if ((rc = sc.keys.ensure(n * 8))) return rc;
+    if ((rc = sc.small.ensure(ZH_DISTANCE_SCRATCH_BYTES))) return rc;
+    float *da = sc.in.as<float>(), *dq = da + n * dim;
+    HIPCHK(hipMemcpyAsync(da, a, n * dim * 4, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(dq, q, dim * 4, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(zh_launch_distance_rows(da, n, (uint32_t)dim, dq, metric, mode, sc.keys.as<uint64_t>(), sc.small.p, nullptr));
+    HIPCHK(hipMemcpy(out_keys, sc.keys.p, n * 8, hipMemcpyDeviceToHost));  // synchronises the null stream
     return ZH_OK;
 }
 

@@ -23,16 +23,17 @@ struct ZhVisit {
     uint32_t pad;
 };
 
-// Visits of one leaf by different queries of the batch are swept together, ZH_GROUP at a time:
-// the leaf's rows cross HBM once per group instead of once per query.
-#ifndef ZH_GROUP
-#define ZH_GROUP 4
-#endif
+// Visits of one leaf by different queries of the batch (or window) are swept together, `group` at a time (2 or 4, chosen
+// per index by zh_group_size): the leaf's rows cross HBM once per group instead of once per query.
+#define ZH_GROUP_MAX 4
 struct ZhGroup {
     uint32_t leaf_off, len, gsize, pad;
-    uint32_t b[ZH_GROUP];
-    uint64_t key_off[ZH_GROUP];  // the member visits' row_off (slice of the key scratch)
+    uint32_t b[ZH_GROUP_MAX];
+    uint64_t key_off[ZH_GROUP_MAX];  // the member visits' row_off (slice of the key scratch)
 };
+// 4 queries per group where a row is long enough for the loads to dominate; short rows (d <= 128: a 512-byte row is half a
+// wave-load) are bound by the per-(row, query) reduction work as well, and pairs measure faster there.  ZH_GROUP=2|4 forces.
+uint32_t zh_group_size(uint32_t dim);
 
 // per (query, tree) pair counts produced by the walk's first pass, then their exclusive scans
 struct ZhPairCounts {
@@ -56,6 +57,20 @@ struct ZhWalkLog {
     ZhLogCtl *ctl;
 };
 
+// Blocked view of the forest for walks that find every sign precomputed (ZH_BLOCK_NODES, zh_api.hip build_blocks): every
+// maximal subtree of at most ZH_BLOCK_NODES nodes is one BLOCK, its nodes stored contiguously in pre-order as 16-byte
+// records {plane | -1, inner: left_local | right_local << 16 / leaf: offset into leaf_ids, leaf: length, global node id}.
+// The nodes above the blocks ("upper" nodes, all inner) keep 16-byte records {plane, left ref, right ref, bits of the
+// constant} whose child refs are >= 0 for an upper node and -(block + 1) for a block.
+#define ZH_BLOCK_NODES 64
+struct ZhBlocksDev {
+    const int4 *recs;           // all blocks' node records
+    const uint32_t *start;      // n_blocks + 1 offsets into recs
+    const int4 *upper;          // indexed by global node id (only upper nodes are meaningful)
+    const int32_t *root_ref;    // per tree
+    uint32_t n_blocks;
+};
+
 struct ZhForestDev {
     const int32_t *node_plane, *node_left, *node_right;
     // one 16-byte record per node for the walk: {plane, left, right, bits of the plane's constant} for an internal node,
@@ -65,6 +80,7 @@ struct ZhForestDev {
     const float *planes, *consts;
     const uint32_t *leaf_ids;
     uint32_t n_nodes, n_planes, n_trees;
+    uint32_t group;  // queries per sweep group (zh_group_size)
 };
 
 #if defined(__HIPCC__)
@@ -115,6 +131,10 @@ hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, 
 hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint32_t d, int32_t n,
                                 const uint32_t *dBits, uint32_t words_per_q, uint32_t P_dense, ZhPairCounts *dCounts,
                                 ZhVisit *dInline, uint32_t *dLeafCount, ZhWalkLog log, hipStream_t s);
+// the counting pass for all-dense signs over the blocked forest: one memory round trip per BLOCK instead of per node
+hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
+                                  uint32_t words_per_q, ZhPairCounts *dCounts, ZhVisit *dInline, uint32_t *dLeafCount,
+                                  ZhWalkLog log, hipStream_t s);
 // places every visit recorded by the counting pass (inline + log) and joins the leaf groups: the cheap, flat
 // replacement of the emit walk whenever the log did not overflow
 hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCounts, const ZhVisit *dInline,
@@ -140,7 +160,7 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s);
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
-                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, hipStream_t s);
+                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, uint32_t group, hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);
 // max_leaf_len: the longest leaf of the forest (picks the LDS footprint of the select blocks)
@@ -156,8 +176,9 @@ hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *d
                            const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
                            uint64_t stride64, uint64_t stride32, hipStream_t s);
 // plain distance of n contiguous rows against one query (zh_distance_batch)
+#define ZH_DISTANCE_SCRATCH_BYTES (sizeof(ZhGroup) + 16)
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
-                                   uint64_t *dKeys, hipStream_t s);
+                                   uint64_t *dKeys, void *dScratch, hipStream_t s);
 
 // ---- launchers (zh_build.hip) ----------------------------------------------------------------
 struct ZhBuildNode {   // an active (to be split) node of the current level

@@ -398,21 +398,21 @@ hipError_t zh_launch_qnorm(const float *dQ, uint32_t B, uint32_t d, float *dQQ, 
 #define WALK_STACK 64
 #define WALK_BUF 16
 
-// emit pass: the s-th visit of a leaf joins group s / ZH_GROUP of that leaf as member s % ZH_GROUP
-__device__ __forceinline__ void join_group(const ZhVisit &v, const uint32_t *__restrict__ leafCount,
+// emit pass: the s-th visit of a leaf joins group s / GRP of that leaf as member s % GRP
+__device__ __forceinline__ void join_group(const uint32_t GRP, const ZhVisit &v, const uint32_t *__restrict__ leafCount,
                                            uint32_t *__restrict__ leafFill, const uint32_t *__restrict__ groupBase,
                                            const uint64_t *__restrict__ groupRowBase, ZhGroup *__restrict__ groups,
                                            uint64_t *__restrict__ groupRowOff) {
     const uint32_t s = atomicAdd(&leafFill[v.node], 1u);
     const uint32_t c = leafCount[v.node];
-    const uint32_t gl = s / ZH_GROUP, slot = s % ZH_GROUP;
+    const uint32_t gl = s / GRP, slot = s % GRP;
     const uint32_t g = groupBase[v.node] + gl;
-    const uint32_t rest = c - gl * ZH_GROUP;
+    const uint32_t rest = c - gl * GRP;
     ZhGroup *G = groups + g;
     G->b[slot] = v.b;
     G->key_off[slot] = v.row_off;
     if (slot == 0) {
-        G->leaf_off = v.leaf_off; G->len = v.len; G->gsize = rest < ZH_GROUP ? rest : ZH_GROUP; G->pad = 0;
+        G->leaf_off = v.leaf_off; G->len = v.len; G->gsize = rest < GRP ? rest : GRP; G->pad = 0;
         groupRowOff[g] = groupRowBase[v.node] + (uint64_t)gl * v.len;
     }
 }
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                 v.row_off += rowBase[pair];
                 v.cand_off += candBase[pair];
                 visits[visitBase[pair] + i] = v;
-                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+                join_group(f.group, v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
             }
             active = false;
         }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
         if (EMIT) {
             if (mine) {
                 visits[vb + vi] = v;
-                join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+                join_group(f.group, v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
             }
         } else {
             if (mine) {
@@ -751,6 +751,159 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// walk over the BLOCKED forest (every sign precomputed): one (query, tree) pair per wave.  The pointer-based walk above
+// pays a memory round trip (~1 us on a busy chip) for every node it steps on; the wandering walk of small-leaf forests
+// (thousands of leaf visits per pair, ~3 new inner nodes per visit) is nothing but such steps.  Here the bottom
+// of every tree is cut into blocks of <= 64 nodes: lane i loads record i of the block the walk enters (one coalesced
+// 1-KiB load) and gathers that node's sign bit, and the DFS inside the block then runs on v_readlane / v_writelane with a
+// wave-uniform cursor (the block's own stack is one VGPR, entry j in lane j) -- no memory access at all until the walk
+// leaves the block.  Same control flow as tree_result
+// (lsh.rs:290-348), same visit order, same logs as walk_kernel<false, ..., ALLDENSE>.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rl(int v, uint32_t lane) { return __builtin_amdgcn_readlane(v, (int)lane); }
+
+__global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
+                                                           const uint32_t *__restrict__ bits, uint32_t wpq,
+                                                           ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
+                                                           uint32_t *__restrict__ leafCount, ZhWalkLog wlog) {
+    __shared__ int2 ust[WALK_STACK];  // upper-level stack {child ref, n}
+    __shared__ uint4 vb_a[WALK_BUF];
+    __shared__ uint64_t vb_r[WALK_BUF], vb_c[WALK_BUF];
+    const uint32_t T = f.n_trees, lane = threadIdx.x;
+    const uint64_t pair = blockIdx.x;
+    const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
+    const uint32_t *__restrict__ qbits = bits + (size_t)b * wpq;
+    uint32_t nv = 0, nbuf = 0;
+    uint64_t nrows = 0, ntakes = 0;
+    uint32_t log_chunk = 0xFFFFFFFFu;
+    int32_t log_cn = -1;
+    bool log_ok = true;
+    auto flush = [&]() {  // as walk_kernel's count-pass flush: visits leave the wave WALK_BUF at a time, one lane each
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t first = nv - nbuf, vi = first + lane;
+        const bool mine = lane < nbuf;
+        const uint4 va = vb_a[mine ? lane : 0];
+        ZhVisit v;
+        v.b = b; v.leaf_off = va.y; v.len = va.z; v.take = va.w; v.node = va.x; v.pad = 0;
+        v.row_off = vb_r[mine ? lane : 0]; v.cand_off = vb_c[mine ? lane : 0];
+        if (mine) {
+            atomicAdd(&leafCount[v.node], 1u);
+            if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
+        }
+        if (nv > ZH_INLINE_VISITS && log_ok) {
+            constexpr uint32_t PER = ZH_LOG_CHUNK - 1;
+            const int32_t c1 = (int32_t)((nv - 1 - ZH_INLINE_VISITS) / PER);
+            uint32_t newc = 0xFFFFFFFFu;
+            if (c1 > log_cn) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&wlog.ctl->next_chunk, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= wlog.capacity) {
+                    if (lane == 0) wlog.ctl->overflow = 1u;
+                    log_ok = false;
+                } else {
+                    newc = c;
+                    if (lane == 0) {
+                        if (log_cn < 0) wlog.head[pair] = c;
+                        else wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK].x = c;
+                    }
+                }
+            }
+            if (log_ok) {
+                if (mine && vi >= ZH_INLINE_VISITS) {
+                    const uint32_t li = vi - ZH_INLINE_VISITS;
+                    const uint32_t id = (int32_t)(li / PER) == log_cn ? log_chunk : newc;
+                    wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = make_uint2(v.node, v.take);
+                }
+                if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
+            }
+        }
+        nbuf = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    int32_t ref = __builtin_amdgcn_readfirstlane(blk.root_ref[t]);
+    int32_t n = n0;
+    int usp = 0;
+    for (;;) {
+        if (ref >= 0) {  // an upper (inner) node: one step of the pointer walk
+            const int4 rec = uni4(blk.upper[ref]);
+            const bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)qbits[(uint32_t)rec.x >> 5]) >> (rec.x & 31)) & 1;
+            if (usp < WALK_STACK && lane == 0) ust[usp] = make_int2(above ? rec.y : rec.z, n);
+            usp++;
+            ref = above ? rec.z : rec.y;  // lsh.rs:335-338: above -> right is main
+            continue;
+        }
+        // ---- a block: records and signs into registers, then the DFS without memory ----
+        const uint32_t bi = (uint32_t)(-ref - 1);
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk.start[bi]);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk.start[bi + 1]) - s0;
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (lane < cnt) r = blk.recs[s0 + lane];
+        int sgn = 0;
+        if (r.x >= 0) sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
+        int lstk = 0;          // the block's DFS stack: lane j holds entry j = local node | n << 8
+        uint32_t lsp = 0, cur = 0;
+        int32_t ret = 0;
+        for (;;) {
+            const int x = rl(r.x, cur);
+            if (x >= 0) {
+                const int ch = rl(r.y, cur), ab = rl(sgn, cur);
+                const uint32_t l = (uint32_t)ch & 0xFFFFu, rr = (uint32_t)ch >> 16;
+                lstk = lane == lsp ? (int)((ab ? l : rr) | ((uint32_t)n << 8)) : lstk;  // "v_writelane": one compare + select
+                lsp++;
+                cur = ab ? rr : l;
+                continue;
+            }
+            const uint32_t off = (uint32_t)rl(r.y, cur), len = (uint32_t)rl(r.z, cur), node = (uint32_t)rl(r.w, cur);
+            const uint32_t take = n <= 0 ? 0u : (len < (uint32_t)n ? len : (uint32_t)n);
+            ret = (int32_t)take;  // lsh.rs:306 / 329
+            if (take > 0) {
+                if (lane == 0) { vb_a[nbuf] = make_uint4(node, off, len, take); vb_r[nbuf] = nrows; vb_c[nbuf] = ntakes; }
+                nbuf++; nv++; nrows += len; ntakes += take;
+                if (nbuf == WALK_BUF) flush();
+            }
+            bool down = false;
+            while (lsp > 0) {
+                lsp--;
+                const uint32_t e = (uint32_t)rl(lstk, lsp);
+                const int32_t nn = (int32_t)(e >> 8);
+                if (ret < nn) { cur = e & 0xFFu; n = nn - ret; down = true; break; }  // lsh.rs:341-343
+            }
+            if (!down) break;
+        }
+        // the block returned `ret` to the upper walk
+        bool down = false;
+        __builtin_amdgcn_wave_barrier();
+        while (usp > 0) {
+            usp--;
+            if (usp < WALK_STACK) {
+                const int2 e = ust[usp];
+                const int32_t nn = __builtin_amdgcn_readfirstlane(e.y);
+                if (ret < nn) { ref = __builtin_amdgcn_readfirstlane(e.x); n = nn - ret; down = true; break; }
+            }
+        }
+        if (!down) break;
+    }
+    if (nbuf) flush();
+    if (lane == 0) {
+        ZhPairCounts c;
+        c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
+        counts[pair] = c;
+    }
+}
+
+hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
+                                  uint32_t words_per_q, ZhPairCounts *dCounts, ZhVisit *dInline, uint32_t *dLeafCount,
+                                  ZhWalkLog log, hipStream_t s) {
+    const uint64_t pairs = (uint64_t)B * f.n_trees;
+    if (!pairs) return hipSuccess;
+    hipLaunchKernelGGL(walk_blocked_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, blk, B, n, dBits, words_per_q, dCounts,
+                       dInline, dLeafCount, log);
+    return hipGetLastError();
+}
+
 // expand: one wave per (query, tree) pair places the visits the counting pass recorded -- the inline ones, then the
 // log's chunks, 63 entries at a time with a wave scan for the row / candidate offsets -- and joins the leaf groups.
 __global__ __launch_bounds__(64) void expand_kernel(ZhForestDev f, uint32_t T, const ZhPairCounts *__restrict__ counts,
@@ -773,7 +926,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ZhForestDev f, uint32_t T, c
         v.row_off += rb;
         v.cand_off += cb;
         visits[vb + lane] = v;
-        join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+        join_group(f.group, v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
     }
     if (nv <= ZH_INLINE_VISITS) return;
     const ZhVisit last = inl[pair * ZH_INLINE_VISITS + ZH_INLINE_VISITS - 1];
@@ -800,7 +953,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ZhForestDev f, uint32_t T, c
             v.row_off = rb + run_rows + (sl - len);
             v.cand_off = cb + run_takes + (stk - take);
             visits[vb + idx + lane - 1] = v;
-            join_group(v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
+            join_group(f.group, v, leafCount, leafFill, groupBase, groupRowBase, groups, groupRowOff);
         }
         run_rows += __shfl(sl, 63);
         run_takes += __shfl(stk, 63);
@@ -820,7 +973,7 @@ hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCoun
     return hipGetLastError();
 }
 
-// leaf allocation: node i with c visits forms ceil(c / ZH_GROUP) groups of len(i) rows each.  Group indices
+// leaf allocation: node i with c visits forms ceil(c / group) groups of len(i) rows each.  Group indices
 // and flat row offsets are handed out by ONE packed 64-bit atomic (groups << 36 | rows), so both are
 // monotone in the same (arbitrary) order -- the sweep's binary search only needs that.
 __global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const uint32_t *__restrict__ leafCount,
@@ -831,7 +984,7 @@ __global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const ui
     if (i >= f.n_nodes) return;
     uint32_t c = leafCount[i];
     if (!c) return;
-    uint64_t ng = (c + ZH_GROUP - 1) / ZH_GROUP;
+    uint64_t ng = (c + f.group - 1) / f.group;
     uint64_t rows = ng * (uint32_t)f.node_right[i];
     unsigned long long old = atomicAdd(packed, (unsigned long long)((ng << 36) | rows));
     groupBase[i] = (uint32_t)(old >> 36);
@@ -957,9 +1110,9 @@ __device__ __forceinline__ void load_row(const float *__restrict__ row, uint32_t
     }
 }
 
-// one row against the (up to ZH_GROUP) queries of its group.  s0[m] (and s1[m] for Bray-Curtis) are per
+// one row against the (up to G) queries of its group.  s0[m] (and s1[m] for Bray-Curtis) are per
 // member; for cosine s1[0] carries a2, the stored row's norm, shared by the members
-template <int D, int KIND>
+template <int D, int KIND, int G>
 __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q)[RowVec<D>::NV], uint32_t gsize,
                                                uint32_t lane, int power, float *s0, float *s1) {
     constexpr int NV = RowVec<D>::NV;
@@ -976,7 +1129,7 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
         s1[0] = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
     }
 #pragma unroll
-    for (int m = 0; m < ZH_GROUP; m++) {
+    for (int m = 0; m < G; m++) {
         if ((uint32_t)m < gsize) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
 #pragma unroll
@@ -996,7 +1149,7 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
 }
 
 // D > 0: compile-time dimension (multiple of 4); D == 0: runtime d, any value (slow path)
-template <int D, int KIND, int SWEEP_RG = 4, bool NT = false>
+template <int D, int KIND, int G, int SWEEP_RG = 4, bool NT = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X, uint32_t d,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
@@ -1023,13 +1176,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
         uint32_t lo_off = groups[lo].leaf_off;
         my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
     }
-    float mine0[ZH_GROUP], mine1[ZH_GROUP];
+    float mine0[G], mine1[G];
 #pragma unroll
-    for (int m = 0; m < ZH_GROUP; m++) { mine0[m] = 0.f; mine1[m] = 0.f; }
+    for (int m = 0; m < G; m++) { mine0[m] = 0.f; mine1[m] = 0.f; }
     if (D > 0) {
         constexpr int DD = (D > 0 ? D : 4);
         constexpr int NV = RowVec<DD>::NV;
-        float4 q[ZH_GROUP][NV];
+        float4 q[G][NV];
         uint32_t cur_g = 0xFFFFFFFFu, gsize = 0;
         for (uint32_t i0 = 0; i0 < cnt; i0 += SWEEP_RG) {
             float4 v[SWEEP_RG][NV];
@@ -1048,16 +1201,16 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                         cur_g = g;
                         gsize = groups[g].gsize;
 #pragma unroll
-                        for (int m = 0; m < ZH_GROUP; m++)
+                        for (int m = 0; m < G; m++)
                             if ((uint32_t)m < gsize) load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[m]);
                     }
-                    float s0[ZH_GROUP], s1[ZH_GROUP];
+                    float s0[G], s1[G];
 #pragma unroll
-                    for (int m = 0; m < ZH_GROUP; m++) { s0[m] = 0.f; s1[m] = 0.f; }
-                    row_sums_group<DD, KIND>(v[r], q, gsize, lane, param, s0, s1);
+                    for (int m = 0; m < G; m++) { s0[m] = 0.f; s1[m] = 0.f; }
+                    row_sums_group<DD, KIND, G>(v[r], q, gsize, lane, param, s0, s1);
                     if (lane == i) {
 #pragma unroll
-                        for (int m = 0; m < ZH_GROUP; m++) { mine0[m] = s0[m]; mine1[m] = KIND == K_COS ? s1[0] : s1[m]; }
+                        for (int m = 0; m < G; m++) { mine0[m] = s0[m]; mine1[m] = KIND == K_COS ? s1[0] : s1[m]; }
                     }
                 }
             }
@@ -1072,18 +1225,18 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                 lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)groups[g].b[m] * d, d, lane, param, t0, t1);
                 if (lane == i) {
 #pragma unroll
-                    for (int mm = 0; mm < ZH_GROUP; mm++)
+                    for (int mm = 0; mm < G; mm++)
                         if ((uint32_t)mm == m) { mine0[mm] = t0; mine1[mm] = t1; }
                 }
             }
         }
     }
     if (lane < cnt) {
-        const ZhGroup G = groups[my_g];
+        const ZhGroup grp = groups[my_g];
 #pragma unroll
-        for (int m = 0; m < ZH_GROUP; m++)
-            if ((uint32_t)m < G.gsize)
-                keys[G.key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1[m], KIND == K_COS ? QQ[G.b[m]] : 0.f);
+        for (int m = 0; m < G; m++)
+            if ((uint32_t)m < grp.gsize)
+                keys[grp.key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1[m], KIND == K_COS ? QQ[grp.b[m]] : 0.f);
     }
 }
 
@@ -1094,8 +1247,8 @@ uint64_t zh_sweep_rows_per_launch(uint32_t d) {
     return rows < 65536 ? 65536 : rows;
 }
 
-template <int D, int KIND>
-static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
+template <int D, int KIND, int G>
+static hipError_t launch_sweep_g(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
                                  const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                  const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
                                  hipStream_t s) {
@@ -1112,13 +1265,24 @@ static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, c
         uint64_t blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
         if (variant == 1)
-            hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
                                dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
         else
-            hipLaunchKernelGGL((sweep_kernel<D, KIND, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
                                dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
     }
     return hipGetLastError();
+}
+
+static thread_local uint32_t g_sweep_group = 2;  // set by zh_launch_sweep for the launch being issued
+template <int D, int KIND>
+static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
+                                 const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
+                                 hipStream_t s) {
+    if (g_sweep_group == 4)
+        return launch_sweep_g<D, KIND, 4>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
+    return launch_sweep_g<D, KIND, 2>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
 }
 
 // the two simsimd-path kinds get every specialised dimension; the ten `distances`-path kinds the three
@@ -1149,10 +1313,17 @@ static hipError_t launch_sweep_kind(const float *dX, uint32_t d, const float *dQ
 #undef ZH_SWEEP_CASE
 }
 
+uint32_t zh_group_size(uint32_t dim) {
+    static const int forced = [] { const char *e = getenv("ZH_GROUP"); return e ? atoi(e) : 0; }();
+    if (forced == 2 || forced == 4) return (uint32_t)forced;
+    return dim <= 128 ? 2u : 4u;
+}
+
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
-                           uint64_t R_grouped, int metric, int param, uint64_t *dKeys, hipStream_t s) {
+                           uint64_t R_grouped, int metric, int param, uint64_t *dKeys, uint32_t group, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
+    g_sweep_group = group == 4 ? 4u : 2u;
 #define ZH_KIND_CASE(K) \
     case K: return launch_sweep_kind<K>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s)
     switch (zh_kind_of(metric)) {
@@ -1173,25 +1344,20 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
 // n contiguous rows against one query: a single synthetic group, ids = row numbers
 __global__ void one_group_kernel(ZhGroup *g, uint64_t *rowoff, uint64_t n) {
     g->leaf_off = 0; g->len = (uint32_t)n; g->gsize = 1; g->pad = 0;
-    for (int m = 0; m < ZH_GROUP; m++) { g->b[m] = 0; g->key_off[m] = 0; }
+    for (int m = 0; m < ZH_GROUP_MAX; m++) { g->b[m] = 0; g->key_off[m] = 0; }
     rowoff[0] = 0;
 }
+// scratch: one ZhGroup, one u64 row offset and one float (the query's norm), caller-owned device memory
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
-                                   uint64_t *dKeys, hipStream_t s) {
+                                   uint64_t *dKeys, void *dScratch, hipStream_t s) {
     if (!n) return hipSuccess;
-    ZhGroup *dg = nullptr;
-    uint64_t *dro = nullptr;
-    float *dqq = nullptr;
-    hipError_t e;
-    if ((e = hipMalloc(&dg, sizeof(ZhGroup))) != hipSuccess) return e;
-    if ((e = hipMalloc(&dro, 8)) != hipSuccess) { hipFree(dg); return e; }
-    if ((e = hipMalloc(&dqq, 4)) != hipSuccess) { hipFree(dg); hipFree(dro); return e; }
+    ZhGroup *dg = reinterpret_cast<ZhGroup *>(dScratch);
+    uint64_t *dro = reinterpret_cast<uint64_t *>(dg + 1);
+    float *dqq = reinterpret_cast<float *>(dro + 1);
     hipLaunchKernelGGL(one_group_kernel, dim3(1), dim3(1), 0, s, dg, dro, n);
-    e = zh_launch_qnorm(dq, 1, d, dqq, s);
-    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dg, dro, 1, nullptr, n, metric, mode, dKeys, s);
-    hipError_t e2 = hipStreamSynchronize(s);
-    hipFree(dg); hipFree(dro); hipFree(dqq);
-    return e != hipSuccess ? e : e2;
+    hipError_t e = zh_launch_qnorm(dq, 1, d, dqq, s);
+    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dg, dro, 1, nullptr, n, metric, mode, dKeys, 2, s);
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------
