@@ -7,17 +7,51 @@
 //! rayon loop of `Database::query_vectors` (`src/database/core.rs:299-303`) through `search_batch`.
 #![allow(non_camel_case_types)]
 
+use std::collections::HashMap;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 use std::sync::{Arc, RwLock};
 
+use dashmap::{DashMap, DashSet};
+use space::Metric;
 use uuid::Uuid;
 
 pub type DistanceUnit = u64; // src/distance.rs:13
 pub type EmbeddingPrecision = f32; // src/lib.rs:48
 
-/// `Embedding<N>` of the reference is a newtype over `[f32; N]` (src/lib.rs:18); the shim takes plain arrays.
-pub type Embedding<const N: usize> = [EmbeddingPrecision; N];
+/// `Embedding<N>` as in the reference (src/lib.rs:15-46): a newtype over `[f32; N]` with Deref / DerefMut / Default /
+/// From / TryFrom.  `repr(transparent)`: a `&[Embedding<N>]` is `len * N` contiguous f32, which is what crosses the FFI.
+/// (The reference also derives serde's Serialize / Deserialize through `serde_with`; unchanged, omitted here.)
+#[repr(transparent)]
+#[derive(Debug, Clone)]
+pub struct Embedding<const N: usize>([EmbeddingPrecision; N]);
+impl<const N: usize> std::ops::Deref for Embedding<N> {
+    type Target = [EmbeddingPrecision; N];
+    fn deref(&self) -> &[EmbeddingPrecision; N] {
+        &self.0
+    }
+}
+impl<const N: usize> std::ops::DerefMut for Embedding<N> {
+    fn deref_mut(&mut self) -> &mut [EmbeddingPrecision; N] {
+        &mut self.0
+    }
+}
+impl<const N: usize> Default for Embedding<N> {
+    fn default() -> Self {
+        Self([0.0; N])
+    }
+}
+impl<const N: usize> From<[EmbeddingPrecision; N]> for Embedding<N> {
+    fn from(value: [EmbeddingPrecision; N]) -> Self {
+        Self(value)
+    }
+}
+impl<const N: usize> TryFrom<Vec<EmbeddingPrecision>> for Embedding<N> {
+    type Error = Vec<EmbeddingPrecision>;
+    fn try_from(value: Vec<EmbeddingPrecision>) -> Result<Self, Self::Error> {
+        Ok(Self(value.try_into()?))
+    }
+}
 
 pub mod ffi {
     use super::*;
@@ -103,8 +137,11 @@ impl Drop for HipIndex {
     }
 }
 
-/// What a metric struct must tell the index so that it can run on the device.
-pub trait BatchMetric {
+/// What a metric struct tells the index so that the batched search can run it on the device.  Every metric struct of
+/// `src/distance.rs` implements it, so every call site of the reference compiles unchanged against
+/// `search<Met: Metric<Embedding<N>, Unit = DistanceUnit> + HipMetric + Send + Sync>` -- the reference's own bound
+/// (lsh.rs:544-549) plus this one marker, which is the only addition to any public signature.
+pub trait HipMetric {
     const METRIC: c_int;
     /// cosine mode for `CosineDistance`, `power` for Minkowski / p-norm, ignored otherwise
     fn param(&self) -> c_int {
@@ -117,10 +154,10 @@ macro_rules! simple_metric {
         #[doc = $doc]
         #[derive(Default, Debug, Clone)]
         pub struct $name<const N: usize>;
-        impl<const N: usize> BatchMetric for $name<N> {
+        impl<const N: usize> HipMetric for $name<N> {
             const METRIC: c_int = $code;
         }
-        impl<const N: usize> space::Metric<Embedding<N>> for $name<N> {
+        impl<const N: usize> Metric<Embedding<N>> for $name<N> {
             type Unit = DistanceUnit;
             fn distance(&self, a: &Embedding<N>, b: &Embedding<N>) -> DistanceUnit {
                 let mut key = 0u64;
@@ -146,7 +183,7 @@ simple_metric!(HammingDistance, ffi::ZH_HAMMING, "src/distance.rs:140-158");
 pub struct MinkowskiDistance<const N: usize> {
     pub power: i32,
 }
-impl<const N: usize> BatchMetric for MinkowskiDistance<N> {
+impl<const N: usize> HipMetric for MinkowskiDistance<N> {
     const METRIC: c_int = ffi::ZH_MINKOWSKI;
     fn param(&self) -> c_int {
         self.power
@@ -157,12 +194,26 @@ impl<const N: usize> BatchMetric for MinkowskiDistance<N> {
 pub struct PNormDistance<const N: usize> {
     pub power: i32,
 }
-impl<const N: usize> BatchMetric for PNormDistance<N> {
+impl<const N: usize> HipMetric for PNormDistance<N> {
     const METRIC: c_int = ffi::ZH_PNORM;
     fn param(&self) -> c_int {
         self.power
     }
 }
+macro_rules! power_metric {
+    ($name:ident, $code:expr) => {
+        impl<const N: usize> Metric<Embedding<N>> for $name<N> {
+            type Unit = DistanceUnit;
+            fn distance(&self, a: &Embedding<N>, b: &Embedding<N>) -> DistanceUnit {
+                let mut key = 0u64;
+                let _ = unsafe { ffi::zh_distance_pair($code, self.power, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                key
+            }
+        }
+    };
+}
+power_metric!(MinkowskiDistance, ffi::ZH_MINKOWSKI);
+power_metric!(PNormDistance, ffi::ZH_PNORM);
 
 /// lsh.rs:122-139
 #[derive(Debug, Clone)]
@@ -180,7 +231,14 @@ impl<const N: usize> Default for LSHIndexOptions<N> {
 #[derive(Clone)]
 pub struct LSHIndex<const N: usize> {
     hip: Arc<HipIndex>,
-    uuids: Arc<RwLock<Vec<Uuid>>>, // row -> Uuid (Uuid::now_v7 at add time, lsh.rs:415)
+    ids: Arc<RwLock<IdTable>>,
+}
+
+/// row <-> Uuid (the library's ids are dense row numbers; Uuid::now_v7 at add time as in lsh.rs:415)
+#[derive(Default)]
+struct IdTable {
+    of_row: Vec<Uuid>,
+    row_of: HashMap<Uuid, u64>,
 }
 
 impl<const N: usize> LSHIndex<N> {
@@ -192,7 +250,7 @@ impl<const N: usize> LSHIndex<N> {
         o.num_trees = options.num_trees as u32;
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::zh_index_create(&o, &mut h) })?;
-        Ok(Self { hip: Arc::new(HipIndex(h)), uuids: Default::default() })
+        Ok(Self { hip: Arc::new(HipIndex(h)), ids: Default::default() })
     }
     pub fn save(&self) -> anyhow::Result<()> {
         Ok(())
@@ -210,49 +268,139 @@ impl<const N: usize> LSHIndex<N> {
     /// lsh.rs:440-466
     pub fn add(&self, embeddings: &Vec<Embedding<N>>) -> anyhow::Result<Vec<Uuid>> {
         let ids: Vec<Uuid> = embeddings.iter().map(|_| Uuid::now_v7()).collect();
+        let mut t = self.ids.write().unwrap(); // rows are numbered in insertion order: hold the table across the call
         check(unsafe { ffi::zh_index_add(self.hip.0, embeddings.as_ptr() as *const f32, embeddings.len(), std::ptr::null_mut()) })?;
-        self.uuids.write().unwrap().extend(ids.iter().copied());
+        for u in &ids {
+            let row = t.of_row.len() as u64;
+            t.of_row.push(*u);
+            t.row_of.insert(*u, row);
+        }
         Ok(ids)
     }
 
     /// lsh.rs:544-565
-    pub fn search<Met: BatchMetric>(&self, query: &Embedding<N>, top_k: usize, metric: &Met) -> anyhow::Result<Vec<(Uuid, DistanceUnit)>> {
+    pub fn search<Met: Metric<Embedding<N>, Unit = DistanceUnit> + HipMetric + Send + Sync>(
+        &self,
+        query: &Embedding<N>,
+        top_k: usize,
+        metric: &Met,
+    ) -> anyhow::Result<Vec<(Uuid, DistanceUnit)>> {
         Ok(self.search_batch(std::slice::from_ref(query), top_k, metric)?.pop().unwrap_or_default())
     }
 
     /// the rayon loop of core.rs:299-303 as one call
-    pub fn search_batch<Met: BatchMetric>(&self, queries: &[Embedding<N>], top_k: usize, metric: &Met) -> anyhow::Result<Vec<Vec<(Uuid, DistanceUnit)>>> {
+    pub fn search_batch<Met: Metric<Embedding<N>, Unit = DistanceUnit> + HipMetric + Send + Sync>(
+        &self,
+        queries: &[Embedding<N>],
+        top_k: usize,
+        metric: &Met,
+    ) -> anyhow::Result<Vec<Vec<(Uuid, DistanceUnit)>>> {
         let b = queries.len();
         let (mut ids, mut keys, mut counts) = (vec![0u64; b * top_k], vec![0u64; b * top_k], vec![0u32; b]);
         check(unsafe {
             ffi::zh_search_batch(self.hip.0, queries.as_ptr() as *const f32, b, top_k, Met::METRIC, metric.param(), ids.as_mut_ptr(),
                                  keys.as_mut_ptr(), counts.as_mut_ptr())
         })?;
-        let uu = self.uuids.read().unwrap();
-        Ok((0..b).map(|i| (0..counts[i] as usize).map(|j| (uu[ids[i * top_k + j] as usize], keys[i * top_k + j])).collect()).collect())
+        let t = self.ids.read().unwrap();
+        Ok((0..b).map(|i| (0..counts[i] as usize).map(|j| (t.of_row[ids[i * top_k + j] as usize], keys[i * top_k + j])).collect()).collect())
     }
 
     /// lsh.rs:473-503 (as intended: the ids leave every tree)
-    pub fn remove(&self, embedding_ids: &Vec<Uuid>) -> anyhow::Result<Vec<Uuid>> {
-        let uu = self.uuids.read().unwrap();
-        let rows: Vec<u64> = embedding_ids.iter().filter_map(|u| uu.iter().position(|x| x == u).map(|r| r as u64)).collect();
+    pub fn remove(&self, embedding_ids: &Vec<Uuid>) -> anyhow::Result<DashSet<Uuid>> {
+        let t = self.ids.read().unwrap();
+        let rows: Vec<u64> = embedding_ids.iter().filter_map(|u| t.row_of.get(u).copied()).collect(); // O(1) per id
         let mut found = vec![0u8; rows.len()];
         check(unsafe { ffi::zh_index_remove(self.hip.0, rows.as_ptr(), rows.len(), found.as_mut_ptr(), std::ptr::null_mut()) })?;
-        Ok(rows.iter().zip(found).filter(|(_, f)| *f != 0).map(|(r, _)| uu[*r as usize]).collect())
+        let removed = DashSet::new();
+        for (r, f) in rows.iter().zip(found) {
+            if f != 0 {
+                removed.insert(t.of_row[*r as usize]);
+            }
+        }
+        Ok(removed)
     }
 
     /// lsh.rs:270-288
-    pub fn deduplicate(&self) -> anyhow::Result<Vec<Uuid>> {
+    pub fn deduplicate(&self) -> anyhow::Result<DashSet<Uuid>> {
         let cap = unsafe { ffi::zh_index_count(self.hip.0) } as usize + 1;
         let (mut out, mut n) = (vec![0u64; cap], 0usize);
         check(unsafe { ffi::zh_index_deduplicate(self.hip.0, out.as_mut_ptr(), cap, &mut n) })?;
-        let uu = self.uuids.read().unwrap();
-        Ok(out[..n.min(cap)].iter().map(|r| uu[*r as usize]).collect())
+        let t = self.ids.read().unwrap();
+        Ok(out[..n.min(cap)].iter().map(|r| t.of_row[*r as usize]).collect())
     }
 
     /// lsh.rs:506-529
     pub fn clear(&self) -> anyhow::Result<()> {
-        self.uuids.write().unwrap().clear();
+        let mut t = self.ids.write().unwrap();
+        t.of_row.clear();
+        t.row_of.clear();
         check(unsafe { ffi::zh_index_clear(self.hip.0) })
+    }
+}
+
+/// The model side of `Database<N, Met, Mod>` (src/model/core.rs:12-37) is untouched by this path; a marker stands in.
+pub trait DatabaseEmbeddingModel<const N: usize> {}
+
+/// `Database<N, Met, Mod>` (src/database/core.rs:55-62) for the two calls on the hot path.  In the reference the
+/// struct also carries the header (`DatabaseInner`) and a path, and documents live in lz4 files
+/// (`save_documents_to_disk` / `read_documents_from_disk`, core.rs:322-380): unchanged code, represented here by an
+/// in-memory map so that the skeleton is self-contained.
+#[derive(Clone)]
+pub struct Database<
+    const N: usize,
+    Met: Metric<Embedding<N>, Unit = DistanceUnit> + HipMetric + Default + Send + Sync,
+    Mod: DatabaseEmbeddingModel<N> + Default + Send + Sync,
+> {
+    metric: Met,
+    #[allow(dead_code)]
+    model: Mod,
+    /// The database index used to approximate nearest-neighbour search (pub field, core.rs:62).
+    pub index: LSHIndex<N>,
+    documents: Arc<DashMap<Uuid, Vec<u8>>>,
+}
+
+impl<
+        const N: usize,
+        Met: Metric<Embedding<N>, Unit = DistanceUnit> + HipMetric + Default + Send + Sync,
+        Mod: DatabaseEmbeddingModel<N> + Default + Send + Sync,
+    > Database<N, Met, Mod>
+{
+    pub fn new(uuid: &Uuid, index_options: &LSHIndexOptions<N>) -> anyhow::Result<Self> {
+        Ok(Self { metric: Met::default(), model: Mod::default(), index: LSHIndex::new(uuid, index_options)?, documents: Default::default() })
+    }
+
+    /// core.rs:245-254
+    pub fn insert_records(&self, embeddings: &Vec<Embedding<N>>, documents: &Vec<Vec<u8>>) -> anyhow::Result<()> {
+        let embedding_ids = self.index.add(embeddings)?;
+        for (id, doc) in embedding_ids.iter().zip(documents) {
+            self.documents.insert(*id, doc.clone());
+        }
+        Ok(())
+    }
+
+    /// core.rs:290-313: the rayon loop over queries (core.rs:299-303) is ONE batched call; order and distances are
+    /// dropped as in core.rs:304-305.  A batch has no per-query failure mode, so a library error is returned, not
+    /// turned into empty entries (the reference's `unwrap_or_default` is per query).
+    pub fn query_vectors(&self, vectors: &Vec<Embedding<N>>, number_of_results: usize) -> anyhow::Result<DashMap<usize, DashMap<Uuid, Vec<u8>>>> {
+        if self.index.no_vectors() {
+            return Ok(DashMap::new()); // core.rs:295-297
+        }
+        let results = DashMap::new();
+        for (idx, neighbours) in self.index.search_batch(vectors, number_of_results, &self.metric)?.into_iter().enumerate() {
+            let docs = DashMap::new();
+            for (id, _) in neighbours {
+                docs.insert(id, self.documents.get(&id).map(|d| d.clone()).unwrap_or_default());
+            }
+            results.insert(idx, docs);
+        }
+        Ok(results)
+    }
+
+    /// core.rs:205-214
+    pub fn remove(&self, embedding_ids: &Vec<Uuid>) -> anyhow::Result<()> {
+        for id in self.index.remove(embedding_ids)?.iter() {
+            self.documents.remove(&*id);
+        }
+        Ok(())
     }
 }
