@@ -140,8 +140,8 @@ struct zh_index {
     uint64_t n_dead = 0;
     uint32_t max_leaf_len = 0;
     // blocked view of the forest (ZhBlocksDev) for all-dense walks: built on first use, dropped whenever the trees change
-    DevBuf blk_recs, blk_start, blk_upper, blk_roots;
-    uint32_t n_blocks = 0;
+    DevBuf blk_recs, blk_upper, blk_roots;
+    uint32_t n_blocks = 0, n_upper = 0;
     bool blocks_valid = false;
     std::mutex blk_mu;
 
@@ -253,7 +253,7 @@ extern "C" int zh_index_create(const zh_options *opt, zh_index **out) {
 static void free_forest(zh_index *ix) {
     ix->node_plane.release(); ix->node_left.release(); ix->node_right.release(); ix->node_pack.release(); ix->roots.release();
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
-    ix->blk_recs.release(); ix->blk_start.release(); ix->blk_upper.release(); ix->blk_roots.release();
+    ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
@@ -1014,16 +1014,13 @@ static int build_blocks(zh_index *ix) {
             size[n] = 1 + (ix->h_plane[n] >= 0 ? size[(uint32_t)ix->h_left[n]] + size[(uint32_t)ix->h_right[n]] : 0);
         }
     }
-    std::vector<int4> recs, upper(std::max<size_t>(nn, 1), make_int4(-1, 0, 0, 0));
-    std::vector<uint32_t> start;
-    std::vector<int32_t> roots(std::max<uint32_t>(T, 1), 0);
-    recs.reserve(nn);
-    std::vector<float> hc(ix->n_planes);
-    if (ix->n_planes) HIPCHK(hipMemcpy(hc.data(), ix->consts.p, (size_t)ix->n_planes * 4, hipMemcpyDeviceToHost));
+    std::vector<int4> recs, upper;
+    std::vector<int2> roots(std::max<uint32_t>(T, 1), make_int2(0, 0));
+    recs.reserve(nn + ZH_BLOCK_NODES);
     std::vector<uint32_t> nodes;
+    uint32_t n_blocks = 0;
     auto emit_block = [&](uint32_t root) -> int32_t {  // nodes of the subtree in pre-order, children as local indices
-        const uint32_t base = (uint32_t)recs.size();
-        start.push_back(base);
+        const size_t base = recs.size();
         nodes.clear();
         st.assign(1, root);
         while (!st.empty()) {
@@ -1036,43 +1033,51 @@ static int build_blocks(zh_index *ix) {
             const uint32_t n = nodes[i];
             if (ix->h_plane[n] >= 0) {
                 const uint32_t l = i + 1, r = i + 1 + size[(uint32_t)ix->h_left[n]];
-                recs.push_back(make_int4(ix->h_plane[n], (int)(l | (r << 16)), 0, (int)n));
+                recs.push_back(make_int4(ix->h_plane[n], (int)(l | (r << 16)), i == 0 ? (int)nodes.size() : 0, (int)n));
             } else
                 recs.push_back(make_int4(-1, ix->h_left[n], ix->h_right[n], (int)n));
         }
-        return -(int32_t)(start.size() - 1) - 1;
+        n_blocks++;
+        return -(int32_t)base - 1;
     };
-    auto ref_of = [&](uint32_t n) -> int32_t { return size[n] <= ZH_BLOCK_NODES ? emit_block(n) : (int32_t)n; };
+    // upper nodes get dense ids in the order they are met; a child's ref is final once the child has been classified
+    std::vector<uint32_t> up;
+    std::vector<std::pair<uint32_t, uint32_t>> todo;  // (node, its upper id)
     for (uint32_t t = 0; t < T; t++) {
-        st.assign(1, ix->h_roots[t]);
-        std::vector<uint32_t> up;  // upper nodes of this tree (subtree larger than a block), top-down
-        if (size[ix->h_roots[t]] <= ZH_BLOCK_NODES) { roots[t] = emit_block(ix->h_roots[t]); continue; }
-        roots[t] = (int32_t)ix->h_roots[t];
-        up.push_back(ix->h_roots[t]);
-        while (!up.empty()) {
-            const uint32_t n = up.back(); up.pop_back();
-            const uint32_t l = (uint32_t)ix->h_left[n], r = (uint32_t)ix->h_right[n];
-            const int32_t lr = ref_of(l), rr = ref_of(r);
-            float cf = hc[(uint32_t)ix->h_plane[n]];
-            int cb;
-            memcpy(&cb, &cf, 4);
-            upper[n] = make_int4(ix->h_plane[n], lr, rr, cb);
-            if (lr >= 0) up.push_back(l);
-            if (rr >= 0) up.push_back(r);
+        const uint32_t rt = ix->h_roots[t];
+        if (size[rt] <= ZH_BLOCK_NODES) { roots[t] = make_int2(emit_block(rt), 0); continue; }
+        roots[t] = make_int2((int32_t)(upper.size() / 2), ix->h_plane[rt]);
+        upper.push_back(make_int4(0, 0, 0, 0)); upper.push_back(make_int4(0, 0, 0, 0));
+        todo.assign(1, {rt, (uint32_t)(upper.size() / 2 - 1)});
+        while (!todo.empty()) {
+            const auto [n, uid] = todo.back(); todo.pop_back();
+            const uint32_t ch[2] = {(uint32_t)ix->h_left[n], (uint32_t)ix->h_right[n]};
+            int32_t ref[2], cpl[2];
+            for (int e = 0; e < 2; e++) {
+                if (size[ch[e]] <= ZH_BLOCK_NODES) { ref[e] = emit_block(ch[e]); cpl[e] = 0; }
+                else {
+                    ref[e] = (int32_t)(upper.size() / 2); cpl[e] = ix->h_plane[ch[e]];
+                    upper.push_back(make_int4(0, 0, 0, 0)); upper.push_back(make_int4(0, 0, 0, 0));
+                    todo.push_back({ch[e], (uint32_t)ref[e]});
+                }
+            }
+            upper[2 * (size_t)uid] = make_int4(ix->h_plane[n], ref[0], ref[1], 0);
+            upper[2 * (size_t)uid + 1] = make_int4(cpl[0], cpl[1], 0, 0);
         }
     }
-    start.push_back((uint32_t)recs.size());
-    if (recs.size() > 0xFFFFFFF0ull || start.size() > 0x7FFFFFF0ull) return fail(ZH_ELIMIT, "forest too large for the blocked view");
+    if (recs.size() > 0x7FFFFFF0ull || upper.size() > 0x7FFFFFF0ull) return fail(ZH_ELIMIT, "forest too large for the blocked view");
+    const size_t n_recs = recs.size();
+    recs.resize(n_recs + ZH_BLOCK_NODES, make_int4(-1, 0, 0, 0));  // a wave always reads 64 records
+    if (upper.empty()) upper.assign(2, make_int4(0, 0, 0, 0));
     int rc;
-    if ((rc = ix->blk_recs.ensure(std::max<size_t>(recs.size(), 1) * sizeof(int4)))) return rc;
-    if ((rc = ix->blk_start.ensure(start.size() * 4))) return rc;
+    if ((rc = ix->blk_recs.ensure(recs.size() * sizeof(int4)))) return rc;
     if ((rc = ix->blk_upper.ensure(upper.size() * sizeof(int4)))) return rc;
-    if ((rc = ix->blk_roots.ensure(roots.size() * 4))) return rc;
-    if (!recs.empty()) HIPCHK(hipMemcpy(ix->blk_recs.p, recs.data(), recs.size() * sizeof(int4), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ix->blk_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice));
+    if ((rc = ix->blk_roots.ensure(roots.size() * sizeof(int2)))) return rc;
+    HIPCHK(hipMemcpy(ix->blk_recs.p, recs.data(), recs.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->blk_upper.p, upper.data(), upper.size() * sizeof(int4), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ix->blk_roots.p, roots.data(), roots.size() * 4, hipMemcpyHostToDevice));
-    ix->n_blocks = (uint32_t)(start.size() - 1);
+    HIPCHK(hipMemcpy(ix->blk_roots.p, roots.data(), roots.size() * sizeof(int2), hipMemcpyHostToDevice));
+    ix->n_blocks = n_blocks;
+    ix->n_upper = (uint32_t)(upper.size() / 2);
     ix->blocks_valid = true;
     return ZH_OK;
 }
@@ -1181,8 +1186,8 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     static const bool no_blocks = getenv("ZH_WALK_NO_BLOCKS") != nullptr;  // A/B: the pointer walk for all-dense signs too
     if (c->P_dense >= ix->n_planes && ix->n_planes && ix->blocks_valid && !no_blocks) {
         ZhBlocksDev bd;
-        bd.recs = ix->blk_recs.as<int4>(); bd.start = ix->blk_start.as<uint32_t>(); bd.upper = ix->blk_upper.as<int4>();
-        bd.root_ref = ix->blk_roots.as<int32_t>(); bd.n_blocks = ix->n_blocks;
+        bd.recs = ix->blk_recs.as<int4>(); bd.upper = ix->blk_upper.as<int4>(); bd.root = ix->blk_roots.as<int2>();
+        bd.n_blocks = ix->n_blocks; bd.n_upper = ix->n_upper;
         HIPCHK(zh_launch_walk_blocked(f, bd, (uint32_t)B, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->wCounts.as<ZhPairCounts>(),
                                       c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
     } else

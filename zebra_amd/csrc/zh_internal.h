@@ -59,16 +59,17 @@ struct ZhWalkLog {
 
 // Blocked view of the forest for walks that find every sign precomputed (ZH_BLOCK_NODES, zh_api.hip build_blocks): every
 // maximal subtree of at most ZH_BLOCK_NODES nodes is one BLOCK, its nodes stored contiguously in pre-order as 16-byte
-// records {plane | -1, inner: left_local | right_local << 16 / leaf: offset into leaf_ids, leaf: length, global node id}.
-// The nodes above the blocks ("upper" nodes, all inner) keep 16-byte records {plane, left ref, right ref, bits of the
-// constant} whose child refs are >= 0 for an upper node and -(block + 1) for a block.
+// records {plane | -1, inner: left_local | right_local << 16 / leaf: offset into leaf_ids, inner: nodes in the block (root
+// record only) / leaf: length, global node id}.  The nodes above the blocks ("upper" nodes, all inner, numbered densely)
+// keep two 16-byte records: {plane, left ref, right ref, 0} and {plane of the left child, plane of the right child, 0, 0}
+// -- a child's sign can be requested together with its record.  A ref is >= 0 for an upper node and -(offset of the
+// block's first record + 1) for a block: no directory lookup between a ref and its data.
 #define ZH_BLOCK_NODES 64
 struct ZhBlocksDev {
-    const int4 *recs;           // all blocks' node records
-    const uint32_t *start;      // n_blocks + 1 offsets into recs
-    const int4 *upper;          // indexed by global node id (only upper nodes are meaningful)
-    const int32_t *root_ref;    // per tree
-    uint32_t n_blocks;
+    const int4 *recs;           // all blocks' node records (+ ZH_BLOCK_NODES records of padding: a wave always loads 64)
+    const int4 *upper;          // 2 records per upper node
+    const int2 *root;           // per tree: {ref, plane of the root when it is an upper node}
+    uint32_t n_blocks, n_upper;
 };
 
 struct ZhForestDev {

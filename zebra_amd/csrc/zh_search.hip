@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
                                                            const uint32_t *__restrict__ bits, uint32_t wpq,
                                                            ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
                                                            uint32_t *__restrict__ leafCount, ZhWalkLog wlog) {
-    __shared__ int2 ust[WALK_STACK];  // upper-level stack {child ref, n}
+    __shared__ int4 ust[WALK_STACK];  // upper-level stack {child ref, n, the child's plane when it is an upper node}
     __shared__ uint4 vb_a[WALK_BUF];
     __shared__ uint64_t vb_r[WALK_BUF], vb_c[WALK_BUF];
     const uint32_t T = f.n_trees, lane = threadIdx.x;
@@ -823,24 +823,28 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         nbuf = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    int32_t ref = __builtin_amdgcn_readfirstlane(blk.root_ref[t]);
+    const int2 root = blk.root[t];
+    int32_t ref = __builtin_amdgcn_readfirstlane(root.x), pl = __builtin_amdgcn_readfirstlane(root.y);
     int32_t n = n0;
     int usp = 0;
     for (;;) {
-        if (ref >= 0) {  // an upper (inner) node: one step of the pointer walk
-            const int4 rec = uni4(blk.upper[ref]);
-            const bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)qbits[(uint32_t)rec.x >> 5]) >> (rec.x & 31)) & 1;
-            if (usp < WALK_STACK && lane == 0) ust[usp] = make_int2(above ? rec.y : rec.z, n);
+        if (ref >= 0) {  // an upper (inner) node: its records and its sign word are requested together
+            const int4 ra = blk.upper[2 * (size_t)ref], rb = blk.upper[2 * (size_t)ref + 1];
+            const uint32_t word = qbits[(uint32_t)pl >> 5];
+            const int4 a = uni4(ra), c2 = uni4(rb);
+            const bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)word) >> (pl & 31)) & 1;
+            if (usp < WALK_STACK && lane == 0) ust[usp] = make_int4(above ? a.y : a.z, n, above ? c2.x : c2.y, 0);
             usp++;
-            ref = above ? rec.z : rec.y;  // lsh.rs:335-338: above -> right is main
+            ref = above ? a.z : a.y;  // lsh.rs:335-338: above -> right is main
+            pl = above ? c2.y : c2.x;
             continue;
         }
         // ---- a block: records and signs into registers, then the DFS without memory ----
-        const uint32_t bi = (uint32_t)(-ref - 1);
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk.start[bi]);
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk.start[bi + 1]) - s0;
-        int4 r = make_int4(-1, 0, 0, 0);
-        if (lane < cnt) r = blk.recs[s0 + lane];
+        const uint32_t s0 = (uint32_t)(-ref - 1);
+        int4 r = blk.recs[s0 + lane];  // the array is padded: 64 records can always be read
+        const int r0x = rl(r.x, 0);
+        const uint32_t cnt = r0x >= 0 ? (uint32_t)rl(r.z, 0) : 1u;
+        if (lane >= cnt) r = make_int4(-1, 0, 0, 0);
         int sgn = 0;
         if (r.x >= 0) sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
         int lstk = 0;          // the block's DFS stack: lane j holds entry j = local node | n << 8
@@ -879,9 +883,13 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         while (usp > 0) {
             usp--;
             if (usp < WALK_STACK) {
-                const int2 e = ust[usp];
+                const int4 e = ust[usp];
                 const int32_t nn = __builtin_amdgcn_readfirstlane(e.y);
-                if (ret < nn) { ref = __builtin_amdgcn_readfirstlane(e.x); n = nn - ret; down = true; break; }
+                if (ret < nn) {
+                    ref = __builtin_amdgcn_readfirstlane(e.x); pl = __builtin_amdgcn_readfirstlane(e.z); n = nn - ret;
+                    down = true;
+                    break;
+                }
             }
         }
         if (!down) break;
@@ -1615,7 +1623,17 @@ hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uin
     if (max_leaf_len <= 1024)
         hipLaunchKernelGGL(select_kernel<1024>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
-    else
+    else if (max_leaf_len > ZH_SORT_N && max_leaf_len <= 8192) {
+        // leaves of 4097..8192 rows (max_node_size 8192: the 1B x 128-d configuration): 96 KB of the CU's 160 KB of LDS hold
+        // the whole leaf, so its keys cross HBM once instead of once per histogram round (8 bytes per row against the 512-byte
+        // row the sweep read: each extra pass costs the sweep beside it 1.5 % of the memory system)
+        static const bool attr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel<8192>), hipFuncAttributeMaxDynamicSharedMemorySize, 0) == hipSuccess;
+        }();
+        (void)attr;
+        hipLaunchKernelGGL(select_kernel<8192>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
+                           dLeafIds, dKeys, dCandKeys, dCandIds);
+    } else
         hipLaunchKernelGGL(select_kernel<ZH_SORT_N>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
     return hipGetLastError();
