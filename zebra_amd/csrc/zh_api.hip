@@ -90,7 +90,7 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wLogPool, wLogHead, wLogCtl;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wLogPool, wLogHead, wLogCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -109,7 +109,7 @@ struct zh_search_ctx {
     ZhTotals tot{};
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff,
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup,
                         &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
@@ -1248,6 +1248,8 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if ((rc = c->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
     if ((rc = c->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
     if ((rc = c->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;
+    static const bool no_wave_table = getenv("ZH_NO_WAVE_TABLE") != nullptr;  // A/B: per-lane binary search over all groups
+    if (!no_wave_table && (rc = c->wWaveGroup.ensure((tot.group_rows / 64 + 2) * 4))) return rc;
     if ((rc = c->wKeys.ensure(std::max<uint64_t>(tot.rows, 1) * 8))) return rc;
     if ((rc = c->wCandKeys.ensure(std::max<uint64_t>(tot.takes, 1) * 8))) return rc;
     if ((rc = c->wCandIds.ensure(std::max<uint64_t>(tot.takes, 1) * 4))) return rc;
@@ -1275,6 +1277,8 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
             if (c->wLogPool.ensure(chunks * ZH_LOG_CHUNK * sizeof(uint2)) == ZH_OK) c->log_chunks = chunks;
         }
     }
+    if (!no_wave_table)
+        HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
     // successive batches execute back to back while everything else overlaps them on the contexts' own streams
@@ -1282,7 +1286,8 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
     HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
-                           c->wGroupRowOff.as<uint64_t>(), tot.groups, f.leaf_ids, tot.group_rows, c->metric, c->mode,
+                           c->wGroupRowOff.as<uint64_t>(), tot.groups, no_wave_table ? nullptr : c->wWaveGroup.as<uint32_t>(), f.leaf_ids,
+                           tot.group_rows, c->metric, c->mode,
                            c->wKeys.as<uint64_t>(), f.group, hs));
     HIPCHK(hipEventRecord(c->ev_sw1, hs));
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));

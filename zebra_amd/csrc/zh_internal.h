@@ -31,8 +31,7 @@ struct ZhGroup {
     uint32_t b[ZH_GROUP_MAX];
     uint64_t key_off[ZH_GROUP_MAX];  // the member visits' row_off (slice of the key scratch)
 };
-// 4 queries per group where a row is long enough for the loads to dominate; short rows (d <= 128: a 512-byte row is half a
-// wave-load) are bound by the per-(row, query) reduction work as well, and pairs measure faster there.  ZH_GROUP=2|4 forces.
+// 4 queries per group (ZH_GROUP=2|4 forces; A/B in profiles/).
 uint32_t zh_group_size(uint32_t dim);
 
 // per (query, tree) pair counts produced by the walk's first pass, then their exclusive scans
@@ -159,9 +158,14 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint64_t *dCandBase, const uint64_t *dVisitBase, ZhVisit *dVisits,
                                const uint32_t *dLeafCount, uint32_t *dLeafFill, const uint32_t *dGroupBase,
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s);
+// dWaveGroup: the wave-start table of zh_launch_wave_groups (ceil(R_grouped / 64) entries), or nullptr
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
-                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
-                           uint64_t R_grouped, int metric, int mode, uint64_t *dKeys, uint32_t group, hipStream_t s);
+                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dWaveGroup,
+                           const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int mode, uint64_t *dKeys,
+                           uint32_t group, hipStream_t s);
+// waveGroup[w] = group of flat row 64 w, for every wave start of [0, R_grouped)
+hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups, uint32_t *dWaveGroup,
+                                 hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);
 // max_leaf_len: the longest leaf of the forest (picks the LDS footprint of the select blocks)

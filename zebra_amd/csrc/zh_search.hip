@@ -1091,6 +1091,48 @@ hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, ui
 // every lane loading one float4 per 1 KiB of row (coalesced 1 KiB wave loads), RG rows in flight --
 // and lane i keeps the canonical sums of row i.  Keys go to the scratch (8 B per 4*D B read).
 // ------------------------------------------------------------------------------------------------
+// Which group does the wave's first flat row fall in?  One thread per group writes the slots of the wave starts its row range
+// covers (waveGroup[w] = group of flat row 64 w), so a sweep wave starts with ONE load instead of a ~17-step binary search
+// over all groups -- a prologue that costs a 32-KB wave of 512-byte rows as much time as its rows.
+__global__ __launch_bounds__(256) void wave_group_kernel(const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                                                          uint64_t n_groups, uint32_t *__restrict__ waveGroup) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint64_t off = groupRowOff[g], end = off + groups[g].len;
+    for (uint64_t w = (off + 63) >> 6; (w << 6) < end; w++) waveGroup[w] = (uint32_t)g;
+}
+hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups, uint32_t *dWaveGroup,
+                                 hipStream_t s) {
+    if (!n_groups) return hipSuccess;
+    hipLaunchKernelGGL(wave_group_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, dGroups, dGroupRowOff, n_groups,
+                       dWaveGroup);
+    return hipGetLastError();
+}
+
+// lane i of a sweep wave -> (group, stored row, position in the group) of flat row r0 + i.  With the wave-start table the
+// search is confined to the <= 64 groups the wave's 64 rows can span (every group has at least one row), and skipped when
+// the whole wave lies in one group (the common case with leaves of thousands of rows).
+__device__ __forceinline__ void resolve_flat_rows(uint64_t r0, uint32_t cnt, uint32_t lane, const ZhGroup *__restrict__ groups,
+                                                  const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                                  const uint32_t *__restrict__ waveGroup, const uint32_t *__restrict__ leaf_ids,
+                                                  uint32_t &my_g, uint32_t &my_id, uint32_t &my_within) {
+    const uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
+    uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
+    if (waveGroup) {
+        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)waveGroup[r0 >> 6]);
+        hi = lo + 64 < n_groups ? lo + 64 : n_groups;
+        if (lo + 1 >= n_groups || groupRowOff[lo + 1] > r0 + cnt - 1) hi = lo + 1;  // wave-uniform: one group
+    }
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (groupRowOff[mid] <= r) lo = mid; else hi = mid;
+    }
+    my_g = (uint32_t)lo;
+    my_within = (uint32_t)(r - groupRowOff[lo]);
+    const uint32_t lo_off = groups[lo].leaf_off;
+    my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
+}
+
 template <int D>
 struct RowVec {
     static constexpr int NJ = D / 256;            // full 1-KiB pieces
@@ -1162,28 +1204,18 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
                                                      const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                                     const uint32_t *__restrict__ waveGroup,
                                                      const uint32_t *__restrict__ leaf_ids, uint64_t row_begin,
                                                      uint64_t R_grouped, int metric, int param,
                                                      uint64_t *__restrict__ keys) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t r0 = row_begin + wave * 64;  // this launch covers flat rows [row_begin, R_grouped)
     if (r0 >= R_grouped) return;
     const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
     // lane i -> (group, stored row) of flat row r0 + i
     uint32_t my_g, my_id, my_within;
-    {
-        uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
-        uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
-        while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
-            if (groupRowOff[mid] <= r) lo = mid; else hi = mid;
-        }
-        my_g = (uint32_t)lo;
-        my_within = (uint32_t)(r - groupRowOff[lo]);
-        uint32_t lo_off = groups[lo].leaf_off;
-        my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
-    }
+    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
     float mine0[G], mine1[G];
 #pragma unroll
     for (int m = 0; m < G; m++) { mine0[m] = 0.f; mine1[m] = 0.f; }
@@ -1248,6 +1280,106 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
     }
 }
 
+// ---- d = 128 (SIFT-style shards): a 512-byte row is HALF a wave-load, so the wave streams TWO rows per instruction ----
+// Lanes 0..31 take flat row j of the wave's 64, lanes 32..63 flat row j + 32: every load instruction is a full 1-KiB wave
+// load (two 512-byte segments), the per-row instruction count halves (one butterfly serves two rows) and RG instructions
+// keep 2 * RG rows in flight.  Same canonical sums: lane l < 32 of a row's half holds accumulators 4l..4l+3, the butterfly
+// steps 1..16 stay inside the half, and step 32 adds the other half's total -- which is +0.0 at d <= 128, added explicitly.
+__device__ __forceinline__ float half_sum_canonical(float s) {
+    s = s + dpp_mov<0xB1>(s);   // xor 1
+    s = s + dpp_mov<0x4E>(s);   // xor 2
+    s = s + dpp_mov<0x141>(s);  // other quad of the 8
+    s = s + dpp_mov<0x140>(s);  // other 8 of the 16
+    s = s + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));  // xor 16 (inside a 32-lane half)
+    return s + 0.0f;            // xor 32: lanes 32..63 of a 128-d row hold no elements
+}
+
+template <int KIND, int G, int RG, bool NT>
+__global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__ X, const float *__restrict__ Q,
+                                                        const float *__restrict__ QQ, const ZhGroup *__restrict__ groups,
+                                                        const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                                        const uint32_t *__restrict__ waveGroup,
+                                                        const uint32_t *__restrict__ leaf_ids, uint64_t row_begin,
+                                                        uint64_t R_grouped, int metric, int param,
+                                                        uint64_t *__restrict__ keys) {
+    static_assert(KIND == K_L2 || KIND == K_COS, "the half-wave sweep covers the two simsimd-path kinds");
+    const uint32_t lane = threadIdx.x & 63, hl = lane & 31;
+    const bool up = lane >= 32;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t r0 = row_begin + wave * 64;
+    if (r0 >= R_grouped) return;
+    const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+    uint32_t my_g, my_id, my_within;
+    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
+    const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
+    const float4 *__restrict__ Q4 = reinterpret_cast<const float4 *>(Q);
+    float mine0[G], mine1 = 0.f;
+    float4 q[G];
+#pragma unroll
+    for (int m = 0; m < G; m++) { mine0[m] = 0.f; q[m] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    uint32_t cur_g = 0xFFFFFFFFu, gsize = 0;  // per half
+    const uint32_t npair = cnt < 32 ? cnt : 32;  // pair j = flat rows j (lower half) and j + 32 (upper half, if < cnt)
+    for (uint32_t j0 = 0; j0 < npair; j0 += RG) {
+        float4 v[RG];
+#pragma unroll
+        for (int r = 0; r < RG; r++) {
+            const uint32_t j = j0 + r < npair ? j0 + r : npair - 1;
+            const uint32_t jh = j + 32 < cnt ? j + 32 : cnt - 1;
+            const uint32_t idl = __builtin_amdgcn_readlane(my_id, j), idh = __builtin_amdgcn_readlane(my_id, jh);
+            v[r] = ld16<NT>(X4 + (size_t)(up ? idh : idl) * 32 + hl);
+        }
+#pragma unroll
+        for (int r = 0; r < RG; r++) {
+            const uint32_t j = j0 + r;
+            if (j < npair) {
+                const uint32_t jh = j + 32 < cnt ? j + 32 : cnt - 1;
+                const uint32_t gl = __builtin_amdgcn_readlane(my_g, j), gh = __builtin_amdgcn_readlane(my_g, jh);
+                const uint32_t g = up ? gh : gl;
+                if (g != cur_g) {  // uniform inside a half
+                    cur_g = g;
+                    gsize = groups[g].gsize;
+#pragma unroll
+                    for (int m = 0; m < G; m++)
+                        if ((uint32_t)m < gsize) q[m] = Q4[(size_t)groups[g].b[m] * 32 + hl];
+                }
+                float a2 = 0.f;
+                if (KIND == K_COS) {
+                    float4 c;
+                    c.x = __builtin_fmaf(v[r].x, v[r].x, 0.f); c.y = __builtin_fmaf(v[r].y, v[r].y, 0.f);
+                    c.z = __builtin_fmaf(v[r].z, v[r].z, 0.f); c.w = __builtin_fmaf(v[r].w, v[r].w, 0.f);
+                    a2 = half_sum_canonical((c.x + c.y) + (c.z + c.w));
+                }
+                float s0[G];
+#pragma unroll
+                for (int m = 0; m < G; m++) {
+                    s0[m] = 0.f;
+                    if ((uint32_t)m < gsize) {
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        float e = 0.f;
+                        acc_elem<KIND>(v[r].x, q[m].x, a.x, e, param);
+                        acc_elem<KIND>(v[r].y, q[m].y, a.y, e, param);
+                        acc_elem<KIND>(v[r].z, q[m].z, a.z, e, param);
+                        acc_elem<KIND>(v[r].w, q[m].w, a.w, e, param);
+                        s0[m] = half_sum_canonical((a.x + a.y) + (a.z + a.w));
+                    }
+                }
+                if (hl == j) {  // lane j holds flat row j, lane 32 + j flat row j + 32
+#pragma unroll
+                    for (int m = 0; m < G; m++) mine0[m] = s0[m];
+                    mine1 = a2;
+                }
+            }
+        }
+    }
+    if (lane < cnt) {
+        const ZhGroup grp = groups[my_g];
+#pragma unroll
+        for (int m = 0; m < G; m++)
+            if ((uint32_t)m < grp.gsize)
+                keys[grp.key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1, KIND == K_COS ? QQ[grp.b[m]] : 0.f);
+    }
+}
+
 uint64_t zh_sweep_rows_per_launch(uint32_t d) {
     static const uint64_t launch_bytes = [] { const char *e = getenv("ZH_SWEEP_LAUNCH_MB"); return (uint64_t)(e ? atoi(e) : 12288) << 20; }();
     uint64_t rows = launch_bytes / ((uint64_t)4 * (d ? d : 1));
@@ -1255,55 +1387,64 @@ uint64_t zh_sweep_rows_per_launch(uint32_t d) {
     return rows < 65536 ? 65536 : rows;
 }
 
+struct SweepArgs {
+    const float *dX; uint32_t d; const float *dQ, *dQQ;
+    const ZhGroup *dGroups; const uint64_t *dGroupRowOff; uint64_t n_groups;
+    const uint32_t *dWaveGroup;  // wave-start table (zh_launch_wave_groups) or nullptr: full binary search per lane
+    const uint32_t *dLeafIds; uint64_t R_grouped; int metric, param; uint64_t *dKeys; uint32_t group; hipStream_t s;
+};
+
 template <int D, int KIND, int G>
-static hipError_t launch_sweep_g(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
-                                 const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
-                                 hipStream_t s) {
+static hipError_t launch_sweep_g(const SweepArgs &a) {
     // rows are streamed once per batch: non-temporal loads (+1.3 % measured, profiles/); ZH_SWEEP_VARIANT=1
-    // switches them off for A/B runs.  Rows in flight (2/4/8) made no measurable difference: 4.
+    // switches them off for A/B runs.  Rows in flight (2/4/8) made no measurable difference at d = 768: 4.
     static const int variant = [] { const char *e = getenv("ZH_SWEEP_VARIANT"); return e ? atoi(e) : 0; }();
+    // d = 128: the half-wave kernel, RG load instructions = 2 RG rows in flight (ZH_SWEEP128=0: the generic kernel; A/B)
+    static const int v128 = [] { const char *e = getenv("ZH_SWEEP128"); return e ? atoi(e) : 8; }();
     // One batch is issued as several launches of ~ZH_SWEEP_LAUNCH_BYTES each (about 2 ms of HBM time): a single
     // 18-ms dispatch keeps its dispatch pipe busy until its last workgroup is issued, and kernels of other
     // queues that share the pipe (the next batch's hash / walk, RCCL) would wait that long.
-    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(d);
-    for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
-        uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
+    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(a.d);
+    for (uint64_t r = 0; r < a.R_grouped; r += rows_per_launch) {
+        uint64_t r_end = r + rows_per_launch < a.R_grouped ? r + rows_per_launch : a.R_grouped;
         uint64_t waves = (r_end - r + 63) / 64;
         uint64_t blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        const dim3 grid((uint32_t)blocks), blk(256);
+        if constexpr (D == 128 && (KIND == K_L2 || KIND == K_COS)) {
+            if (v128 > 0) {
+#define ZH_S128(RG_) hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true>), grid, blk, 0, a.s, a.dX, a.dQ, a.dQQ, a.dGroups, \
+                                        a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys)
+                if (v128 == 4) ZH_S128(4);
+                else if (v128 == 16) ZH_S128(16);
+                else ZH_S128(8);
+#undef ZH_S128
+                continue;
+            }
+        }
         if (variant == 1)
-            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
-                               dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, false>), grid, blk, 0, a.s, a.dX, a.d, a.dQ, a.dQQ, a.dGroups,
+                               a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys);
         else
-            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, d, dQ, dQQ,
-                               dGroups, dGroupRowOff, n_groups, dLeafIds, r, r_end, metric, param, dKeys);
+            hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, true>), grid, blk, 0, a.s, a.dX, a.d, a.dQ, a.dQQ, a.dGroups,
+                               a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys);
     }
     return hipGetLastError();
 }
 
-static thread_local uint32_t g_sweep_group = 2;  // set by zh_launch_sweep for the launch being issued
 template <int D, int KIND>
-static hipError_t launch_sweep_k(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
-                                 const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                                 const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
-                                 hipStream_t s) {
-    if (g_sweep_group == 4)
-        return launch_sweep_g<D, KIND, 4>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
-    return launch_sweep_g<D, KIND, 2>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
+static hipError_t launch_sweep_k(const SweepArgs &a) {
+    if (a.group == 4) return launch_sweep_g<D, KIND, 4>(a);
+    return launch_sweep_g<D, KIND, 2>(a);
 }
 
 // the two simsimd-path kinds get every specialised dimension; the ten `distances`-path kinds the three
 // production dimensions (text 384, image/audio 768, SIFT-style 128) and otherwise the runtime-d kernel
 template <int KIND>
-static hipError_t launch_sweep_kind(const float *dX, uint32_t d, const float *dQ, const float *dQQ,
-                                    const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                                    const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param,
-                                    uint64_t *dKeys, hipStream_t s) {
-#define ZH_SWEEP_CASE(DD) \
-    case DD: return launch_sweep_k<DD, KIND>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s)
+static hipError_t launch_sweep_kind(const SweepArgs &a) {
+#define ZH_SWEEP_CASE(DD) case DD: return launch_sweep_k<DD, KIND>(a)
     if (KIND == K_L2 || KIND == K_COS) {
-        switch (d) {
+        switch (a.d) {
             ZH_SWEEP_CASE(64);
             ZH_SWEEP_CASE(256);
             ZH_SWEEP_CASE(512);
@@ -1312,11 +1453,11 @@ static hipError_t launch_sweep_kind(const float *dX, uint32_t d, const float *dQ
         default: break;
         }
     }
-    switch (d) {
+    switch (a.d) {
         ZH_SWEEP_CASE(128);
         ZH_SWEEP_CASE(384);
         ZH_SWEEP_CASE(768);
-    default: return launch_sweep_k<0, KIND>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
+    default: return launch_sweep_k<0, KIND>(a);
     }
 #undef ZH_SWEEP_CASE
 }
@@ -1324,16 +1465,17 @@ static hipError_t launch_sweep_kind(const float *dX, uint32_t d, const float *dQ
 uint32_t zh_group_size(uint32_t dim) {
     static const int forced = [] { const char *e = getenv("ZH_GROUP"); return e ? atoi(e) : 0; }();
     if (forced == 2 || forced == 4) return (uint32_t)forced;
-    return dim <= 128 ? 2u : 4u;
+    return 4u;  // (d = 128 with the half-wave kernel: 4 measures equal or better than 2, profiles/r02_ab_sweep128.txt)
 }
 
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
-                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dLeafIds,
-                           uint64_t R_grouped, int metric, int param, uint64_t *dKeys, uint32_t group, hipStream_t s) {
+                           const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dWaveGroup,
+                           const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
+                           uint32_t group, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
-    g_sweep_group = group == 4 ? 4u : 2u;
-#define ZH_KIND_CASE(K) \
-    case K: return launch_sweep_kind<K>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s)
+    const SweepArgs a{dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, metric, param, dKeys,
+                      group == 4 ? 4u : 2u, s};
+#define ZH_KIND_CASE(K) case K: return launch_sweep_kind<K>(a)
     switch (zh_kind_of(metric)) {
         ZH_KIND_CASE(K_COS);
         ZH_KIND_CASE(K_MAX);
@@ -1344,7 +1486,7 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
         ZH_KIND_CASE(K_P4);
         ZH_KIND_CASE(K_HAMM);
         ZH_KIND_CASE(K_PP);
-    default: return launch_sweep_kind<K_L2>(dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dLeafIds, R_grouped, metric, param, dKeys, s);
+    default: return launch_sweep_kind<K_L2>(a);
     }
 #undef ZH_KIND_CASE
 }
@@ -1364,7 +1506,7 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
     float *dqq = reinterpret_cast<float *>(dro + 1);
     hipLaunchKernelGGL(one_group_kernel, dim3(1), dim3(1), 0, s, dg, dro, n);
     hipError_t e = zh_launch_qnorm(dq, 1, d, dqq, s);
-    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dg, dro, 1, nullptr, n, metric, mode, dKeys, 2, s);
+    if (e == hipSuccess) e = zh_launch_sweep(dX, d, dq, dqq, dg, dro, 1, nullptr, nullptr, n, metric, mode, dKeys, 2, s);
     return e;
 }
 
