@@ -140,6 +140,9 @@ typedef struct zh_stats_t {
     uint64_t swept_rows_accum;  /* rows_swept summed over the timed batches */
     uint64_t sweep_launches_accum; /* sweep_kernel launches over the timed batches (a batch is several launches) */
     uint64_t window_batches;    /* API batches handled together in the most recent internal batch (zh_search_begin_window) */
+    uint64_t table_scan;        /* 1: the most recent batch was swept by the table scan (every stored row streamed once, scored
+                                 * against every query that visits one of its leaves; rows_swept = stored rows), 0: leaf by leaf */
+    uint64_t scan_batches_accum; /* timed internal batches swept by the table scan */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

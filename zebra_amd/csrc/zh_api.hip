@@ -107,6 +107,7 @@ struct zh_search_ctx {
     uint32_t P_dense = 0, wpq = 0;
     hipStream_t s = nullptr;
     ZhTotals tot{};
+    bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                         &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup,
@@ -144,6 +145,9 @@ struct zh_index {
     uint32_t n_blocks = 0, n_upper = 0;
     bool blocks_valid = false;
     std::mutex blk_mu;
+    // row -> (leaf, position) per tree for the table-scan sweep (zh_launch_row_leaf): built on first use, dropped with the trees
+    DevBuf row_leaf;
+    bool row_leaf_valid = false, row_leaf_failed = false;
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
     zh_search_ctx dctx;
@@ -255,6 +259,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
+    ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
     ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
@@ -396,6 +401,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
+    ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->max_leaf_len = 0;
     for (size_t i = 0; i < nn; i++)
         if (ix->h_plane[i] < 0) ix->max_leaf_len = std::max(ix->max_leaf_len, (uint32_t)ix->h_right[i]);
@@ -1082,6 +1088,51 @@ static int build_blocks(zh_index *ix) {
     return ZH_OK;
 }
 
+// row -> {leaf node, position in the leaf} for every tree (the table-scan sweep's view of the forest): host pass for the
+// node -> tree map (iterative, as build_blocks), then one kernel over the leaves.  A failed allocation is remembered: the
+// leaf-major sweep serves the index until the trees change.
+static int build_row_leaf(zh_index *ix) {
+    const size_t nn = ix->h_plane.size();
+    const uint32_t T = (uint32_t)ix->h_roots.size();
+    if (ix->row_leaf.ensure(std::max<uint64_t>(ix->n_rows * T, 1) * sizeof(uint2)) != ZH_OK) { ix->row_leaf_failed = true; return ZH_OK; }
+    std::vector<uint32_t> node_tree(std::max<size_t>(nn, 1), 0xFFFFFFFFu), st;
+    for (uint32_t t = 0; t < T; t++) {
+        st.assign(1, ix->h_roots[t]);
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            node_tree[n] = t;
+            if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
+        }
+    }
+    DevBuf dTree;
+    int rc = dTree.ensure(node_tree.size() * 4);
+    if (rc) { ix->row_leaf_failed = true; return ZH_OK; }
+    hipError_t e = hipMemcpy(dTree.p, node_tree.data(), node_tree.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = zh_launch_row_leaf(ix->node_pack.as<int4>(), dTree.as<uint32_t>(), (uint32_t)nn, ix->leaf_ids.as<uint32_t>(), T, ix->n_rows,
+                               ix->row_leaf.as<uint2>(), ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    dTree.release();
+    if (e != hipSuccess) return fail(ZH_EHIP, "row -> leaf table: %s", hipGetErrorString(e));
+    ix->row_leaf_valid = true;
+    return ZH_OK;
+}
+
+// Leaf by leaf or the whole table once?  The leaf-major sweep reads group_rows rows from HBM as a gather; the table scan
+// streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and fetches one query from L2 per scored
+// (row, query) pair.  ZH_SWEEP_MODE=leaf|scan forces.
+static bool choose_scan(const zh_index *ix, const ZhTotals &tot) {
+    static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
+    const uint32_t d = ix->opt.dim, T = ix->n_trees;
+    if (forced == 1 || !zh_scan_sweep_supported(d, T) || ix->row_leaf_failed) return false;
+    if (forced == 2) return true;
+    const double row_b = 4.0 * d;
+    const double t_leaf = (double)tot.group_rows * row_b / 5.9e12;
+    const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 5.9e12,
+                                   ((double)tot.rows + (double)ix->n_rows) * row_b / 14e12 + (double)tot.rows * 1.0e-10);
+    return t_scan < 0.9 * t_leaf;
+}
+
 // number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
 static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     const auto &below = ix->planes_below_level;
@@ -1277,7 +1328,13 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
             if (c->wLogPool.ensure(chunks * ZH_LOG_CHUNK * sizeof(uint2)) == ZH_OK) c->log_chunks = chunks;
         }
     }
-    if (!no_wave_table)
+    c->scan = choose_scan(ix, tot);
+    if (c->scan && !ix->row_leaf_valid) {  // first table scan since the trees changed
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if (!ix->row_leaf_valid && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;
+        if (!ix->row_leaf_valid) c->scan = false;
+    }
+    if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
@@ -1285,10 +1342,14 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     hipStream_t hs = heavy ? heavy : s;
     if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
-    HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
-                           c->wGroupRowOff.as<uint64_t>(), tot.groups, no_wave_table ? nullptr : c->wWaveGroup.as<uint32_t>(), f.leaf_ids,
-                           tot.group_rows, c->metric, c->mode,
-                           c->wKeys.as<uint64_t>(), f.group, hs));
+    if (c->scan)
+        HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
+                                    c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(), c->wGroups.as<ZhGroup>(), f.group,
+                                    c->metric, c->mode, c->wKeys.as<uint64_t>(), hs));
+    else
+        HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
+                               c->wGroupRowOff.as<uint64_t>(), tot.groups, no_wave_table ? nullptr : c->wWaveGroup.as<uint32_t>(), f.leaf_ids,
+                               tot.group_rows, c->metric, c->mode, c->wKeys.as<uint64_t>(), f.group, hs));
     HIPCHK(hipEventRecord(c->ev_sw1, hs));
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
     HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1335,17 +1396,21 @@ int ctx_wait(zh_search_ctx *c) {
     zh_stats_t &st = ix->stats;
     st.batch = c->B; st.window_batches = c->nwin; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
     st.planes_dense = c->P_dense; st.planes_total = ix->n_planes;
-    st.rows_swept = tot.group_rows;
-    st.sweep_bytes = tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
+    const uint64_t swept = c->scan ? ix->n_rows : tot.group_rows;
+    st.rows_swept = swept;
+    st.sweep_bytes = c->scan ? ix->n_rows * ((uint64_t)4 * ix->opt.dim + 8 * ix->n_trees) + tot.rows * 8
+                             : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
+    st.table_scan = c->scan ? 1 : 0;
     if (ix->profiling >= 2) st.rows_unique = uniq;
     if (ix->profiling > 0) {
         st.ms_hash += ms[0]; st.ms_walk += ms[1]; st.ms_sweep += ms[2]; st.ms_select += ms[3]; st.ms_final += ms[4];
         st.ms_total += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
         st.timed_batches++;
         st.sweep_rows_accum += tot.rows;
-        st.swept_rows_accum += tot.group_rows;
+        st.swept_rows_accum += swept;
         const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim);
-        st.sweep_launches_accum += (tot.group_rows + rpl - 1) / rpl;
+        st.sweep_launches_accum += (swept + rpl - 1) / rpl;
+        st.scan_batches_accum += c->scan ? 1 : 0;
     }
     return ZH_OK;
 }

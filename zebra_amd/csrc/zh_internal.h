@@ -166,6 +166,16 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
 // waveGroup[w] = group of flat row 64 w, for every wave start of [0, R_grouped)
 hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups, uint32_t *dWaveGroup,
                                  hipStream_t s);
+// ---- the table-scan sweep (zh_search.hip): the stored rows streamed once, each scored against every query that visits
+// one of its leaves.  rowLeaf is n_rows x T {leaf node, position in the leaf}, built per forest by zh_launch_row_leaf from
+// node_pack, a node -> tree map (UINT32_MAX for nodes no root reaches) and leaf_ids.
+bool zh_scan_sweep_supported(uint32_t d, uint32_t T);
+uint32_t zh_scan_rows_per_wave(uint32_t T);
+hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, uint32_t n_nodes, const uint32_t *dLeafIds,
+                              uint32_t T, uint64_t n_rows, uint2 *dRowLeaf, hipStream_t s);
+hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase,
+                                const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);
 // max_leaf_len: the longest leaf of the forest (picks the LDS footprint of the select blocks)

@@ -1491,6 +1491,227 @@ hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const f
 #undef ZH_KIND_CASE
 }
 
+// ------------------------------------------------------------------------------------------------
+// TABLE-SCAN sweep.  With the batch sizes of the BASELINE configurations a batch scores several times more (row, query)
+// pairs than the index has rows (cfg3: 1024 queries x 15 trees x ~2.8k rows = 43M pairs over 10M rows): every stored row
+// is wanted by ~4 queries, through DIFFERENT trees, and the leaf-major sweep above -- whose unit is (leaf, <= 4 queries) --
+// fetches it from HBM once per tree that wants it (98 GB per batch against a 31 GB table).  Here the unit is the stored
+// ROW: the table is streamed ONCE, in address order (sequential HBM reads, no gather), and each row is scored against
+// every query that visits any of its T leaves; the queries (3 MB for 1024 x 768) come from L2.  Per (row, query) pair one
+// operand has to reach the CU either way; here it is the query, from L2, instead of the row, from HBM.
+//   rowLeaf[row][tree] = {leaf node of `row` in `tree`, position of the row inside that leaf}   (built once per forest)
+//   per batch: leafCount[node] visits, groups[groupBase[node] + s / GRP].{b, key_off}[s % GRP] for visit s -- exactly what
+//   the walk / expand kernels produce for the leaf-major sweep, so keys land in the same slots and select / final are
+//   unchanged; the sums are the same canonical sums, so the keys are bit-identical.
+// A wave takes RW consecutive rows (RW * T <= 256): phase 1 resolves their RW * T (row, tree) entries lane-parallel (which
+// leaves are visited, by which query, where the key goes); phase 2 walks the rows, loads each once, and runs its pairs;
+// the finished sums wait in lane registers (pair p in lane p mod 64) so that key_of and the stores run for 64 pairs at once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void row_leaf_kernel(const int4 *__restrict__ node_pack, const uint32_t *__restrict__ node_tree,
+                                                       const uint32_t *__restrict__ leaf_ids, uint32_t T, uint64_t n_rows,
+                                                       uint32_t node0, uint2 *__restrict__ rowLeaf) {
+    const uint32_t node = node0 + blockIdx.x;
+    const int4 rec = node_pack[node];
+    if (rec.x >= 0) return;  // inner node
+    const uint32_t t = node_tree[node];
+    if (t >= T) return;      // not reachable from a root
+    const uint32_t off = (uint32_t)rec.y, len = (uint32_t)rec.z;
+    for (uint32_t i = threadIdx.x; i < len; i += 64) {
+        const uint32_t r = leaf_ids[(size_t)off + i];
+        if (r < n_rows) rowLeaf[(size_t)r * T + t] = make_uint2(node, i);
+    }
+}
+hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, uint32_t n_nodes, const uint32_t *dLeafIds,
+                              uint32_t T, uint64_t n_rows, uint2 *dRowLeaf, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(dRowLeaf, 0xFF, n_rows * T * sizeof(uint2), s);  // {-1, -1}: the row is not in that tree
+    if (e != hipSuccess) return e;
+    for (uint32_t n0 = 0; n0 < n_nodes; n0 += (1u << 22)) {  // block-indexed: slices well below 2^32 threads per launch
+        const uint32_t nb = n_nodes - n0 < (1u << 22) ? n_nodes - n0 : (1u << 22);
+        hipLaunchKernelGGL(row_leaf_kernel, dim3(nb), dim3(64), 0, s, dNodePack, dNodeTree, dLeafIds, T, n_rows, n0, dRowLeaf);
+    }
+    return hipGetLastError();
+}
+
+// one stored row (in the canonical lane layout) against one query: the canonical sums of the pair
+template <int D, int KIND>
+__device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, uint32_t lane, int power, float &s0, float &s1) {
+    constexpr int NV = RowVec<D>::NV;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+        if (act) {
+            acc_elem<KIND>(v[j].x, q[j].x, a.x, e.x, power);
+            acc_elem<KIND>(v[j].y, q[j].y, a.y, e.y, power);
+            acc_elem<KIND>(v[j].z, q[j].z, a.z, e.z, power);
+            acc_elem<KIND>(v[j].w, q[j].w, a.w, e.w, power);
+        }
+    }
+    s0 = wave_combine<KIND>(a.x, a.y, a.z, a.w);
+    if (KIND == K_BRAY) s1 = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
+}
+
+#define ZH_SCAN_NE 4  // (row, tree) entries per lane: RW * T <= 64 * ZH_SCAN_NE
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
+                                                          const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
+                                                          uint32_t T, uint32_t RW, const uint32_t *__restrict__ leafCount,
+                                                          const uint32_t *__restrict__ groupBase,
+                                                          const ZhGroup *__restrict__ groups, uint32_t GRP, uint64_t row_begin,
+                                                          uint64_t row_end, int metric, int param,
+                                                          uint64_t *__restrict__ keys) {
+    constexpr int NV = RowVec<D>::NV;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t r0 = row_begin + wave * RW;
+    if (r0 >= row_end) return;
+    const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
+    // ---- phase 1: the wave's nr * T (row, tree) entries, lane-parallel ----
+    uint32_t eRow[ZH_SCAN_NE], eC[ZH_SCAN_NE], eB0[ZH_SCAN_NE], eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE];
+    uint64_t eSlot0[ZH_SCAN_NE];
+    const uint32_t n_ent = nr * T;
+    const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t e = lane + 64u * j;
+        eRow[j] = 0xFFFFFFFFu; eC[j] = 0; eB0[j] = 0; eGb[j] = 0; eWithin[j] = 0; eSlot0[j] = 0;
+        if (e < n_ent) {
+            const uint2 rl = ent[e];
+            if (rl.x != 0xFFFFFFFFu) {
+                const uint32_t c = leafCount[rl.x];
+                if (c) {
+                    const uint32_t gb = groupBase[rl.x];
+                    eRow[j] = e / T; eC[j] = c; eGb[j] = gb; eWithin[j] = rl.y;
+                    eB0[j] = groups[gb].b[0];
+                    eSlot0[j] = groups[gb].key_off[0] + rl.y;
+                }
+            }
+        }
+    }
+    // ---- phase 2: row after row ----
+    float my_s0 = 0.f, my_s1 = 0.f;
+    uint64_t my_slot = 0;
+    uint32_t my_b = 0, npend = 0;
+    auto flush = [&]() {
+        if (lane < npend) keys[my_slot] = key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f);
+        npend = 0;
+    };
+    for (uint32_t rl = 0; rl < nr; rl++) {
+        unsigned long long masks[ZH_SCAN_NE];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) { masks[j] = __ballot(eRow[j] == rl); any = any || masks[j] != 0; }
+        if (!any) continue;  // nobody wants this row: it is not even loaded
+        float4 v[NV];
+        load_row<D, true>(X + (size_t)(r0 + rl) * D, lane, v);
+        float a2 = 0.f;
+        if (KIND == K_COS) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+                if (act) {
+                    c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
+                    c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
+                }
+            }
+            a2 = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
+        }
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            unsigned long long m = masks[j];
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], l);
+                for (uint32_t sidx = 0; sidx < c; sidx++) {
+                    uint32_t b;
+                    uint64_t slot;
+                    if (sidx == 0) {
+                        b = (uint32_t)__builtin_amdgcn_readlane((int)eB0[j], l);
+                        slot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(eSlot0[j] >> 32), l) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eSlot0[j], l);
+                    } else {
+                        const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], l);
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], l);
+                        const ZhGroup *g = groups + gb + sidx / GRP;
+                        b = g->b[sidx % GRP];
+                        slot = g->key_off[sidx % GRP] + w;
+                    }
+                    float4 q[NV];
+                    load_row<D>(Q + (size_t)b * D, lane, q);
+                    float s0 = 0.f, s1 = 0.f;
+                    row_pair_sums<D, KIND>(v, q, lane, param, s0, s1);
+                    if (lane == npend) { my_s0 = s0; my_s1 = KIND == K_COS ? a2 : s1; my_slot = slot; my_b = b; }
+                    if (++npend == 64) flush();
+                }
+            }
+        }
+    }
+    flush();
+}
+
+// rows per wave of the table scan for T trees (0: T is beyond what a wave's entry registers hold -> leaf-major sweep)
+uint32_t zh_scan_rows_per_wave(uint32_t T) {
+    if (T == 0 || T > 64u * ZH_SCAN_NE) return 0;
+    const uint32_t rw = 64u * ZH_SCAN_NE / T;
+    return rw > 16 ? 16 : rw;
+}
+bool zh_scan_sweep_supported(uint32_t d, uint32_t T) {
+    if (!zh_scan_rows_per_wave(T)) return false;
+    switch (d) { case 64: case 128: case 256: case 384: case 512: case 768: case 1024: case 1536: return true; default: return false; }
+}
+
+template <int D, int KIND>
+static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *dQ, const float *dQQ, const uint2 *dRowLeaf,
+                                 uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase, const ZhGroup *dGroups,
+                                 uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
+    const uint32_t RW = zh_scan_rows_per_wave(T);
+    uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
+    rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
+    for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
+        const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
+        const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((scan_sweep_kernel<D, KIND>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, dQ, dQQ, dRowLeaf, T, RW,
+                           dLeafCount, dGroupBase, dGroups, group, r, r_end, metric, param, dKeys);
+    }
+    return hipGetLastError();
+}
+template <int KIND>
+static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase,
+                                const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
+#define ZH_SCAN_CASE(DD) \
+    case DD: return launch_scan_dk<DD, KIND>(dX, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s)
+    switch (d) {
+        ZH_SCAN_CASE(64); ZH_SCAN_CASE(128); ZH_SCAN_CASE(256); ZH_SCAN_CASE(384);
+        ZH_SCAN_CASE(512); ZH_SCAN_CASE(768); ZH_SCAN_CASE(1024); ZH_SCAN_CASE(1536);
+    default: return hipErrorInvalidValue;
+    }
+#undef ZH_SCAN_CASE
+}
+hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase,
+                                const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
+    if (!n_rows) return hipSuccess;
+#define ZH_KIND_CASE(K) \
+    case K: return launch_scan_k<K>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s)
+    switch (zh_kind_of(metric)) {
+        ZH_KIND_CASE(K_COS);
+        ZH_KIND_CASE(K_MAX);
+        ZH_KIND_CASE(K_CANB);
+        ZH_KIND_CASE(K_BRAY);
+        ZH_KIND_CASE(K_ABS);
+        ZH_KIND_CASE(K_P3);
+        ZH_KIND_CASE(K_P4);
+        ZH_KIND_CASE(K_HAMM);
+        ZH_KIND_CASE(K_PP);
+    default: return launch_scan_k<K_L2>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s);
+    }
+#undef ZH_KIND_CASE
+}
+
 // n contiguous rows against one query: a single synthetic group, ids = row numbers
 __global__ void one_group_kernel(ZhGroup *g, uint64_t *rowoff, uint64_t n) {
     g->leaf_off = 0; g->len = (uint32_t)n; g->gsize = 1; g->pad = 0;
