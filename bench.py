@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined")
     ap.add_argument("--window", type=int, default=2,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
+    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan"], default="auto",
+                    help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority stream (N = 1)")
@@ -186,6 +188,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     t_setup = time.perf_counter()
     ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=env.local_rank, id_base=first_row,
                      reserve_rows=rows_local)
+    ix.set_sweep_mode(args.sweep_mode)
     ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=first_row, kind=wl["kind"])
     t_fill = time.perf_counter() - t_setup
     ix.build()

@@ -341,6 +341,11 @@ ZH_API int zh_stats(zh_index *idx, zh_stats_t *out);
 ZH_API int zh_stats_reset(zh_index *idx);
 /* number of leading tree levels hashed by the dense MFMA kernel; -1 = choose per batch (default) */
 ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
+/* How the distance sweep of a batch is organised: 1 = leaf by leaf (the rows of every visited leaf are gathered from HBM once
+ * per group of <= 4 queries that visit it), 2 = table scan (every stored row is streamed from HBM once per batch window, in
+ * address order, and scored against every query that visits one of its num_trees leaves; the queries come from L2), 0 = the
+ * library chooses per batch from the counted work (default).  Results are bit-identical in both. */
+ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
 
 ZH_API const char *zh_last_error(void);
 ZH_API const char *zh_version(void);

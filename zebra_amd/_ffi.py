@@ -114,6 +114,7 @@ SYMBOLS = [
     ("zh_stats", _i, [_vp, _vp]),
     ("zh_stats_reset", _i, [_vp]),
     ("zh_set_dense_levels", _i, [_vp, _i]),
+    ("zh_set_sweep_mode", _i, [_vp, _i]),
     ("zh_last_error", C.c_char_p, []),
     ("zh_version", C.c_char_p, []),
 ]

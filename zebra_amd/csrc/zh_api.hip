@@ -155,6 +155,7 @@ struct zh_index {
 
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
+    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model, 1 leaf-major, 2 table scan
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
     std::mutex stats_mu;
@@ -985,6 +986,12 @@ extern "C" int zh_set_dense_levels(zh_index *ix, int levels) {
     ix->dense_levels = levels;
     return ZH_OK;
 }
+extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    if (mode < 0 || mode > 2) return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan)", mode);
+    ix->sweep_mode = mode;
+    return ZH_OK;
+}
 extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
     if (!ix || !out) return fail(ZH_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -1118,19 +1125,23 @@ static int build_row_leaf(zh_index *ix) {
     return ZH_OK;
 }
 
-// Leaf by leaf or the whole table once?  The leaf-major sweep reads group_rows rows from HBM as a gather; the table scan
-// streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and fetches one query from L2 per scored
-// (row, query) pair.  ZH_SWEEP_MODE=leaf|scan forces.
-static bool choose_scan(const zh_index *ix, const ZhTotals &tot) {
+// Leaf by leaf or the whole table once?  The leaf-major sweep gathers group_rows rows from HBM (5.9-6.1 TB/s of 3-KB rows,
+// 5.5 TB/s of 512-byte ones); the table scan streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and
+// fetches one query from L2 per scored (row, query) pair -- measured 0.144 + 0.000175 d ns per pair chip-wide (3.7 G pairs/s
+// at d = 768 = the ~19 TB/s the L2s deliver; 6 G pairs/s at d = 128, instruction-bound), slower once the window's queries no
+// longer fit beside the stream in the 8 x 4 MB of L2.  zh_set_sweep_mode / ZH_SWEEP_MODE=leaf|scan force one of them.
+static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
-    if (forced == 1 || !zh_scan_sweep_supported(d, T) || ix->row_leaf_failed) return false;
-    if (forced == 2) return true;
+    const int mode = ix->sweep_mode ? ix->sweep_mode : forced;
+    if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed) return false;
+    if (mode == 2) return true;
     const double row_b = 4.0 * d;
-    const double t_leaf = (double)tot.group_rows * row_b / 5.9e12;
-    const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 5.9e12,
-                                   ((double)tot.rows + (double)ix->n_rows) * row_b / 14e12 + (double)tot.rows * 1.0e-10);
-    return t_scan < 0.9 * t_leaf;
+    const double t_leaf = (double)tot.group_rows * row_b / (d >= 256 ? 6.0e12 : 5.5e12);
+    const double q_bytes = (double)B * row_b;
+    const double t_pairs = (double)tot.rows * (0.144e-9 + 0.000175e-9 * d) * (q_bytes > 8e6 ? 1.25 : 1.0);
+    const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 6.0e12, t_pairs) + 20e-6;
+    return t_scan < 0.92 * t_leaf;
 }
 
 // number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
@@ -1328,7 +1339,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
             if (c->wLogPool.ensure(chunks * ZH_LOG_CHUNK * sizeof(uint2)) == ZH_OK) c->log_chunks = chunks;
         }
     }
-    c->scan = choose_scan(ix, tot);
+    c->scan = choose_scan(ix, tot, c->metric, B);
     if (c->scan && !ix->row_leaf_valid) {  // first table scan since the trees changed
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if (!ix->row_leaf_valid && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;

@@ -169,7 +169,7 @@ hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupR
 // ---- the table-scan sweep (zh_search.hip): the stored rows streamed once, each scored against every query that visits
 // one of its leaves.  rowLeaf is n_rows x T {leaf node, position in the leaf}, built per forest by zh_launch_row_leaf from
 // node_pack, a node -> tree map (UINT32_MAX for nodes no root reaches) and leaf_ids.
-bool zh_scan_sweep_supported(uint32_t d, uint32_t T);
+bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric);
 uint32_t zh_scan_rows_per_wave(uint32_t T);
 hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, uint32_t n_nodes, const uint32_t *dLeafIds,
                               uint32_t T, uint64_t n_rows, uint2 *dRowLeaf, hipStream_t s);

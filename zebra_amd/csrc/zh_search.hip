@@ -1443,7 +1443,7 @@ static hipError_t launch_sweep_k(const SweepArgs &a) {
 template <int KIND>
 static hipError_t launch_sweep_kind(const SweepArgs &a) {
 #define ZH_SWEEP_CASE(DD) case DD: return launch_sweep_k<DD, KIND>(a)
-    if (KIND == K_L2 || KIND == K_COS) {
+    if constexpr (KIND == K_L2 || KIND == K_COS) {
         switch (a.d) {
             ZH_SWEEP_CASE(64);
             ZH_SWEEP_CASE(256);
@@ -1551,7 +1551,28 @@ __device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, 
     if (KIND == K_BRAY) s1 = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
 }
 
-#define ZH_SCAN_NE 4  // (row, tree) entries per lane: RW * T <= 64 * ZH_SCAN_NE
+// A stored row of the table scan: streamed exactly once per batch window.  ZH_SCAN_ROWPOL (build-time, A/B) picks the cache
+// policy of these loads: 0 = global_load ... nt; n > 0 = buffer_load with aux bits n (1 = sc0, 2 = nt, 16 = sc1).
+#ifndef ZH_SCAN_ROWPOL
+#define ZH_SCAN_ROWPOL 0
+#endif
+template <int D>
+__device__ __forceinline__ void load_row_stream(const float *__restrict__ row, uint32_t lane, float4 *v) {
+#if ZH_SCAN_ROWPOL == 0
+    load_row<D, true>(row, lane, v);
+#else
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, D * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < RowVec<D>::NV; j++) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * j) * 16, 0, ZH_SCAN_ROWPOL);  // out of range -> 0
+        v[j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    }
+#endif
+}
+
+#define ZH_SCAN_NE 4     // (row, tree) entries per lane: RW * T <= 64 * ZH_SCAN_NE
+#define ZH_SCAN_CAP 256  // pair records of a wave's LDS list (16 bytes each); a wave with more pairs takes the slow path
 template <int D, int KIND>
 __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
                                                           const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
@@ -1561,89 +1582,156 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
                                                           uint64_t row_end, int metric, int param,
                                                           uint64_t *__restrict__ keys) {
     constexpr int NV = RowVec<D>::NV;
+    __shared__ uint4 pair_list[4][ZH_SCAN_CAP];  // {row of the wave's RW, query, key slot lo, hi}
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
     const uint64_t r0 = row_begin + wave * RW;
     if (r0 >= row_end) return;
     const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
-    // ---- phase 1: the wave's nr * T (row, tree) entries, lane-parallel ----
-    uint32_t eRow[ZH_SCAN_NE], eC[ZH_SCAN_NE], eB0[ZH_SCAN_NE], eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE];
-    uint64_t eSlot0[ZH_SCAN_NE];
     const uint32_t n_ent = nr * T;
     const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+    // ---- phase 1: the wave's nr * T (row, tree) entries, lane-parallel: visits of the entry's leaf -> pairs; the pairs of
+    // the whole wave go to an LDS list in (row, tree, visit) order ----
+    uint32_t eNode[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
+    uint32_t P = 0;
 #pragma unroll
     for (int j = 0; j < ZH_SCAN_NE; j++) {
         const uint32_t e = lane + 64u * j;
-        eRow[j] = 0xFFFFFFFFu; eC[j] = 0; eB0[j] = 0; eGb[j] = 0; eWithin[j] = 0; eSlot0[j] = 0;
+        eNode[j] = 0xFFFFFFFFu; eWithin[j] = 0; eC[j] = 0;
         if (e < n_ent) {
-            const uint2 rl = ent[e];
-            if (rl.x != 0xFFFFFFFFu) {
-                const uint32_t c = leafCount[rl.x];
-                if (c) {
-                    const uint32_t gb = groupBase[rl.x];
-                    eRow[j] = e / T; eC[j] = c; eGb[j] = gb; eWithin[j] = rl.y;
-                    eB0[j] = groups[gb].b[0];
-                    eSlot0[j] = groups[gb].key_off[0] + rl.y;
-                }
-            }
+            const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));  // streamed once
+            const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
+            eNode[j] = rl.x; eWithin[j] = rl.y;
+            if (rl.x != 0xFFFFFFFFu) eC[j] = leafCount[rl.x];
         }
+        uint32_t incl = eC[j];  // inclusive scan over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        off[j] = P + incl - eC[j];
+        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    // ---- phase 2: row after row ----
-    float my_s0 = 0.f, my_s1 = 0.f;
+    if (P == 0) return;  // nobody wants any of these rows: they are not even loaded
+    float my_s0 = 0.f, my_s1 = 0.f;  // finished sums wait here (pair n in lane n mod 64): key_of and the stores run 64 at a time
     uint64_t my_slot = 0;
     uint32_t my_b = 0, npend = 0;
     auto flush = [&]() {
-        if (lane < npend) keys[my_slot] = key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f);
+        // keys are written once and read once, much later, by the select kernel: non-temporal, so that 8-byte stores to
+        // 64 different lines do not push the queries out of L2
+        if (lane < npend)
+            __builtin_nontemporal_store(key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f), keys + my_slot);
         npend = 0;
     };
-    for (uint32_t rl = 0; rl < nr; rl++) {
-        unsigned long long masks[ZH_SCAN_NE];
-        bool any = false;
+    auto row_norm = [&](const float4 *v) {  // cosine: the stored row's a2, once per row
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < ZH_SCAN_NE; j++) { masks[j] = __ballot(eRow[j] == rl); any = any || masks[j] != 0; }
-        if (!any) continue;  // nobody wants this row: it is not even loaded
-        float4 v[NV];
-        load_row<D, true>(X + (size_t)(r0 + rl) * D, lane, v);
-        float a2 = 0.f;
-        if (KIND == K_COS) {
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-                if (act) {
-                    c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
-                    c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
-                }
+        for (int j = 0; j < NV; j++) {
+            const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+            if (act) {
+                c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
+                c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
             }
-            a2 = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
         }
+        return wave_sum_canonical((c.x + c.y) + (c.z + c.w));
+    };
+    auto score = [&](const float4 *v, float a2, uint32_t b, uint64_t slot, const float4 *q) {
+        float s0 = 0.f, s1 = 0.f;
+        row_pair_sums<D, KIND>(v, q, lane, param, s0, s1);
+        if (lane == npend) { my_s0 = s0; my_s1 = KIND == K_COS ? a2 : s1; my_slot = slot; my_b = b; }
+        if (++npend == 64) flush();
+    };
+    if (P <= ZH_SCAN_CAP) {
+        uint4 *list = pair_list[wid];
+        uint32_t mrows = 0;  // rows of the wave that have pairs
 #pragma unroll
         for (int j = 0; j < ZH_SCAN_NE; j++) {
-            unsigned long long m = masks[j];
+            const uint32_t c = eC[j];
+            if (c) {
+                const uint32_t rl = (lane + 64u * j) / T, gb = groupBase[eNode[j]];
+                mrows |= 1u << rl;
+                for (uint32_t sidx = 0; sidx < c; sidx++) {
+                    const ZhGroup *g = groups + gb + sidx / GRP;
+                    const uint64_t slot = g->key_off[sidx % GRP] + eWithin[j];
+                    list[off[j] + sidx] = make_uint4(rl, g->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+            }
+        }
+        uint32_t rowmask = 0;
+#pragma unroll
+        for (int bit = 0; bit < 16; bit++) rowmask |= (__ballot((mrows >> bit) & 1u) != 0 ? 1u : 0u) << bit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto rd = [&](uint32_t p) {
+            const uint4 r = list[p];
+            return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)r.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)r.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w));
+        };
+        // Rows with pairs are taken FOUR at a time (their loads go out together: one HBM round trip per four rows, the
+        // in-order return of a wave's loads would otherwise stall every later query load behind each row); the pairs of those
+        // rows follow in list order, the query of pair p + 1 on its way from L2 while pair p is scored.
+        float4 qc[NV], qn[NV];
+        uint4 rec = rd(0), recn = rec;
+        uint32_t p = 0;
+        load_row<D>(Q + (size_t)rec.y * D, lane, qc);
+        auto segment = [&](const float4 *vr, float a2, uint32_t rowid) {
+            while (p < P && rec.x == rowid) {
+                const bool more = p + 1 < P;
+                if (more) { recn = rd(p + 1); load_row<D>(Q + (size_t)recn.y * D, lane, qn); }
+                score(vr, a2, rec.y, ((uint64_t)rec.w << 32) | rec.z, qc);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) qc[j] = qn[j];
+                    rec = recn;
+                }
+                p++;
+            }
+        };
+        while (rowmask) {
+            uint32_t rid[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rid[r] = rowmask ? (uint32_t)__builtin_ctz(rowmask) : 0xFFFFFFFFu;
+                rowmask &= rowmask - 1;  // (0 & anything stays 0)
+            }
+            float4 v0[NV], v1[NV], v2[NV], v3[NV];
+            load_row_stream<D>(X + (size_t)(r0 + rid[0]) * D, lane, v0);
+            if (rid[1] != 0xFFFFFFFFu) load_row_stream<D>(X + (size_t)(r0 + rid[1]) * D, lane, v1);
+            if (rid[2] != 0xFFFFFFFFu) load_row_stream<D>(X + (size_t)(r0 + rid[2]) * D, lane, v2);
+            if (rid[3] != 0xFFFFFFFFu) load_row_stream<D>(X + (size_t)(r0 + rid[3]) * D, lane, v3);
+            segment(v0, KIND == K_COS ? row_norm(v0) : 0.f, rid[0]);
+            if (rid[1] != 0xFFFFFFFFu) segment(v1, KIND == K_COS ? row_norm(v1) : 0.f, rid[1]);
+            if (rid[2] != 0xFFFFFFFFu) segment(v2, KIND == K_COS ? row_norm(v2) : 0.f, rid[2]);
+            if (rid[3] != 0xFFFFFFFFu) segment(v3, KIND == K_COS ? row_norm(v3) : 0.f, rid[3]);
+        }
+    } else {
+        // more pairs than the list holds (hot leaves): entry after entry, no list
+        float4 v[NV];
+        float a2 = 0.f;
+        uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            unsigned long long m = __ballot(eC[j] != 0);
             while (m) {
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], l);
+                const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)eNode[j], l);
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], l);
+                const uint32_t rl = ((uint32_t)l + 64u * j) / T, gb = groupBase[node];
+                if (rl != cur) {
+                    cur = rl;
+                    load_row<D, true>(X + (size_t)(r0 + rl) * D, lane, v);
+                    if (KIND == K_COS) a2 = row_norm(v);
+                }
                 for (uint32_t sidx = 0; sidx < c; sidx++) {
-                    uint32_t b;
-                    uint64_t slot;
-                    if (sidx == 0) {
-                        b = (uint32_t)__builtin_amdgcn_readlane((int)eB0[j], l);
-                        slot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(eSlot0[j] >> 32), l) << 32) |
-                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eSlot0[j], l);
-                    } else {
-                        const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], l);
-                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], l);
-                        const ZhGroup *g = groups + gb + sidx / GRP;
-                        b = g->b[sidx % GRP];
-                        slot = g->key_off[sidx % GRP] + w;
-                    }
+                    const ZhGroup *g = groups + gb + sidx / GRP;
+                    const uint32_t b = g->b[sidx % GRP];
                     float4 q[NV];
                     load_row<D>(Q + (size_t)b * D, lane, q);
-                    float s0 = 0.f, s1 = 0.f;
-                    row_pair_sums<D, KIND>(v, q, lane, param, s0, s1);
-                    if (lane == npend) { my_s0 = s0; my_s1 = KIND == K_COS ? a2 : s1; my_slot = slot; my_b = b; }
-                    if (++npend == 64) flush();
+                    score(v, a2, b, g->key_off[sidx % GRP] + w, q);
                 }
             }
         }
@@ -1657,9 +1745,13 @@ uint32_t zh_scan_rows_per_wave(uint32_t T) {
     const uint32_t rw = 64u * ZH_SCAN_NE / T;
     return rw > 16 ? 16 : rw;
 }
-bool zh_scan_sweep_supported(uint32_t d, uint32_t T) {
+// dimensions as the leaf-major sweep specialises them: the two simsimd-path kinds everywhere, the others at 128 / 384 / 768
+bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric) {
     if (!zh_scan_rows_per_wave(T)) return false;
-    switch (d) { case 64: case 128: case 256: case 384: case 512: case 768: case 1024: case 1536: return true; default: return false; }
+    const int kind = zh_kind_of(metric);
+    if (d == 128 || d == 384 || d == 768) return true;
+    if (kind != K_L2 && kind != K_COS) return false;
+    switch (d) { case 64: case 256: case 512: case 1024: case 1536: return true; default: return false; }
 }
 
 template <int D, int KIND>
@@ -1684,9 +1776,14 @@ static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, co
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
 #define ZH_SCAN_CASE(DD) \
     case DD: return launch_scan_dk<DD, KIND>(dX, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s)
+    if constexpr (KIND == K_L2 || KIND == K_COS) {
+        switch (d) {
+            ZH_SCAN_CASE(64); ZH_SCAN_CASE(256); ZH_SCAN_CASE(512); ZH_SCAN_CASE(1024); ZH_SCAN_CASE(1536);
+        default: break;
+        }
+    }
     switch (d) {
-        ZH_SCAN_CASE(64); ZH_SCAN_CASE(128); ZH_SCAN_CASE(256); ZH_SCAN_CASE(384);
-        ZH_SCAN_CASE(512); ZH_SCAN_CASE(768); ZH_SCAN_CASE(1024); ZH_SCAN_CASE(1536);
+        ZH_SCAN_CASE(128); ZH_SCAN_CASE(384); ZH_SCAN_CASE(768);
     default: return hipErrorInvalidValue;
     }
 #undef ZH_SCAN_CASE

@@ -276,6 +276,10 @@ class LSHIndex:
     def set_dense_levels(self, levels):
         check(lib().zh_set_dense_levels(self._h, levels))
 
+    def set_sweep_mode(self, mode):
+        """0 = chosen per batch (default), 1 = leaf by leaf, 2 = table scan (zh_set_sweep_mode)"""
+        check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2}.get(mode, mode)))
+
     def stats(self, reset=False):
         s = _ffi.Stats()
         check(lib().zh_stats(self._h, C.byref(s)))
