@@ -90,7 +90,7 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wLogPool, wLogHead, wLogCtl;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wLogPool, wLogHead, wLogCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -110,7 +110,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup,
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit,
                         &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
@@ -1345,6 +1345,13 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         if (!ix->row_leaf_valid && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;
         if (!ix->row_leaf_valid) c->scan = false;
     }
+    if (c->scan) {
+        const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
+        if ((rc = c->wVisitBits.ensure((nn + 31) / 32 * 4))) return rc;
+        if ((rc = c->wNodeVisit.ensure(nn * sizeof(uint2)))) return rc;
+        HIPCHK(zh_launch_node_visits(c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(), ix->n_nodes, c->wVisitBits.as<uint32_t>(),
+                                     c->wNodeVisit.as<uint2>(), s));
+    }
     if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     HIPCHK(hipEventRecord(c->ev[2], s));
@@ -1355,7 +1362,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
     if (c->scan)
         HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
-                                    c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(), c->wGroups.as<ZhGroup>(), f.group,
+                                    c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint2>(), c->wGroups.as<ZhGroup>(), f.group,
                                     c->metric, c->mode, c->wKeys.as<uint64_t>(), hs));
     else
         HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),

@@ -1532,6 +1532,29 @@ hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, 
     return hipGetLastError();
 }
 
+// Per batch, for the table scan: bit n of `bits` = leaf node n is visited by the batch (a 16-KB bitmap for the 130k nodes of
+// cfg3: it stays in L1, and two thirds of a row's T entries are answered by it without an L2 request), and the visited
+// leaves' {visits, first group} side by side (one 8-byte load instead of two 4-byte ones in different arrays).
+__global__ __launch_bounds__(256) void node_visit_kernel(const uint32_t *__restrict__ leafCount, const uint32_t *__restrict__ groupBase,
+                                                          uint32_t n_nodes, uint32_t *__restrict__ bits, uint2 *__restrict__ nodeVisit) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // one 32-node word per thread
+    const uint32_t n0 = w * 32;
+    if (n0 >= n_nodes) return;
+    uint32_t word = 0;
+    for (uint32_t i = 0; i < 32 && n0 + i < n_nodes; i++) {
+        const uint32_t c = leafCount[n0 + i];
+        if (c) { word |= 1u << i; nodeVisit[n0 + i] = make_uint2(c, groupBase[n0 + i]); }
+    }
+    bits[w] = word;
+}
+hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGroupBase, uint32_t n_nodes, uint32_t *dBits,
+                                 uint2 *dNodeVisit, hipStream_t s) {
+    const uint32_t words = (n_nodes + 31) / 32;
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(node_visit_kernel, dim3((words + 255) / 256), dim3(256), 0, s, dLeafCount, dGroupBase, n_nodes, dBits, dNodeVisit);
+    return hipGetLastError();
+}
+
 // one stored row (in the canonical lane layout) against one query: the canonical sums of the pair
 template <int D, int KIND>
 __device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, uint32_t lane, int power, float &s0, float &s1) {
@@ -1576,8 +1599,8 @@ __device__ __forceinline__ void load_row_stream(const float *__restrict__ row, u
 template <int D, int KIND>
 __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
                                                           const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
-                                                          uint32_t T, uint32_t RW, const uint32_t *__restrict__ leafCount,
-                                                          const uint32_t *__restrict__ groupBase,
+                                                          uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
+                                                          const uint2 *__restrict__ nodeVisit,
                                                           const ZhGroup *__restrict__ groups, uint32_t GRP, uint64_t row_begin,
                                                           uint64_t row_end, int metric, int param,
                                                           uint64_t *__restrict__ keys) {
@@ -1593,17 +1616,20 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
     const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
     // ---- phase 1: the wave's nr * T (row, tree) entries, lane-parallel: visits of the entry's leaf -> pairs; the pairs of
     // the whole wave go to an LDS list in (row, tree, visit) order ----
-    uint32_t eNode[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
     uint32_t P = 0;
 #pragma unroll
     for (int j = 0; j < ZH_SCAN_NE; j++) {
         const uint32_t e = lane + 64u * j;
-        eNode[j] = 0xFFFFFFFFu; eWithin[j] = 0; eC[j] = 0;
+        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0;
         if (e < n_ent) {
             const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));  // streamed once
             const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
-            eNode[j] = rl.x; eWithin[j] = rl.y;
-            if (rl.x != 0xFFFFFFFFu) eC[j] = leafCount[rl.x];
+            eWithin[j] = rl.y;
+            if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
+                const uint2 nv = nodeVisit[rl.x];
+                eC[j] = nv.x; eGb[j] = nv.y;
+            }
         }
         uint32_t incl = eC[j];  // inclusive scan over the lanes
 #pragma unroll
@@ -1650,7 +1676,7 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
         for (int j = 0; j < ZH_SCAN_NE; j++) {
             const uint32_t c = eC[j];
             if (c) {
-                const uint32_t rl = (lane + 64u * j) / T, gb = groupBase[eNode[j]];
+                const uint32_t rl = (lane + 64u * j) / T, gb = eGb[j];
                 mrows |= 1u << rl;
                 for (uint32_t sidx = 0; sidx < c; sidx++) {
                     const ZhGroup *g = groups + gb + sidx / GRP;
@@ -1718,9 +1744,9 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], l);
-                const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)eNode[j], l);
+                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], l);
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], l);
-                const uint32_t rl = ((uint32_t)l + 64u * j) / T, gb = groupBase[node];
+                const uint32_t rl = ((uint32_t)l + 64u * j) / T;
                 if (rl != cur) {
                     cur = rl;
                     load_row<D, true>(X + (size_t)(r0 + rl) * D, lane, v);
@@ -1756,7 +1782,7 @@ bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric) {
 
 template <int D, int KIND>
 static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *dQ, const float *dQQ, const uint2 *dRowLeaf,
-                                 uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase, const ZhGroup *dGroups,
+                                 uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit, const ZhGroup *dGroups,
                                  uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
     const uint32_t RW = zh_scan_rows_per_wave(T);
     uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
@@ -1766,16 +1792,16 @@ static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *
         const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
         hipLaunchKernelGGL((scan_sweep_kernel<D, KIND>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, dQ, dQQ, dRowLeaf, T, RW,
-                           dLeafCount, dGroupBase, dGroups, group, r, r_end, metric, param, dKeys);
+                           dVisitBits, dNodeVisit, dGroups, group, r, r_end, metric, param, dKeys);
     }
     return hipGetLastError();
 }
 template <int KIND>
 static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
-                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit,
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
 #define ZH_SCAN_CASE(DD) \
-    case DD: return launch_scan_dk<DD, KIND>(dX, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s)
+    case DD: return launch_scan_dk<DD, KIND>(dX, n_rows, dQ, dQQ, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, param, dKeys, s)
     if constexpr (KIND == K_L2 || KIND == K_COS) {
         switch (d) {
             ZH_SCAN_CASE(64); ZH_SCAN_CASE(256); ZH_SCAN_CASE(512); ZH_SCAN_CASE(1024); ZH_SCAN_CASE(1536);
@@ -1789,11 +1815,11 @@ static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, co
 #undef ZH_SCAN_CASE
 }
 hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
-                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dLeafCount, const uint32_t *dGroupBase,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit,
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
     if (!n_rows) return hipSuccess;
 #define ZH_KIND_CASE(K) \
-    case K: return launch_scan_k<K>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s)
+    case K: return launch_scan_k<K>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, param, dKeys, s)
     switch (zh_kind_of(metric)) {
         ZH_KIND_CASE(K_COS);
         ZH_KIND_CASE(K_MAX);
@@ -1804,7 +1830,7 @@ hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, co
         ZH_KIND_CASE(K_P4);
         ZH_KIND_CASE(K_HAMM);
         ZH_KIND_CASE(K_PP);
-    default: return launch_scan_k<K_L2>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dLeafCount, dGroupBase, dGroups, group, metric, param, dKeys, s);
+    default: return launch_scan_k<K_L2>(dX, d, n_rows, dQ, dQQ, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, param, dKeys, s);
     }
 #undef ZH_KIND_CASE
 }
