@@ -361,20 +361,13 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     launches_per_batch = n_launch / n_timed
     # algorithmic bytes of one sweep launch (DESIGN.md "Kernels"): every distinct stored row crosses HBM once (4*d bytes),
     # every scored row reads a 4-byte leaf id and writes an 8-byte key, plus the query batch
-    bytes_leaf_unique = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
+    # SURVEY s8(d)'s numerator, the same for both sweep kinds: every row of every DISTINCT LEAF the launch's visits touch crosses
+    # HBM once (4*d bytes), every scored (row, query) pair reads a 4-byte leaf id and writes an 8-byte key, plus the queries
+    bytes_alg = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
     bytes_nosharing = (4.0 * d + 12.0) * rows_per_launch
     scan = st["scan_batches_accum"] > 0
     kind = 1 if wl["metric"] == "cosine" else 0
-    if scan:
-        # table scan: one launch streams `stored` consecutive stored rows ONCE (4*d bytes each, in address order) with their
-        # T row -> leaf entries (8 bytes each), and writes one 8-byte key per scored (row, query) pair; the queries of the
-        # pairs come from L2.  These are the bytes the kernel has to move through HBM by design.
-        stored = st["swept_rows_accum"] / n_launch
-        bytes_alg = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
-        kname = "scan_sweep_kernel<%d, %d>" % (d, kind)
-    else:
-        bytes_alg = bytes_leaf_unique
-        kname = "sweep_kernel<%d, %d, ...>" % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
+    kname = ("scan_sweep_kernel<%d, %d>" if scan else "sweep_kernel<%d, %d, ...>") % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
     achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch,
@@ -382,13 +375,21 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             "launches_per_batch": launches_per_batch, "bytes_per_launch": bytes_alg,
             "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0}
     if scan:
-        # SURVEY s8(d)'s numerator -- every row of every DISTINCT LEAF touched crosses HBM once -- is what the leaf-major
-        # sweep is priced by; the table scan reads a row once for ALL the leaves (trees) that want it, so this figure can
-        # exceed the HBM peak.  It is reported for comparison with round 1, never as `achieved`.
-        roof["sweep_mode"] = "table scan (stored rows streamed once per batch window, queries from L2)"
-        roof["leaf_unique_bytes_per_launch"] = bytes_leaf_unique
-        roof["leaf_unique_equivalent_GBps"] = bytes_leaf_unique / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
-        roof["pair_operand_GBps_from_L2"] = 4.0 * d * rows_per_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
+        # The table scan does not move s8(d)'s bytes through HBM: a stored row is wanted by several leaves (one per tree) and is
+        # read ONCE for all of them, so `achieved` -- the s8(d) bytes over the launch time, the figure comparable with the
+        # leaf-major sweep and with round 1 -- can exceed the HBM peak.  What the kernel moves through HBM by design: the launch's
+        # stored rows once (4*d bytes, address order) + their T row->leaf entries (8 bytes each) + an 8-byte key per pair; what
+        # binds it is the L2 -> CU operand traffic, one query (4*d bytes) per pair (measured L2 row-gather ceiling: 16.8-18.8 TB/s,
+        # MI355X_MICROARCH.md 'Indexed rows').
+        stored = st["swept_rows_accum"] / n_launch
+        by_design = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
+        roof["sweep_mode"] = "table scan: stored rows streamed once per batch window, each scored against every query that visits one of its leaves (queries from L2)"
+        roof["frac_note"] = ("achieved = SURVEY s8(d) bytes / launch time; above the HBM peak because one HBM read of a row serves every tree "
+                             "that wants it -- see hbm_bytes_by_design_per_launch / hbm_frac_by_design for what crosses HBM")
+        roof["hbm_bytes_by_design_per_launch"] = by_design
+        roof["hbm_frac_by_design"] = by_design / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms else 0.0
+        roof["l2_operand_GBps"] = (4.0 * d * (rows_per_launch + stored)) / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
+        roof["l2_gather_ceiling_GBps"] = [16800, 18800]
 
     out = {
         "qps": B * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
@@ -536,15 +537,20 @@ def pmc_traffic(args, name, S, roof):
         meta = pm.get("_meta", {})
         traffic = ent["hbm_bytes_per_launch"]
         # the PMC passes run the blocking call, where the last launch of a batch is partial: compare per ROW
-        prof_rows = ((meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}).get("rows_per_launch")
-        if prof_rows and abs(prof_rows / roof["rows_per_launch"] - 1) > 0.10:
+        # (table scan: a launch is a range of STORED rows -- rows_loaded_per_launch -- whatever the window's pair count)
+        key = "rows_loaded_per_launch" if "sweep_mode" in roof else "rows_per_launch"
+        prof_rows = ((meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}).get(key)
+        if prof_rows and abs(prof_rows / roof[key] - 1) > 0.10:
             return  # collected at another launch granularity
         roof["traffic"] = traffic
         roof["traffic_over_algorithmic"] = traffic / roof["bytes_per_launch"]
+        if "hbm_bytes_by_design_per_launch" in roof:
+            roof["traffic_over_by_design"] = traffic / roof["hbm_bytes_by_design_per_launch"]
         roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
-                                  "note": "committed PMC summary of this command (separate rocprofv3 --pmc passes with --no-pipeline; not collected "
-                                          "by this run).  FETCH_SIZE counts what L2 fetches from the fabric: for the table scan that includes "
-                                          "queries evicted from L2 and re-fetched from the Infinity Cache, which are not HBM reads"}
+                                  "note": "committed PMC summary of this command (separate rocprofv3 --pmc passes with --no-pipeline, i.e. window 1: "
+                                          "for the table scan half the pairs per launch of the pipelined run; not collected by this run).  FETCH_SIZE "
+                                          "counts what L2 fetches from the fabric: for the table scan that includes queries evicted from L2 and "
+                                          "re-fetched from the Infinity Cache, which are not HBM reads"}
     except Exception:
         return
 
@@ -584,7 +590,7 @@ def main():
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("kernel", "achieved", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch", "rows_per_launch",
-                                                               "rows_loaded_per_launch", "sweep_mode", "leaf_unique_equivalent_GBps", "pair_operand_GBps_from_L2")
+                                                               "rows_loaded_per_launch", "sweep_mode", "hbm_bytes_by_design_per_launch", "hbm_frac_by_design", "l2_operand_GBps")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"]}
