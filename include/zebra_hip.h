@@ -167,7 +167,7 @@ ZH_API int zh_index_append_device(zh_index *idx, const float *d_rows, size_t n);
 ZH_API int zh_index_append_synthetic(zh_index *idx, size_t n, uint64_t seed, uint64_t first_row, int kind);
 ZH_API int zh_index_build(zh_index *idx); /* (re)build all trees on the GPU */
 /* LSHIndex::remove (lsh.rs:473-503) as intended: the ids leave every tree (the reference only edits trees whose root
- * is a leaf) and zh_index_count drops; their vectors stay addressable for hyperplane sampling.  out_found (may be
+ * is a leaf) and zh_index_count drops; later splits no longer sample them (lsh.rs:495, 197-201).  out_found (may be
  * NULL): 1 per id that was present.  LSHIndex::deduplicate (lsh.rs:270-288): rows bit-identical to an earlier row are
  * removed; out_ids (may be NULL) receives up to cap removed ids, ascending. */
 ZH_API int zh_index_remove(zh_index *idx, const uint64_t *ids, size_t n, uint8_t *out_found, size_t *out_n_removed);

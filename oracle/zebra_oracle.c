@@ -341,6 +341,10 @@ typedef struct zo_forest {
     uint32_t *leaf_ids;
     uint64_t n_leaf_ids, cap_leaf_ids;
     int borrowed; /* the arrays belong to the caller (zo_forest_borrow_arrays): never reallocated or freed here */
+    /* rows removed by zo_forest_remove: LSHIndex::remove deletes the embedding from the KV store (lsh.rs:495) and
+     * build_hyperplane samples from the stored embeddings only (lsh.rs:197-201), so a removed row never defines a plane */
+    uint8_t *dead;
+    uint64_t dead_cap, n_dead;
 } zo_forest;
 
 static uint32_t new_node(zo_forest *f) {
@@ -383,6 +387,27 @@ ZO_EXPORT void zo_sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint6
     if (*j >= *i) (*j)++;
 }
 
+/* The two sample rows of a split, drawn from the LIVE rows among the first n_rows (lsh.rs:197-201 iterates the embeddings
+ * partition, which remove() has deleted from): the draw (i, j) over the live count is mapped to the i-th / j-th live row.
+ * Returns the live count (< 2: lsh.rs:203-220 falls back to default vectors). */
+static uint64_t sample_live_pair(const zo_forest *f, uint32_t tree, uint64_t path, uint64_t n_rows, uint64_t *si, uint64_t *sj) {
+    uint64_t n_live = n_rows;
+    if (f->n_dead)
+        for (uint64_t r = 0; r < n_rows && r < f->dead_cap; r++) n_live -= f->dead[r];
+    zo_sample_pair(f->seed, tree, path, n_live, si, sj);
+    if (f->n_dead && n_live) {
+        uint64_t want[2] = {*si, *sj}, got[2] = {0, 0}, k = 0;
+        for (uint64_t r = 0; r < n_rows; r++) {
+            if (r < f->dead_cap && f->dead[r]) continue;
+            if (k == want[0]) got[0] = r;
+            if (k == want[1]) got[1] = r;
+            k++;
+        }
+        *si = got[0]; *sj = got[1];
+    }
+    return n_live;
+}
+
 /* lsh.rs:222-225: w = b - a ; p = (a + b) / 2 ; c = -(dot(w, p)) as f32 */
 ZO_EXPORT void zo_make_hyperplane(const float *a, const float *b, uint32_t d, float *w, float *c) {
     float acc = 0.0f;
@@ -409,14 +434,14 @@ static int32_t build_node_into(zo_forest *f, uint32_t me, const float *X, uint32
     }
     uint32_t d = f->d;
     uint64_t si, sj;
-    zo_sample_pair(f->seed, tree, path, f->n_rows, &si, &sj);
+    const uint64_t n_live = sample_live_pair(f, tree, path, f->n_rows, &si, &sj);
     uint32_t p = new_plane(f);
     float *w = f->planes + (size_t)p * d;
     float *zero = NULL;
     const float *a = X + si * d, *b = X + sj * d;
-    if (f->n_rows < 2) { /* lsh.rs:203-220: missing samples decode to the all-zero default */
+    if (n_live < 2) { /* lsh.rs:203-220: missing samples decode to the all-zero default */
         zero = calloc(d, sizeof(float));
-        if (f->n_rows == 0) a = zero;
+        if (n_live == 0) a = zero;
         b = zero;
     }
     zo_make_hyperplane(a, b, d, w, &f->consts[p]);
@@ -536,6 +561,15 @@ ZO_EXPORT uint64_t zo_forest_remove(zo_forest *f, const float *X, const uint64_t
                 found |= hit;
             }
         }
+        if (found) { /* the embedding is gone from the store: it can no longer be sampled */
+            if (ids[r] >= f->dead_cap) {
+                uint64_t cap = f->n_rows > ids[r] + 1 ? f->n_rows : ids[r] + 1;
+                f->dead = realloc(f->dead, cap);
+                memset(f->dead + f->dead_cap, 0, cap - f->dead_cap);
+                f->dead_cap = cap;
+            }
+            if (!f->dead[ids[r]]) { f->dead[ids[r]] = 1; f->n_dead++; }
+        }
         if (out_found) out_found[r] = (uint8_t)found;
         removed += found;
     }
@@ -621,6 +655,7 @@ ZO_EXPORT zo_forest *zo_forest_borrow_arrays(uint64_t n_rows, uint32_t d, uint32
 
 ZO_EXPORT void zo_forest_free(zo_forest *f) {
     if (!f) return;
+    free(f->dead);
     if (f->borrowed) { free(f->depth); free(f); return; }
     free(f->plane); free(f->left); free(f->right); free(f->depth); free(f->roots);
     free(f->planes); free(f->consts); free(f->leaf_ids); free(f);

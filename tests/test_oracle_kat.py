@@ -375,3 +375,27 @@ def test_search_with_a_distances_crate_metric():
     f = zo.Forest.build(X, 64, 5)
     ids, keys = f.search(X[77], 5, zo.MANHATTAN)
     assert ids[0] == 77 and keys[0] == 0 and (np.diff(keys.astype(np.int64)) >= 0).all()
+
+
+def test_removed_rows_never_define_a_plane():
+    """LSHIndex::remove deletes the embedding (lsh.rs:495) and build_hyperplane samples the stored embeddings only
+    (lsh.rs:197-201): every plane created after a removal is the hyperplane of two LIVE rows."""
+    n0, n1, d, M, T = 80, 120, 6, 8, 3
+    X = zo.synth_rows(n0 + n1, d)
+    f = zo.Forest.build(X[:n0], M, T, seed=3)
+    planes_before = f.arrays()["planes"].shape[0]
+    gone = np.arange(0, n0, 2, dtype=np.uint64)  # half of the first rows
+    assert f.remove(gone).all()
+    f.insert(X, n0)
+    a = f.arrays()
+    assert a["planes"].shape[0] > planes_before  # the inserts split leaves: new planes exist
+    live = [r for r in range(n0 + n1) if r not in set(gone.tolist())]
+    pairs = {}
+    for i in live:
+        for j in live:
+            if i != j:
+                w, c = zo.make_hyperplane(X[i], X[j])
+                pairs[(w.tobytes(), np.float32(c).tobytes())] = (i, j)
+    for p in range(planes_before, a["planes"].shape[0]):
+        key = (a["planes"][p].astype(np.float32).tobytes(), np.float32(a["consts"][p]).tobytes())
+        assert key in pairs, p

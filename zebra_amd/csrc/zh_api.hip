@@ -139,6 +139,9 @@ struct zh_index {
     std::vector<uint32_t> h_leaf_ids;          // host mirror of leaf_ids, materialised by the first incremental add
     std::vector<uint8_t> h_dead;               // rows removed by zh_index_remove (their vectors stay in X)
     uint64_t n_dead = 0;
+    std::vector<uint32_t> h_live;              // ascending live rows, for hyperplane sampling once rows were removed
+    uint64_t h_live_rows = ~0ull;              // n_rows / n_dead h_live was built for
+    uint64_t h_live_dead = ~0ull;
     uint32_t max_leaf_len = 0;
     // blocked view of the forest (ZhBlocksDev) for all-dense walks: built on first use, dropped whenever the trees change
     DevBuf blk_recs, blk_upper, blk_roots;
@@ -532,6 +535,25 @@ static void sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint64_t n_
     if (*j >= *i) (*j)++;
 }
 
+// The two sample rows of a split come from the LIVE rows among the first n_sample: LSHIndex::remove deletes the embedding from
+// the store (lsh.rs:495) and build_hyperplane samples the stored embeddings only (lsh.rs:197-201), so a removed row never
+// defines a plane.  Returns the live count (< 2: default zero vectors, lsh.rs:203-220).  Same mapping as the oracle's.
+static uint64_t sample_live_pair(zh_index *ix, uint32_t tree, uint64_t path, uint64_t n_sample, uint64_t *si, uint64_t *sj) {
+    if (ix->n_dead == 0) { sample_pair(ix->opt.seed, tree, path, n_sample, si, sj); return n_sample; }
+    if (ix->h_live_rows != ix->n_rows || ix->h_live_dead != ix->n_dead) {
+        ix->h_live.clear();
+        ix->h_live.reserve(ix->n_rows - ix->n_dead);
+        for (uint64_t r = 0; r < ix->n_rows; r++)
+            if (!(r < ix->h_dead.size() && ix->h_dead[r])) ix->h_live.push_back((uint32_t)r);
+        ix->h_live_rows = ix->n_rows; ix->h_live_dead = ix->n_dead;
+    }
+    const uint64_t n_live = (uint64_t)(std::lower_bound(ix->h_live.begin(), ix->h_live.end(), n_sample,
+                                                        [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - ix->h_live.begin());
+    sample_pair(ix->opt.seed, tree, path, n_live, si, sj);
+    if (n_live) { *si = ix->h_live[*si]; *sj = ix->h_live[*sj]; }
+    return n_live;
+}
+
 struct ActiveNode {   // a node whose id list (a segment of a perm array) is to be split
     uint32_t node, tree, len, depth;
     uint64_t seg_start, path, n_sample;  // n_sample: size of the database the two sample rows are drawn from
@@ -569,9 +591,9 @@ static int grow_segments(zh_index *ix, uint32_t *d_perm, uint64_t perm_len, std:
             ZhBuildNode bn;
             bn.seg_start = a.seg_start; bn.len = a.len; bn.plane = n_planes + (uint32_t)i;
             uint64_t si, sj;
-            sample_pair(ix->opt.seed, a.tree, a.path, a.n_sample, &si, &sj);
-            bn.sample_a = a.n_sample >= 1 ? si : ~0ull;   // lsh.rs:203-220: a missing sample decodes to the zero vector
-            bn.sample_b = a.n_sample >= 2 ? sj : ~0ull;
+            const uint64_t n_live = sample_live_pair(ix, a.tree, a.path, a.n_sample, &si, &sj);
+            bn.sample_a = n_live >= 1 ? si : ~0ull;   // lsh.rs:203-220: a missing sample decodes to the zero vector
+            bn.sample_b = n_live >= 2 ? sj : ~0ull;
             bn.first_chunk = (uint32_t)hc.size();
             bn.n_chunks = (a.len + 255) / 256;
             for (uint32_t c = 0; c < bn.n_chunks; c++) {
@@ -631,7 +653,7 @@ static int build_forest_locked(zh_index *ix) {
     free_forest(ix);
     ix->broken = false;
     if ((uint64_t)T * N > 0xFFFFFFFFull) return fail(ZH_ELIMIT, "num_trees * rows exceeds 2^32-1 leaf entries; shard the index");
-    const uint64_t NL = N - ix->n_dead;  // removed rows stay out of a rebuild (their vectors may still be sampled)
+    const uint64_t NL = N - ix->n_dead;  // removed rows stay out of a rebuild, as leaf members and as hyperplane samples
     const uint64_t total = (uint64_t)T * NL;
     DevBuf perm;
     if ((rc = perm.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
