@@ -89,7 +89,10 @@ def parse():
     ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
                     help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking search call per step")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight when pipelined")
+    ap.add_argument("--in-flight", type=int, default=2, help="windows in flight when pipelined (contexts); the look-ahead host loop uses one more")
+    ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
+                    help="host loop: begin window w+1 before finishing window w (its hash runs beside w's walk).  Pays when hash + walk "
+                         "outweigh the sweep (reference-default options: -8 %% per batch), costs elsewhere; auto decides from the warm-up's stage times")
     ap.add_argument("--window", type=int, default=2,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan"], default="auto",
@@ -233,7 +236,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             _hs = torch.cuda.Stream(device=dev, priority=0)
             heavy = _hs.cuda_stream
         slots = [dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1), res=[make_results() for _ in range(WIN)])
-                 for _ in range(NS)] if pipelined else []
+                 for _ in range(NS + 1)] if pipelined else []
 
         def begin(sl, i, nw):
             sl["nw"] = nw
@@ -261,7 +264,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         hip = ctypes.CDLL("libamdhip64.so.7")
         hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
-        slots = [dict(ctx=group.search_context(), res=[make_results() for _ in range(WIN)]) for _ in range(NS if pipelined else 0)]
+        slots = [dict(ctx=group.search_context(), res=[make_results() for _ in range(WIN)]) for _ in range(NS + 1 if pipelined else 0)]
 
         def begin(sl, i, nw):
             sl["nw"] = nw
@@ -286,23 +289,34 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                       r0["counts"].data_ptr())
             to_host(r0, cur)
 
+    look = {"ahead": args.lookahead == "on"}
+
     def run(first, n):
         if not pipelined:
             for i in range(first, first + n):
                 blocking(i)
             torch.cuda.synchronize()
             return
-        # begin + finish of batch i back to back on slot i % NS: begin first retires batch i-NS of that slot (long done),
-        # finish blocks the host only until batch i's own counting pass has run -- beside the sweep of batch i-1, which
-        # is still on the GPU -- and leaves batch i's sweep queued behind it
-        i, w = first, 0
+        # Window w + 1 is BEGUN (hash + walk enqueued on its own stream; begin first retires window w + 1 - NS of that slot,
+        # long done) before window w is FINISHED: finish blocks the host until w's counting pass has run, and with the next
+        # window's hash already queued the GPU runs it beside w's walk (the MFMA-bound hash and the latency-bound walk of the
+        # reference-default regime do not compete) and beside the sweep of w - 1; finish then leaves w's sweep queued.
+        wins = []
+        i = first
         while i < first + n:
-            sl = slots[w % NS]
             nw = min(WIN, first + n - i)
-            begin(sl, i, nw)
-            finish(sl)
+            wins.append((i, nw))
             i += nw
-            w += 1
+        if not look["ahead"]:  # begin + finish of a window back to back, NS windows in flight
+            for w in range(len(wins)):
+                begin(slots[w % NS], *wins[w])
+                finish(slots[w % NS])
+        else:                  # one more slot: a window begun ahead, one being finished, NS - 1 sweeping
+            begin(slots[0], *wins[0])
+            for w in range(len(wins)):
+                if w + 1 < len(wins):
+                    begin(slots[(w + 1) % (NS + 1)], *wins[w + 1])
+                finish(slots[w % (NS + 1)])
         for sl in slots:
             drain(sl)
 
@@ -313,9 +327,17 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         drain(sl)
     if not pipelined:
         blocking(0)
+    ix.set_profiling(1)  # hipEvents around every stage, on the stream the kernels run on
+    ix.stats(reset=True)
     if warmup:
         run(0, warmup)
-    ix.set_profiling(1)  # hipEvents around every stage, on the stream the kernels run on
+    if args.lookahead == "auto" and pipelined and warmup:
+        sw = ix.stats()
+        look["ahead"] = sw["ms_hash"] + sw["ms_walk"] > 1.5 * sw["ms_sweep"]  # same decision on every rank would need a collective:
+        if env.dist and exchange:                                                 # rank 0 decides
+            flag = [look["ahead"]]
+            env.dist.broadcast_object_list(flag, src=0)
+            look["ahead"] = flag[0]
     ix.stats(reset=True)
     torch.cuda.synchronize()
     env.barrier()
@@ -331,7 +353,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ix.stats()
-    last = slots[((steps + WIN - 1) // WIN - 1) % NS]["res"][(steps - 1) % WIN] if pipelined else r0
+    last = slots[((steps + WIN - 1) // WIN - 1) % (NS + 1 if look["ahead"] else NS)]["res"][(steps - 1) % WIN] if pipelined else r0
     last_host = (last["h_ids"].numpy().copy(), last["h_counts"].numpy().copy())
 
     # ---- untimed: R_unique of the timed batches (per internal batch = per window: a row shared by two batches of a window
@@ -400,6 +422,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                    if S > 1 else "1 GPU")},
         "roofline": roof,
         "stage_ms_per_batch": {s_: st["ms_" + s_] / n_timed for s_ in ("hash", "walk", "sweep", "select", "final")},
+        "host_loop": "look-ahead (window w+1 begun before w is finished)" if look["ahead"] else "begin + finish back to back",
         "visits_per_batch": st["visits"] / max(st["window_batches"], 1), "rows_scored_per_batch": st["rows_scored"] / max(st["window_batches"], 1),
         "window_batches": WIN,
         "setup_s": {"fill": t_fill, "build": t_build},
@@ -592,7 +615,7 @@ def main():
                                                               ("kernel", "achieved", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch", "rows_per_launch",
                                                                "rows_loaded_per_launch", "sweep_mode", "hbm_bytes_by_design_per_launch", "hbm_frac_by_design", "l2_operand_GBps")
                                                               if kk in r["roofline"]},
-                          "stage_ms_per_batch": r["stage_ms_per_batch"], "visits_per_batch": r["visits_per_batch"],
+                          "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"]}
         if not only or "recall_clustered" in only:
             # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative
