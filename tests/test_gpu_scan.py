@@ -103,3 +103,23 @@ def test_table_scan_after_insert_remove_and_in_windows(za):
         assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all()
     assert not np.isin(ids[ids != np.uint64(2**64 - 1)], np.arange(100, 400, dtype=np.uint64)).any()
     ix.close()
+
+
+def test_table_scan_with_rows_appended_but_not_yet_in_a_tree(za):
+    """zh_index_append after a build: the new rows are stored but in no tree until the next add / build; the scan covers them
+    with 'in no leaf' entries and results equal the leaf-major sweep's"""
+    n, d, M, T, k, B = 5000, 256, 64, 4, 10, 16
+    X = zo.synth_rows(n + 700, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X[:n])
+    Q = zo.synth_queries(B, d, n)
+    m = za.L2Distance()
+    ix.set_sweep_mode("scan")
+    a = ix.search_batch(Q, k, m)
+    ix.append(X[n:])            # staged rows: stored, not yet indexed
+    b = ix.search_batch(Q, k, m)
+    assert ix.stats()["table_scan"] == 1 and ix.stats()["rows_swept"] == n + 700
+    ix.set_sweep_mode("leaf")
+    c = ix.search_batch(Q, k, m)
+    assert all((x == y).all() for x, y in zip(a, b)) and all((x == y).all() for x, y in zip(a, c))
+    ix.close()

@@ -151,6 +151,7 @@ struct zh_index {
     // row -> (leaf, position) per tree for the table-scan sweep (zh_launch_row_leaf): built on first use, dropped with the trees
     DevBuf row_leaf;
     bool row_leaf_valid = false, row_leaf_failed = false;
+    uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
     zh_search_ctx dctx;
@@ -1144,6 +1145,7 @@ static int build_row_leaf(zh_index *ix) {
     dTree.release();
     if (e != hipSuccess) return fail(ZH_EHIP, "row -> leaf table: %s", hipGetErrorString(e));
     ix->row_leaf_valid = true;
+    ix->row_leaf_rows = ix->n_rows;
     return ZH_OK;
 }
 
@@ -1362,10 +1364,10 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         }
     }
     c->scan = choose_scan(ix, tot, c->metric, B);
-    if (c->scan && !ix->row_leaf_valid) {  // first table scan since the trees changed
+    if (c->scan && (!ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows)) {  // first table scan since the trees (or the row count) changed
         std::lock_guard<std::mutex> lk(ix->blk_mu);
-        if (!ix->row_leaf_valid && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;
-        if (!ix->row_leaf_valid) c->scan = false;
+        if ((!ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows) && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;
+        if (!ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows) c->scan = false;
     }
     if (c->scan) {
         const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
