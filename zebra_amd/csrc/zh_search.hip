@@ -1765,6 +1765,185 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
     flush();
 }
 
+// ---- table scan at d = 128: TWO pairs per step.  A 512-byte row or query fills half a wave, and at 3-4 pairs per stored row
+// the generic kernel above spends its time on per-pair instructions (one butterfly, one record fetch, one stash per pair on a
+// half-empty wave).  Here lanes 0..31 work on pair p, lanes 32..63 on pair p + 1: pair records are read per LANE (no scalar
+// round trip), one load instruction fetches both queries, one half-wave butterfly reduces both, and the rows of a sub-batch
+// (4 at a time) wait in LDS so that each half can take the row its own pair names.  Same canonical sums (half_sum_canonical).
+#define ZH_SCAN128_CAP 192
+template <int KIND>
+__global__ __launch_bounds__(256) void scan128_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
+                                                             const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
+                                                             uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
+                                                             const uint2 *__restrict__ nodeVisit,
+                                                             const ZhGroup *__restrict__ groups, uint32_t GRP, uint64_t row_begin,
+                                                             uint64_t row_end, int metric, int param,
+                                                             uint64_t *__restrict__ keys) {
+    static_assert(KIND == K_L2 || KIND == K_COS, "the paired scan covers the two simsimd-path kinds");
+    __shared__ uint4 pair_list[4][ZH_SCAN128_CAP];
+    __shared__ float4 row_lds[4][4][32];
+    __shared__ uint32_t row_start[4][20];
+    const uint32_t lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r0 = row_begin + wave * RW;
+    if (r0 >= row_end) return;
+    const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
+    const uint32_t n_ent = nr * T;
+    const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+    const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
+    const float4 *__restrict__ Q4 = reinterpret_cast<const float4 *>(Q);
+    // ---- phase 1 (as scan_sweep_kernel): entries -> pairs, plus where every row's pairs start in the list ----
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
+    uint32_t P = 0;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t e = lane + 64u * j;
+        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0;
+        if (e < n_ent) {
+            const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));
+            const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
+            eWithin[j] = rl.y;
+            if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
+                const uint2 nv = nodeVisit[rl.x];
+                eC[j] = nv.x; eGb[j] = nv.y;
+            }
+        }
+        uint32_t incl = eC[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        off[j] = P + incl - eC[j];
+        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (P == 0) return;
+    float my_s0 = 0.f, my_s1 = 0.f;
+    uint64_t my_slot = ~0ull;
+    uint32_t my_b = 0;
+    if (P <= ZH_SCAN128_CAP) {
+        uint4 *list = pair_list[wid];
+        uint32_t *rstart = row_start[wid];
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            const uint32_t e = lane + 64u * j, c = eC[j];
+            if (e < n_ent && e % T == 0) rstart[e / T] = off[j];  // the first entry of a row: its pairs start here
+            if (c) {
+                const uint32_t rl = e / T, gb = eGb[j];
+                for (uint32_t sidx = 0; sidx < c; sidx++) {
+                    const ZhGroup *g = groups + gb + sidx / GRP;
+                    const uint64_t slot = g->key_off[sidx % GRP] + eWithin[j];
+                    list[off[j] + sidx] = make_uint4(rl, g->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+            }
+        }
+        if (lane == 0) rstart[nr] = P;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t npl = 0;  // pairs waiting in each half (pair n of a half in its lane n)
+        auto flush = [&]() {
+            if (hl < npl && my_slot != ~0ull)
+                __builtin_nontemporal_store(key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f), keys + my_slot);
+            npl = 0;
+        };
+        for (uint32_t rb = 0; rb < nr; rb += 4) {
+            const uint32_t re = rb + 4 < nr ? rb + 4 : nr;
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_readfirstlane((int)rstart[rb]);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)rstart[re]);
+            if (pa == pb) continue;  // nobody wants these four rows
+            {   // the sub-batch's rows into LDS: two rows per load instruction
+                const uint32_t ra = rb + half, rc = rb + 2 + half;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vc = va;
+                if (ra < re) va = ld16<true>(X4 + (size_t)(r0 + ra) * 32 + hl);
+                if (rc < re) vc = ld16<true>(X4 + (size_t)(r0 + rc) * 32 + hl);
+                row_lds[wid][half][hl] = va;
+                row_lds[wid][2 + half][hl] = vc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // lower half: pairs pa, pa + 2, ...; upper half: pa + 1, pa + 3, ...
+            uint32_t pi = pa + half;
+            uint4 rec = list[pi < pb ? pi : pb - 1];
+            float4 qc = Q4[(size_t)rec.y * 32 + hl];
+            for (uint32_t p = pa; p < pb; p += 2) {
+                const bool valid = p + half < pb;
+                const uint32_t pn = p + 2 + half;
+                const uint4 recn = list[pn < pb ? pn : pb - 1];
+                const float4 qn = Q4[(size_t)recn.y * 32 + hl];  // the next step's queries fly while this step is scored
+                const float4 v = row_lds[wid][rec.x - rb][hl];
+                float a2 = 0.f;
+                if (KIND == K_COS) {
+                    float4 c;
+                    c.x = __builtin_fmaf(v.x, v.x, 0.f); c.y = __builtin_fmaf(v.y, v.y, 0.f);
+                    c.z = __builtin_fmaf(v.z, v.z, 0.f); c.w = __builtin_fmaf(v.w, v.w, 0.f);
+                    a2 = half_sum_canonical((c.x + c.y) + (c.z + c.w));
+                }
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                float e1 = 0.f;
+                acc_elem<KIND>(v.x, qc.x, a.x, e1, param);
+                acc_elem<KIND>(v.y, qc.y, a.y, e1, param);
+                acc_elem<KIND>(v.z, qc.z, a.z, e1, param);
+                acc_elem<KIND>(v.w, qc.w, a.w, e1, param);
+                const float s0 = half_sum_canonical((a.x + a.y) + (a.z + a.w));
+                if (hl == npl) {
+                    my_s0 = s0; my_s1 = a2; my_b = rec.y;
+                    my_slot = valid ? (((uint64_t)rec.w << 32) | rec.z) : ~0ull;
+                }
+                if (++npl == 32) flush();
+                rec = recn; qc = qn;
+            }
+            __builtin_amdgcn_wave_barrier();  // the next sub-batch overwrites row_lds
+        }
+        flush();
+        return;
+    }
+    // more pairs than the list holds (hot leaves): entry after entry on the whole wave, as scan_sweep_kernel's slow path
+    uint32_t npend = 0;
+    auto flush1 = [&]() {
+        if (lane < npend) __builtin_nontemporal_store(key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f), keys + my_slot);
+        npend = 0;
+    };
+    float4 v[1];
+    float a2 = 0.f;
+    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        unsigned long long m = __ballot(eC[j] != 0);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], l);
+            const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], l);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], l);
+            const uint32_t rl = ((uint32_t)l + 64u * j) / T;
+            if (rl != cur) {
+                cur = rl;
+                load_row<128, true>(X + (size_t)(r0 + rl) * 128, lane, v);
+                if (KIND == K_COS) {
+                    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < 32) {
+                        c4.x = __builtin_fmaf(v[0].x, v[0].x, 0.f); c4.y = __builtin_fmaf(v[0].y, v[0].y, 0.f);
+                        c4.z = __builtin_fmaf(v[0].z, v[0].z, 0.f); c4.w = __builtin_fmaf(v[0].w, v[0].w, 0.f);
+                    }
+                    a2 = wave_sum_canonical((c4.x + c4.y) + (c4.z + c4.w));
+                }
+            }
+            for (uint32_t sidx = 0; sidx < c; sidx++) {
+                const ZhGroup *g = groups + gb + sidx / GRP;
+                const uint32_t b = g->b[sidx % GRP];
+                float4 q[1];
+                load_row<128>(Q + (size_t)b * 128, lane, q);
+                float s0 = 0.f, s1 = 0.f;
+                row_pair_sums<128, KIND>(v, q, lane, param, s0, s1);
+                if (lane == npend) { my_s0 = s0; my_s1 = KIND == K_COS ? a2 : s1; my_slot = g->key_off[sidx % GRP] + w; my_b = b; }
+                if (++npend == 64) flush1();
+            }
+        }
+    }
+    flush1();
+}
+
 // rows per wave of the table scan for T trees (0: T is beyond what a wave's entry registers hold -> leaf-major sweep)
 uint32_t zh_scan_rows_per_wave(uint32_t T) {
     if (T == 0 || T > 64u * ZH_SCAN_NE) return 0;
@@ -1791,6 +1970,14 @@ static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *
         const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
         const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if constexpr (D == 128 && (KIND == K_L2 || KIND == K_COS)) {
+            static const bool paired = getenv("ZH_SCAN128_GENERIC") == nullptr;  // A/B: the generic kernel at d = 128
+            if (paired) {
+                hipLaunchKernelGGL((scan128_sweep_kernel<KIND>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, dQ, dQQ, dRowLeaf, T, RW,
+                                   dVisitBits, dNodeVisit, dGroups, group, r, r_end, metric, param, dKeys);
+                continue;
+            }
+        }
         hipLaunchKernelGGL((scan_sweep_kernel<D, KIND>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, dQ, dQQ, dRowLeaf, T, RW,
                            dVisitBits, dNodeVisit, dGroups, group, r, r_end, metric, param, dKeys);
     }
