@@ -988,15 +988,31 @@ __global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const ui
                                                           uint32_t *__restrict__ groupBase,
                                                           uint64_t *__restrict__ groupRowBase,
                                                           unsigned long long *__restrict__ packed) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= f.n_nodes) return;
-    uint32_t c = leafCount[i];
-    if (!c) return;
-    uint64_t ng = (c + f.group - 1) / f.group;
-    uint64_t rows = ng * (uint32_t)f.node_right[i];
-    unsigned long long old = atomicAdd(packed, (unsigned long long)((ng << 36) | rows));
-    groupBase[i] = (uint32_t)(old >> 36);
-    groupRowBase[i] = old & ((1ull << 36) - 1);
+    // one atomic per WAVE (wave scan of the packed increments, the last lane adds the wave's total): with the reference's
+    // default options millions of visited leaves would otherwise queue on one address (2.4 ms for 6.5M atomics)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const uint32_t c = i < f.n_nodes ? leafCount[i] : 0;
+    unsigned long long v = 0;
+    if (c) {
+        const uint64_t ng = (c + f.group - 1) / f.group;
+        v = (unsigned long long)((ng << 36) | (ng * (uint32_t)f.node_right[i]));
+    }
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    const unsigned long long total = __shfl(incl, 63);
+    if (!total) return;  // wave-uniform
+    unsigned long long old = 0;
+    if (lane == 63) old = atomicAdd(packed, total);
+    old = __shfl(old, 63);
+    if (c) {
+        const unsigned long long mine = old + incl - v;
+        groupBase[i] = (uint32_t)(mine >> 36);
+        groupRowBase[i] = mine & ((1ull << 36) - 1);
+    }
 }
 hipError_t zh_launch_leaf_scan(ZhForestDev f, const uint32_t *dLeafCount, uint32_t *dGroupBase,
                                uint64_t *dGroupRowBase, ZhTotals *dTotals, hipStream_t s) {
