@@ -42,6 +42,7 @@ def test_fuzz_config(seed):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
     ix.set_dense_levels(int(rng.choice([-1, -1, 0, 1, 3, 64])))
+    ix.set_sweep_mode(str(rng.choice(["auto", "leaf", "scan"])))  # (scan falls back to leaf where it has no kernel: odd d)
     f = zo.Forest.build(X, M, T, seed=seed)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
     mets = _metrics(za, rng)
@@ -94,6 +95,7 @@ def test_fuzz_medium_wandering_walks(seed):
     f = zo.Forest.from_arrays(X, M, ix.get_forest())
     for dense in (-1, int(rng.choice([0, 2, 5]))):
         ix.set_dense_levels(dense)
+        ix.set_sweep_mode("scan" if dense == -1 else "leaf")
         m, om, omode = [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
                         (za.ManhattanDistance(), zo.MANHATTAN, 0)][int(rng.integers(0, 3))]
         ids, keys, counts = ix.search_batch(Q, k, m)
