@@ -1215,7 +1215,10 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
 }
 
 // D > 0: compile-time dimension (multiple of 4); D == 0: runtime d, any value (slow path)
-template <int D, int KIND, int G, int SWEEP_RG = 4, bool NT = false>
+// QLDS (A/B only, ZH_SWEEP_QLDS=1): the group's queries staged in LDS (one member's float4s in registers at a time) instead of
+// all G members in registers -- the north_star's "LDS-staged query tiles" taken literally; measured equal (62.2 k against 61.7 k QPS at cfg3:
+// the kernel is HBM-bound either way, profiles/r02_ab_query_staging.txt), registers kept.
+template <int D, int KIND, int G, int SWEEP_RG = 4, bool NT = false, bool QLDS = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X, uint32_t d,
                                                      const float *__restrict__ Q, const float *__restrict__ QQ,
                                                      const ZhGroup *__restrict__ groups,
@@ -1238,7 +1241,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
     if (D > 0) {
         constexpr int DD = (D > 0 ? D : 4);
         constexpr int NV = RowVec<DD>::NV;
-        float4 q[G][NV];
+        float4 q[QLDS ? 1 : G][NV];
+        __shared__ float4 qs[QLDS ? 4 : 1][QLDS ? G : 1][QLDS ? NV : 1][QLDS ? 64 : 1];
+        const uint32_t wq = (threadIdx.x >> 6) & 3;
         uint32_t cur_g = 0xFFFFFFFFu, gsize = 0;
         for (uint32_t i0 = 0; i0 < cnt; i0 += SWEEP_RG) {
             float4 v[SWEEP_RG][NV];
@@ -1258,12 +1263,31 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float *__restrict__ X,
                         gsize = groups[g].gsize;
 #pragma unroll
                         for (int m = 0; m < G; m++)
-                            if ((uint32_t)m < gsize) load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[m]);
+                            if ((uint32_t)m < gsize) {
+                                if constexpr (QLDS) {
+                                    load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[0]);
+#pragma unroll
+                                    for (int j = 0; j < NV; j++) qs[wq][m][j][lane] = q[0][j];
+                                } else
+                                    load_row<DD>(Q + (size_t)groups[g].b[m] * DD, lane, q[m]);
+                            }
                     }
                     float s0[G], s1[G];
 #pragma unroll
                     for (int m = 0; m < G; m++) { s0[m] = 0.f; s1[m] = 0.f; }
-                    row_sums_group<DD, KIND, G>(v[r], q, gsize, lane, param, s0, s1);
+                    if constexpr (QLDS) {
+#pragma unroll
+                        for (int m = 0; m < G; m++)
+                            if ((uint32_t)m < gsize) {
+#pragma unroll
+                                for (int j = 0; j < NV; j++) q[0][j] = qs[wq][m][j][lane];
+                                float t0[1] = {0.f}, t1[1] = {0.f};
+                                row_sums_group<DD, KIND, 1>(v[r], q, 1, lane, param, t0, t1);
+                                s0[m] = t0[0]; s1[m] = t1[0];
+                                if (KIND == K_COS) s1[0] = t1[0];
+                            }
+                    } else
+                        row_sums_group<DD, KIND, G>(v[r], q, gsize, lane, param, s0, s1);
                     if (lane == i) {
 #pragma unroll
                         for (int m = 0; m < G; m++) { mine0[m] = s0[m]; mine1[m] = KIND == K_COS ? s1[0] : s1[m]; }
@@ -1435,6 +1459,14 @@ static hipError_t launch_sweep_g(const SweepArgs &a) {
                 else if (v128 == 16) ZH_S128(16);
                 else ZH_S128(8);
 #undef ZH_S128
+                continue;
+            }
+        }
+        if constexpr (D == 768 && KIND == K_L2 && G == 4) {
+            static const bool qlds = getenv("ZH_SWEEP_QLDS") != nullptr;
+            if (qlds) {
+                hipLaunchKernelGGL((sweep_kernel<D, KIND, G, 4, true, true>), grid, blk, 0, a.s, a.dX, a.d, a.dQ, a.dQQ, a.dGroups,
+                                   a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys);
                 continue;
             }
         }
