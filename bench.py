@@ -637,7 +637,7 @@ def main():
             f"recall_at_{k}": res.get(f"recall_at_{k}"), f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
             "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
             "roofline": res["roofline"], "cpu_baseline": cpu[1] if cpu else None, "cpu_baseline_bitexact": cpu[0] if cpu else None,
-            "host_buffers_qps": res.get("host_buffers_qps"), "stage_ms_per_batch": res["stage_ms_per_batch"],
+            "host_buffers_qps": res.get("host_buffers_qps"), "stage_ms_per_batch": res["stage_ms_per_batch"], "host_loop": res["host_loop"],
             "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
             "setup_s": res["setup_s"],
         }
