@@ -143,6 +143,8 @@ typedef struct zh_stats_t {
     uint64_t table_scan;        /* 1: the most recent batch was swept by the table scan (every stored row streamed once, scored
                                  * against every query that visits one of its leaves; rows_swept = stored rows), 0: leaf by leaf */
     uint64_t scan_batches_accum; /* timed internal batches swept by the table scan */
+    uint64_t hash_from_scores;  /* 1: the most recent batch took every sign of the forest from row scores (zh_set_hash_mode) */
+    uint64_t hash_exact_fixups; /* ... and this many of its signs lay inside the rounding bound and were recomputed exactly */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -346,6 +348,14 @@ ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
  * address order, and scored against every query that visits one of its num_trees leaves; the queries come from L2), 0 = the
  * library chooses per batch from the counted work (default).  Results are bit-identical in both. */
 ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
+/* How a batch that needs EVERY sign of the forest (small leaves: the reference's default max_node_size 5) gets them:
+ * 1 = one dot product per (query, plane), 2 * b * planes * dim flop on the matrix cores; 2 = from row scores: a plane is built from
+ * two stored rows a, b (build_hyperplane, lsh.rs:192-225), and in exact arithmetic w.x + c = (b.x - |b|^2/2) - (a.x - |a|^2/2),
+ * so b * rows dot products decide all planes (planes / rows ~ 6.5x fewer flop at the default options); a sign closer to zero than
+ * a rigorous bound on the rounding that separates the two computations is recomputed with point_is_above's own arithmetic, so
+ * the bits are identical.  Only for forests built or grown by this library (an injected forest has arbitrary planes);
+ * 0 = chosen per batch (default). */
+ZH_API int zh_set_hash_mode(zh_index *idx, int mode);
 
 ZH_API const char *zh_last_error(void);
 ZH_API const char *zh_version(void);

@@ -1,0 +1,77 @@
+"""The row-score hash (zh_set_hash_mode 2; zebra_amd/csrc/zh_score.hip): every sign of a small-leaf forest from N row scores per
+query instead of one dot product per plane, the signs inside the rounding bound recomputed with point_is_above's own arithmetic
+(lsh.rs:39-43).  Bucket membership, ids and keys must stay bit-identical to the oracle and to the per-plane hash."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zebra_oracle as zo  # noqa: E402  (the checker)
+
+
+@pytest.fixture(scope="module")
+def za():
+    import zebra_amd
+    return zebra_amd
+
+
+@pytest.mark.parametrize("n,d,M,T,k,B,kind", [
+    (30000, 384, 5, 6, 10, 32, 0),    # the reference's default leaf size
+    (20000, 64, 3, 4, 10, 16, 2),     # clustered rows: planes between near-identical rows, small margins
+    (8000, 768, 8, 3, 40, 8, 0),
+    (15000, 128, 5, 5, 10, 24, 1),    # integer-valued rows: many exact ties (w.x + c == 0) -> the exact path decides
+    (6000, 100, 4, 3, 5, 12, 0),      # d not a multiple of 4: the score GEMM's scalar staging
+])
+def test_score_hash_equals_oracle_and_dense_hash(za, n, d, M, T, k, B, kind):
+    X = zo.synth_rows(n, d, kind=kind)
+    Q = zo.synth_queries(B, d, n, kind=kind)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    f = zo.Forest.from_arrays(X, M, ix.get_forest())
+    ix.set_dense_levels(100)  # every sign precomputed, as the library chooses by itself for wandering walks
+    m, om = za.L2SquaredDistance(), zo.L2SQ
+    oi, ok, oc = f.search_batch(Q, k, om, 0)
+    n_planes = ix.get_forest()["consts"].size
+    for mode in ("scores", "dense"):
+        ix.set_hash_mode(mode)
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        st = ix.stats()
+        assert st["hash_from_scores"] == (1 if mode == "scores" else 0), mode
+        if mode == "scores":  # the bound is neither vacuous nor empty
+            assert 0 < st["hash_exact_fixups"] < 0.2 * B * n_planes, (st["hash_exact_fixups"], B * n_planes)
+        assert (counts == oc).all(), mode
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), (mode, b)
+    ix.close()
+
+
+def test_score_hash_follows_inserts_and_is_refused_for_injected_forests(za):
+    n0, n1, d, M, T, k, B = 12000, 3000, 256, 5, 4, 10, 16
+    X = zo.synth_rows(n0 + n1, d)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.set_hash_mode("scores")
+    ix.add(X[:n0])
+    ix.add(X[n0:])  # incremental inserts: leaves split, planes (and their sample rows) are appended
+    f = zo.Forest.build(X[:n0], M, T)
+    f.insert(X, n0)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+    Q = zo.synth_queries(B, d, n0 + n1)
+    ix.set_dense_levels(-1)
+    ids, keys, counts = ix.search_batch(Q, k, za.L2Distance())
+    assert ix.stats()["hash_from_scores"] == 1  # small leaves: the library hashes every plane, from scores
+    oi, ok, oc = f.search_batch(Q, k, zo.L2, 0)
+    assert (counts == oc).all()
+    for b in range(B):
+        assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all()
+    # an injected forest has arbitrary planes: no sample rows, the per-plane hash serves it
+    ix2 = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix2.append(X)
+    ix2.set_forest(f.arrays())
+    ix2.set_hash_mode("scores")
+    ix2.set_dense_levels(100)
+    i2, k2, c2 = ix2.search_batch(Q, k, za.L2Distance())
+    assert ix2.stats()["hash_from_scores"] == 0
+    assert (c2 == counts).all() and (i2 == ids).all() and (k2 == keys).all()
+    ix.close()
+    ix2.close()

@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("ms_hash", C.c_double), ("ms_walk", C.c_double), ("ms_sweep", C.c_double),
                 ("ms_select", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
                 ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64), ("swept_rows_accum", C.c_uint64), ("sweep_launches_accum", C.c_uint64),
-                ("window_batches", C.c_uint64), ("table_scan", C.c_uint64), ("scan_batches_accum", C.c_uint64)]
+                ("window_batches", C.c_uint64), ("table_scan", C.c_uint64), ("scan_batches_accum", C.c_uint64),
+                ("hash_from_scores", C.c_uint64), ("hash_exact_fixups", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -115,6 +116,7 @@ SYMBOLS = [
     ("zh_stats_reset", _i, [_vp]),
     ("zh_set_dense_levels", _i, [_vp, _i]),
     ("zh_set_sweep_mode", _i, [_vp, _i]),
+    ("zh_set_hash_mode", _i, [_vp, _i]),
     ("zh_last_error", C.c_char_p, []),
     ("zh_version", C.c_char_p, []),
 ]

@@ -90,7 +90,7 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wLogPool, wLogHead, wLogCtl;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wFixList, wLogPool, wLogHead, wLogCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -108,9 +108,10 @@ struct zh_search_ctx {
     hipStream_t s = nullptr;
     ZhTotals tot{};
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
+    bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit,
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wFixList,
                         &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
@@ -160,6 +161,13 @@ struct zh_index {
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
     int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model, 1 leaf-major, 2 table scan
+    int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
+    // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
+    // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
+    DevBuf plane_samples;
+    bool samples_valid = false;
+    DevBuf row_hn2, row_norm;  // |r|^2 / 2 and |r| of the stored rows, for the first norm_rows rows
+    uint64_t norm_rows = 0;
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
     std::mutex stats_mu;
@@ -265,6 +273,7 @@ static void free_forest(zh_index *ix) {
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false;
+    ix->plane_samples.release(); ix->samples_valid = false;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
     ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
@@ -614,6 +623,14 @@ static int grow_segments(zh_index *ix, uint32_t *d_perm, uint64_t perm_len, std:
         if ((rc = dChunkScan.ensure((size_t)(nc + 1) * 4))) return rc;
         if ((rc = dScanTmp.ensure(((size_t)nc / 1024 + 4) * 4))) return rc;
         if ((rc = dNodeAbove.ensure((size_t)na * 4))) return rc;
+        {   // the planes' sample rows, for the row-score hash
+            std::vector<uint2> hs(na);
+            for (uint32_t i = 0; i < na; i++)
+                hs[i] = make_uint2(hn[i].sample_a == ~0ull ? 0xFFFFFFFFu : (uint32_t)hn[i].sample_a,
+                                   hn[i].sample_b == ~0ull ? 0xFFFFFFFFu : (uint32_t)hn[i].sample_b);
+            if ((rc = ix->plane_samples.ensure((size_t)(n_planes + na) * sizeof(uint2), true, s))) return rc;
+            HIPCHK(hipMemcpy(ix->plane_samples.as<uint2>() + n_planes, hs.data(), na * sizeof(uint2), hipMemcpyHostToDevice));
+        }
         hipError_t e = hipMemcpyAsync(dNodes.p, hn.data(), na * sizeof(ZhBuildNode), hipMemcpyHostToDevice, s);
         if (e == hipSuccess && nc) e = hipMemcpyAsync(dChunks.p, hc.data(), nc * sizeof(ZhBuildChunk), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemsetAsync(dNodeAbove.p, 0, (size_t)na * 4, s);
@@ -687,6 +704,7 @@ static int build_forest_locked(zh_index *ix) {
         if ((rc = ix->planes.ensure(4 * (size_t)ix->opt.dim)) || (rc = ix->consts.ensure(4))) { perm.release(); free_forest(ix); return rc; }
     }
     ix->n_planes = n_planes;
+    ix->samples_valid = true;  // every plane of this forest was made from two stored rows, recorded in plane_samples
     ix->leaf_ids = perm;  // perm is the concatenation of all leaves
     perm.p = nullptr; perm.cap = 0;
     ix->n_leaf_ids = total;
@@ -1009,6 +1027,12 @@ extern "C" int zh_set_dense_levels(zh_index *ix, int levels) {
     ix->dense_levels = levels;
     return ZH_OK;
 }
+extern "C" int zh_set_hash_mode(zh_index *ix, int mode) {
+    if (!ix) return fail(ZH_EINVAL, "null index");
+    if (mode < 0 || mode > 2) return fail(ZH_EINVAL, "hash mode %d (0 = choose per batch, 1 = one dot product per plane, 2 = row scores)", mode);
+    ix->hash_mode = mode;
+    return ZH_OK;
+}
 extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
     if (!ix) return fail(ZH_EINVAL, "null index");
     if (mode < 0 || mode > 2) return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan)", mode);
@@ -1200,6 +1224,52 @@ static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     return top;
 }
 
+// All signs of the batch from N row scores per query instead of P dot products (zh_score.hip)?  Only for forests whose planes
+// are known differences of stored rows, when every plane is hashed anyway, and when the score table fits.
+static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense) {
+    static const int forced = [] { const char *e = getenv("ZH_HASH_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
+    const int mode = ix->hash_mode ? ix->hash_mode : forced;
+    if (mode == 1 || !ix->samples_valid || ix->n_planes == 0 || P_dense < ix->n_planes) return false;
+    if (B % 4 || (uint64_t)ix->n_rows * B * 4 > (4ull << 30) || ix->n_rows > 0xFFFFFFF0ull) return false;
+    if (mode == 2) return true;
+    return (uint64_t)ix->n_planes >= 2 * ix->n_rows && 2.0 * (double)B * ix->n_planes * ix->opt.dim > 2e10;
+}
+
+static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStream_t s) {
+    zh_index *ix = c->ix;
+    const uint32_t d = ix->opt.dim;
+    int rc;
+    if (ix->norm_rows != ix->n_rows) {  // rows were added since the norms were taken
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if (ix->norm_rows != ix->n_rows) {
+            if ((rc = ix->row_hn2.ensure(ix->n_rows * 4)) || (rc = ix->row_norm.ensure(ix->n_rows * 4))) return rc;
+            HIPCHK(zh_launch_row_norms(ix->X.as<float>(), ix->n_rows, d, ix->row_hn2.as<float>(), ix->row_norm.as<float>(), ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            ix->norm_rows = ix->n_rows;
+        }
+    }
+    const uint32_t wq = (uint32_t)((B + 63) / 64 * 2);  // sign words per ROW of the score GEMM's (unused) bit output
+    const uint64_t cap64 = (uint64_t)B * ix->n_planes / 64 + (1u << 16);  // ~1.6 % of the signs: 4x the share seen on ~N(0,1) rows
+    const uint32_t fix_cap = (uint32_t)std::min<uint64_t>(cap64, 0x7FFFFFFFull);
+    if ((rc = c->wScore.ensure((size_t)ix->n_rows * B * 4))) return rc;
+    if ((rc = c->wJunkBits.ensure((size_t)ix->n_rows * wq * 4))) return rc;
+    if ((rc = c->wQnorm.ensure(B * 4))) return rc;
+    if ((rc = c->wFixList.ensure((size_t)fix_cap * sizeof(uint2)))) return rc;
+    if (c->wZeros.cap < B * 4) {
+        if ((rc = c->wZeros.ensure(B * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c->wZeros.p, 0, c->wZeros.cap, s));
+    }
+    // S[row][q] = row . query: the MFMA hash kernel with the roles swapped (stored rows as "queries", the batch as B "planes")
+    HIPCHK(zh_launch_hash_dense(ix->X.as<float>(), (uint32_t)ix->n_rows, dQ, c->wZeros.as<float>(), (uint32_t)B, d, c->wJunkBits.as<uint32_t>(), wq,
+                                c->wScore.as<float>(), s));
+    HIPCHK(zh_launch_row_norms(dQ, B, d, nullptr, c->wQnorm.as<float>(), s));
+    ZhTotals *tot = c->wTotals.as<ZhTotals>();
+    HIPCHK(zh_launch_score_signs(c->wScore.as<float>(), (uint32_t)B, ix->plane_samples.as<uint2>(), ix->n_planes, ix->row_hn2.as<float>(),
+                                 ix->row_norm.as<float>(), c->wQnorm.as<float>(), dQ, d, ix->planes.as<float>(), ix->consts.as<float>(),
+                                 c->wBits.as<uint32_t>(), c->wpq, c->wFixList.as<uint2>(), fix_cap, &tot->hash_fixups, s));
+    return ZH_OK;
+}
+
 int ctx_wait(zh_search_ctx *c);
 
 static ZhWalkLog walk_log(const zh_search_ctx *c) {
@@ -1267,7 +1337,10 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     ZhForestDev f = forest_dev(ix);
     HIPCHK(hipEventRecord(c->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));
-    if (c->P_dense)
+    c->score_hash = use_score_hash(ix, B, c->P_dense);
+    if (c->score_hash) {
+        if ((rc = launch_score_hash(c, dQ, B, s))) return rc;
+    } else if (c->P_dense)
         HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, c->P_dense, d, c->wBits.as<uint32_t>(), c->wpq, nullptr, s));
     HIPCHK(hipEventRecord(c->ev[1], s));
     static const bool no_blocks = getenv("ZH_WALK_NO_BLOCKS") != nullptr;  // A/B: the pointer walk for all-dense signs too
@@ -1444,6 +1517,8 @@ int ctx_wait(zh_search_ctx *c) {
     st.sweep_bytes = c->scan ? ix->n_rows * ((uint64_t)4 * ix->opt.dim + 8 * ix->n_trees) + tot.rows * 8
                              : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
     st.table_scan = c->scan ? 1 : 0;
+    st.hash_from_scores = c->score_hash ? 1 : 0;
+    st.hash_exact_fixups = c->score_hash ? tot.hash_fixups : 0;
     if (ix->profiling >= 2) st.rows_unique = uniq;
     if (ix->profiling > 0) {
         st.ms_hash += ms[0]; st.ms_walk += ms[1]; st.ms_sweep += ms[2]; st.ms_select += ms[3]; st.ms_final += ms[4];

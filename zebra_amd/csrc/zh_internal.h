@@ -41,6 +41,7 @@ struct ZhPairCounts {
 struct ZhTotals {
     uint64_t visits, rows, takes, flags;  // flags bit 0: the visit log overflowed (the emit walk must run)
     uint64_t groups, group_rows;  // filled by the leaf scan
+    unsigned long long hash_fixups;  // signs the row-score hash (zh_score.hip) recomputed exactly
 };
 
 // Visit log of the walk's (single) pass: a pair's visits beyond the ZH_INLINE_VISITS inline ones are appended as
@@ -197,6 +198,16 @@ hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *d
 #define ZH_DISTANCE_SCRATCH_BYTES (sizeof(ZhGroup) + 16)
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
                                    uint64_t *dKeys, void *dScratch, hipStream_t s);
+
+// ---- launchers (zh_score.hip): every sign of a forest built from stored rows, from N row scores per query --------
+hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *dHalfN2 /* may be null */, float *dNorm, hipStream_t s);
+// dS: scores [n_rows][B] (row . query, from zh_launch_hash_dense with the roles swapped); dSamples: the two sample rows of every
+// plane (UINT32_MAX = a default zero vector); writes the sign words of all P planes for the B queries (B % 4 == 0), the signs
+// inside the rounding bound recomputed exactly (list of fix_cap entries; *dFixCount must be 0 on entry and receives their number)
+hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
+                                 const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
+                                 uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
+                                 hipStream_t s);
 
 // ---- launchers (zh_build.hip) ----------------------------------------------------------------
 struct ZhBuildNode {   // an active (to be split) node of the current level

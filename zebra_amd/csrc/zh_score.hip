@@ -1,0 +1,186 @@
+// zh_score.hip -- the hash of a whole small-leaf forest from ROW SCORES instead of one dot product per plane.
+//
+// With the reference's default options (max_node_size 5, lsh.rs:131-138) the walk wanders over thousands of leaves per
+// (query, tree) pair and every sign of the forest is precomputed per batch (zh_api.hip, choose_dense_planes): 2 B P d flop for
+// P ~ 0.44 N T planes (6.5M planes for 1M rows and 15 trees).  But a plane is built from two STORED rows a, b
+// (build_hyperplane, lsh.rs:192-225: w = b - a, p = (a + b) / 2, c = -w.p), so in exact arithmetic
+//     w.x + c = (b.x - |b|^2 / 2) - (a.x - |a|^2 / 2) = s_b(x) - s_a(x),     s_r(x) = r.x - |r|^2 / 2,
+// and the signs of ALL planes follow from the N row scores of a query: 2 B N d flop, P / N ~ 6.5x fewer.
+//
+// Point_is_above (lsh.rs:39-43) is a rounded f32 computation, and results must be bit-identical to it.  So the score
+// difference only DECIDES a sign when it is further from zero than a rigorous bound on everything that separates it from the
+// reference's value (derivation below); the few signs inside the bound are recomputed exactly with the reference's own
+// arithmetic -- the k-ascending fma chain of zh_plane_above -- by the fix-up kernel.
+//
+// Bound.  u = 2^-24, gamma = d u.  The reference computes w_k = fl(b_k - a_k), p_k = fl(fl(a_k + b_k) / 2),
+// c = -chain(w_k p_k), dot = chain(w_k x_k), and tests f64(dot) + f64(c) >= 0.  With T = sum w_k x_k - sum w_k p_k in exact
+// arithmetic on those f32 values: |(dot + c) - T| <= gamma (sum|w_k x_k| + sum|w_k p_k|) <= gamma (|w||x| + |w||p|).
+// w_k = (b_k - a_k)(1 + d1), p_k = (a_k + b_k)/2 (1 + d2), |d1|, |d2| <= u, so
+//     T = s_b - s_a + e,  |e| <= u |b - a||x| + (2u + u^2)(|a|^2 + |b|^2)/2 .
+// The scores themselves are computed in f32: |fl(r.x) - r.x| <= gamma |r||x|, the stored |r|^2/2 within gamma |r|^2/2, and the
+// three subtractions add u times their magnitudes.  With A = |a| + |b| (so |w| <= A(1+u), |p| <= A/2 (1+u)) every term is
+// covered: gamma (2 A|x| + A^2) from the four chains (reference dot and constant, the two score dots, the two stored |r|^2/2)
+// plus u (4 A|x| + 2.5 A^2) from the roundings of w, p and the three subtractions, i.e. (d + 2.5)(1 + 1e-4) u (2 A|x| + A^2).
+// The kernel tests against (d + 8) u (2 A|x| + A^2) * 1.001 (the norms are themselves rounded, relative error ~ d u / 2) -- at
+// d = 384 on ~N(0,1) rows about 0.2 % of the signs fall inside and take the exact path.
+#include "zh_internal.h"
+
+// |r|^2 / 2 and |r| of n rows (one wave per row; any summation order: the bound above covers it)
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
+                                                         float *__restrict__ half_n2, float *__restrict__ norm) {
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float *row = X + r * d;
+    float s = 0.f;
+    for (uint32_t k = lane; k < d; k += 64) s = __builtin_fmaf(row[k], row[k], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (half_n2) half_n2[r] = 0.5f * s;
+        norm[r] = sqrtf(s);
+    }
+}
+hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *dHalfN2, float *dNorm, hipStream_t s) {
+    if (!n) return hipSuccess;
+    for (uint64_t r0 = 0; r0 < n; r0 += (1ull << 24)) {  // block-indexed launches stay far below 2^32 threads
+        const uint64_t nr = n - r0 < (1ull << 24) ? n - r0 : (1ull << 24);
+        hipLaunchKernelGGL(row_norms_kernel, dim3((uint32_t)((nr + 3) / 4)), dim3(256), 0, s, dX + r0 * d, nr, d,
+                           dHalfN2 ? dHalfN2 + r0 : nullptr, dNorm + r0);
+    }
+    return hipGetLastError();
+}
+
+// signs of 32 consecutive planes (one output word) for every query, from the score table S[row][B]: a wave per word, lane l
+// takes queries 4l .. 4l+3 of each 256-query chunk (one float4 of both sample rows' score rows per plane).  Signs inside the
+// bound are flagged in `unc` (same layout as `bits`) and appended to the fix-up list, one atomic per wave and chunk.
+__global__ __launch_bounds__(256) void score_signs_kernel(const float *__restrict__ S, uint32_t B, const uint2 *__restrict__ samples,
+                                                           uint32_t P, const float *__restrict__ hn2,
+                                                           const float *__restrict__ rnorm, const float *__restrict__ qnorm,
+                                                           float K, uint32_t *__restrict__ bits, uint32_t wpq,
+                                                           uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                           unsigned long long *__restrict__ fix_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t W = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t p0 = W * 32;
+    if (p0 >= P) return;
+    const uint32_t np = P - p0 < 32 ? P - p0 : 32;
+    for (uint32_t q0 = 0; q0 < B; q0 += 256) {
+        const uint32_t q = q0 + 4 * lane;
+        const bool in = q < B;  // B % 4 == 0: a lane's four queries are in or out together
+        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) xn = *reinterpret_cast<const float4 *>(qnorm + q);
+        uint32_t sw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < np; j++) {
+            const uint2 ab = samples[p0 + j];  // wave-uniform
+            if (ab.x == 0xFFFFFFFFu || ab.y == 0xFFFFFFFFu) {  // a default (zero) sample vector, lsh.rs:203-220: exact path
+#pragma unroll
+                for (int c = 0; c < 4; c++) uw[c] |= 1u << j;
+                continue;
+            }
+            const float A = rnorm[ab.x] + rnorm[ab.y], ha = hn2[ab.x], hb = hn2[ab.y];
+            float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+            if (in) {
+                sa = *reinterpret_cast<const float4 *>(S + (size_t)ab.x * B + q);
+                sb = *reinterpret_cast<const float4 *>(S + (size_t)ab.y * B + q);
+            }
+            const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float diff = (bv[c] - hb) - (av[c] - ha);
+                const float E = K * (2.0f * A * xv[c] + A * A);
+                sw[c] |= (diff >= 0.0f ? 1u : 0u) << j;
+                uw[c] |= (fabsf(diff) > E ? 0u : 1u) << j;  // NaN / inf anywhere -> not certain
+            }
+        }
+        // the fix-up list: one atomic per wave and chunk
+        uint32_t mine = in ? __popc(uw[0]) + __popc(uw[1]) + __popc(uw[2]) + __popc(uw[3]) : 0;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        unsigned long long base = 0;
+        if (total) {
+            if (lane == 63) base = atomicAdd(fix_count, (unsigned long long)total);
+            base = __shfl(base, 63);
+        }
+        if (in) {
+            unsigned long long pos = base + incl - mine;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                bits[(size_t)(q + c) * wpq + W] = sw[c];
+                uint32_t u = uw[c];
+                while (u) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(u);
+                    u &= u - 1;
+                    if (pos < fix_cap) fix_list[pos] = make_uint2(q + c, p0 + j);
+                    pos++;
+                }
+            }
+        }
+    }
+}
+
+// the exact value of every listed sign: the reference's own arithmetic (zh_plane_above: k-ascending fma chain, f64 test)
+__global__ __launch_bounds__(256) void score_fixup_kernel(const float *__restrict__ Q, uint32_t d, const float *__restrict__ planes,
+                                                           const float *__restrict__ consts, uint32_t *__restrict__ bits,
+                                                           uint32_t wpq, const uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                           const unsigned long long *__restrict__ fix_count) {
+    const unsigned long long n = *fix_count < fix_cap ? *fix_count : fix_cap;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint2 e = fix_list[i];
+        const bool above = zh_plane_above(planes + (size_t)e.y * d, consts[e.y], Q + (size_t)e.x * d, d);
+        uint32_t *w = bits + (size_t)e.x * wpq + (e.y >> 5);
+        if (above) atomicOr(w, 1u << (e.y & 31)); else atomicAnd(w, ~(1u << (e.y & 31)));
+    }
+}
+// more uncertain signs than the list holds (never seen; the list is sized for 4x the expected share): the same decision is
+// re-derived for every sign and the uncertain ones are recomputed in place, a thread per output word
+__global__ __launch_bounds__(256) void score_overflow_kernel(const float *__restrict__ S, uint32_t B, const uint2 *__restrict__ samples,
+                                                              uint32_t P, const float *__restrict__ hn2, const float *__restrict__ rnorm,
+                                                              const float *__restrict__ qnorm, float K, const float *__restrict__ Q,
+                                                              uint32_t d, const float *__restrict__ planes, const float *__restrict__ consts,
+                                                              uint32_t *__restrict__ bits, uint32_t wpq, uint32_t fix_cap,
+                                                              const unsigned long long *__restrict__ fix_count) {
+    if (*fix_count <= fix_cap) return;
+    const uint32_t words = (P + 31) / 32;
+    const unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned long long)B * words) return;
+    const uint32_t q = (uint32_t)(idx / words), W = (uint32_t)(idx % words), p0 = W * 32;
+    uint32_t word = bits[(size_t)q * wpq + W];
+    for (uint32_t j = 0; j < 32 && p0 + j < P; j++) {
+        const uint2 ab = samples[p0 + j];
+        bool certain = false;
+        if (ab.x != 0xFFFFFFFFu && ab.y != 0xFFFFFFFFu) {
+            const float A = rnorm[ab.x] + rnorm[ab.y];
+            const float diff = (S[(size_t)ab.y * B + q] - hn2[ab.y]) - (S[(size_t)ab.x * B + q] - hn2[ab.x]);
+            certain = fabsf(diff) > K * (2.0f * A * qnorm[q] + A * A);
+        }
+        if (!certain) {
+            const bool above = zh_plane_above(planes + (size_t)(p0 + j) * d, consts[p0 + j], Q + (size_t)q * d, d);
+            word = above ? word | (1u << j) : word & ~(1u << j);
+        }
+    }
+    bits[(size_t)q * wpq + W] = word;
+}
+
+float zh_score_bound_factor(uint32_t d) { return (float)(d + 8) * 5.9604645e-8f * 1.001f; }
+
+hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
+                                 const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
+                                 uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
+                                 hipStream_t s) {
+    if (!B || !P) return hipSuccess;
+    const uint32_t words = (P + 31) / 32;
+    const float K = zh_score_bound_factor(d);
+    hipLaunchKernelGGL(score_signs_kernel, dim3((words + 3) / 4), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm, dQNorm, K,
+                       dBits, wpq, dFixList, fix_cap, dFixCount);
+    hipLaunchKernelGGL(score_fixup_kernel, dim3(4096), dim3(256), 0, s, dQ, d, dPlanes, dConsts, dBits, wpq, dFixList, fix_cap, dFixCount);
+    const unsigned long long n = (unsigned long long)B * words;
+    hipLaunchKernelGGL(score_overflow_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm,
+                       dQNorm, K, dQ, d, dPlanes, dConsts, dBits, wpq, fix_cap, dFixCount);
+    return hipGetLastError();
+}

@@ -1003,13 +1003,19 @@ __global__ __launch_bounds__(256) void leaf_alloc_kernel(ZhForestDev f, const ui
         const unsigned long long t = __shfl_up(incl, o);
         if (lane >= (uint32_t)o) incl += t;
     }
-    const unsigned long long total = __shfl(incl, 63);
-    if (!total) return;  // wave-uniform
-    unsigned long long old = 0;
-    if (lane == 63) old = atomicAdd(packed, total);
-    old = __shfl(old, 63);
+    // ... and one per BLOCK: the four waves' totals meet in LDS (same-address atomics retire ~12 ns apart)
+    __shared__ unsigned long long wtot[4], bbase;
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        bbase = total ? atomicAdd(packed, total) : 0;
+    }
+    __syncthreads();
     if (c) {
-        const unsigned long long mine = old + incl - v;
+        unsigned long long mine = bbase + incl - v;
+        for (uint32_t w2 = 0; w2 < wv; w2++) mine += wtot[w2];
         groupBase[i] = (uint32_t)(mine >> 36);
         groupRowBase[i] = mine & ((1ull << 36) - 1);
     }
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(256) void batch_init_kernel(uint32_t *__restrict__ 
                                                           ZhTotals *__restrict__ totals) {
     const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     for (uint32_t i = i0; i < n_nodes; i += stride) { leafCount[i] = 0; leafFill[i] = 0; }
-    if (i0 == 0) { logCtl->next_chunk = 0; logCtl->overflow = 0; totals->flags = 0; }
+    if (i0 == 0) { logCtl->next_chunk = 0; logCtl->overflow = 0; totals->flags = 0; totals->hash_fixups = 0; }
 }
 hipError_t zh_launch_batch_init(uint32_t *dLeafCount, uint32_t *dLeafFill, uint32_t n_nodes, ZhLogCtl *dLogCtl,
                                 ZhTotals *dTotals, hipStream_t s) {

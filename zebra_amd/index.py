@@ -280,6 +280,10 @@ class LSHIndex:
         """0 = chosen per batch (default), 1 = leaf by leaf, 2 = table scan (zh_set_sweep_mode)"""
         check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2}.get(mode, mode)))
 
+    def set_hash_mode(self, mode):
+        """0 = chosen per batch (default), 1 = one dot product per plane, 2 = from row scores (zh_set_hash_mode)"""
+        check(lib().zh_set_hash_mode(self._h, {"auto": 0, "dense": 1, "scores": 2}.get(mode, mode)))
+
     def stats(self, reset=False):
         s = _ffi.Stats()
         check(lib().zh_stats(self._h, C.byref(s)))
