@@ -96,6 +96,7 @@ def test_fuzz_medium_wandering_walks(seed):
     for dense in (-1, int(rng.choice([0, 2, 5]))):
         ix.set_dense_levels(dense)
         ix.set_sweep_mode("scan" if dense == -1 else "leaf")
+        ix.set_hash_mode("scores" if dense == -1 else "dense")  # (row scores whenever the batch hashes every plane and b % 4 == 0)
         m, om, omode = [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
                         (za.ManhattanDistance(), zo.MANHATTAN, 0)][int(rng.integers(0, 3))]
         ids, keys, counts = ix.search_batch(Q, k, m)

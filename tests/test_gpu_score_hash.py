@@ -75,3 +75,29 @@ def test_score_hash_follows_inserts_and_is_refused_for_injected_forests(za):
     assert (c2 == counts).all() and (i2 == ids).all() and (k2 == keys).all()
     ix.close()
     ix2.close()
+
+
+def test_score_hash_on_adversarial_rows(za):
+    """duplicates (w = 0: every point is 'above', the score difference is exactly 0), huge and tiny magnitudes, rows that
+    differ in one element: whatever the bound cannot decide goes to the exact path, so results equal the per-plane hash"""
+    rng = np.random.default_rng(5)
+    n, d, M, T, k, B = 9000, 128, 4, 4, 10, 16
+    X = zo.synth_rows(n, d)
+    X[1000:1400] = X[0]                                   # 400 copies of one row
+    X[2000:2200] *= np.float32(1e18)                      # |r|^2 overflows f32: inf norms -> nothing is "certain"
+    X[3000:3200] *= np.float32(1e-30)                     # subnormal squares
+    X[4000:4300] = X[4000] + (rng.random((300, d)) < 0.01).astype(np.float32) * np.float32(1e-3)  # near-duplicates
+    Q = np.concatenate([zo.synth_queries(B - 4, d, n), X[[0, 2000, 3000, 4000]]])
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_dense_levels(100)
+    f = zo.Forest.from_arrays(X, M, ix.get_forest())
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+    for mode in ("scores", "dense"):
+        ix.set_hash_mode(mode)
+        ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+        assert ix.stats()["hash_from_scores"] == (1 if mode == "scores" else 0)
+        assert (counts == oc).all(), mode
+        for b in range(B):
+            assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all(), (mode, b)
+    ix.close()
