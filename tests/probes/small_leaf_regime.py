@@ -21,8 +21,8 @@ print("build s", round(time.perf_counter() - t0, 2), "planes", ix.get_forest()["
 m = za.CosineDistance(parity=True) if COS else za.L2SquaredDistance()
 if os.environ.get("DENSE_LEVELS"):
     ix.set_dense_levels(int(os.environ["DENSE_LEVELS"]))
-ix.search_batch(Q, k, m)  # first batch: learns the visits per pair (on-demand hash + emit walk)
-ix.search_batch(Q, k, m)  # second batch: every sign precomputed from now on; builds the blocked view of the forest (host, once per forest)
+for _ in range(5):  # the first batch learns the visits per pair (on-demand hash + emit walk); once the forest has served a few
+    ix.search_batch(Q, k, m)  # batches unchanged the library builds its derived views (blocked forest, row -> leaf table: host time, once)
 ix.set_profiling(1)
 ix.stats(reset=True)
 t0 = time.perf_counter()

@@ -3,6 +3,7 @@
 // zh_search.hip / zh_build.hip.  There is no CPU compute path in this file: every entry point
 // that produces distances, signs or neighbours launches gfx950 kernels.
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -152,6 +153,10 @@ struct zh_index {
     // row -> (leaf, position) per tree for the table-scan sweep (zh_launch_row_leaf): built on first use, dropped with the trees
     DevBuf row_leaf;
     bool row_leaf_valid = false, row_leaf_failed = false;
+    // Both derived views cost host time per build (a traversal of every node: ~0.35 s for the 13M nodes of a 1M-row forest at the
+    // default leaf size), so a forest that changes between searches (insert, search, insert, ...) keeps the pointer walk / the
+    // leaf-major sweep: the views are built once the forest has served a few batches unchanged.
+    std::atomic<uint32_t> batches_since_change{0};
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
@@ -416,6 +421,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
     ix->row_leaf_valid = false; ix->row_leaf_failed = false;
+    ix->batches_since_change = 0;
     ix->max_leaf_len = 0;
     for (size_t i = 0; i < nn; i++)
         if (ix->h_plane[i] < 0) ix->max_leaf_len = std::max(ix->max_leaf_len, (uint32_t)ix->h_right[i]);
@@ -1184,6 +1190,7 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
     const int mode = ix->sweep_mode ? ix->sweep_mode : forced;
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed) return false;
     if (mode == 2) return true;
+    if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
     const double row_b = 4.0 * d;
     const double t_leaf = (double)tot.group_rows * row_b / (d >= 256 ? 6.0e12 : 5.5e12);
     const double q_bytes = (double)B * row_b;
@@ -1300,7 +1307,8 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     const uint64_t pairs = (uint64_t)B * T;
     if (pairs >= (1ull << 26)) { c->state = 0; return fail(ZH_ELIMIT, "batch * num_trees >= 2^26"); }
     c->P_dense = choose_dense_planes(ix, B, k);
-    if (c->P_dense >= ix->n_planes && ix->n_planes && !ix->blocks_valid) {  // first all-dense batch since the trees changed
+    const uint32_t seen = ix->batches_since_change.fetch_add(1);
+    if (c->P_dense >= ix->n_planes && ix->n_planes && !ix->blocks_valid && seen >= 2) {  // the forest has been stable for a few batches
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if (!ix->blocks_valid && (rc = build_blocks(ix))) { c->state = 0; return rc; }
     }
