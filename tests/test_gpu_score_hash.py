@@ -101,3 +101,30 @@ def test_score_hash_on_adversarial_rows(za):
         for b in range(B):
             assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all(), (mode, b)
     ix.close()
+
+
+@pytest.mark.parametrize("n,d,M,T,B,kind,scale", [
+    (60000, 384, 5, 8, 64, 0, 1.0),     # ~210k planes x 64 queries = 13M signs
+    (40000, 768, 4, 6, 32, 0, 1.0),
+    (50000, 128, 5, 8, 64, 1, 1.0),     # integer rows: exact zeros of w.x + c
+    (50000, 64, 3, 8, 128, 2, 1.0),     # clustered rows
+    (30000, 256, 5, 6, 64, 0, 1e-3),    # small magnitudes
+    (30000, 256, 5, 6, 64, 0, 3e4),     # large magnitudes
+])
+def test_whole_sign_matrix_equals_the_per_plane_hash(za, n, d, M, T, B, kind, scale):
+    """every sign of every plane for every query, row-score path vs one dot product per plane (zh_hash_signs honours
+    zh_set_hash_mode): identical bit for bit -- this is the check of the rounding bound at scale, visited or not"""
+    X = (zo.synth_rows(n, d, kind=kind) * np.float32(scale)).astype(np.float32)
+    Q = (zo.synth_queries(B, d, n, kind=kind) * np.float32(scale)).astype(np.float32)
+    Q[:4] = X[[0, 1, n // 2, n - 1]]  # queries that ARE stored rows: sample points of many planes
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_hash_mode("dense")
+    bits_dense = ix.hash_signs(Q)
+    ix.set_hash_mode("scores")
+    bits_score = ix.hash_signs(Q)
+    st = ix.stats()
+    assert st["hash_from_scores"] == 1 and 0 < st["hash_exact_fixups"] < 0.25 * bits_dense.size, st["hash_exact_fixups"]
+    assert bits_dense.shape == bits_score.shape and bits_dense.size > 0
+    assert (bits_dense == bits_score).all(), int((bits_dense != bits_score).sum())
+    ix.close()

@@ -1698,7 +1698,8 @@ extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *o
     const uint32_t wpq = (P + 63) / 64 * 2, words = (P + 31) / 32;
     DevBuf dq, dbits, ddots;
     struct G { DevBuf *a, *b, *c; ~G() { a->release(); b->release(); c->release(); } } g{&dq, &dbits, &ddots};
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(b, (size_t)(256u << 20) / ((size_t)P * 4 + 1)));
+    size_t chunk = std::max<size_t>(1, std::min<size_t>(b, (size_t)(256u << 20) / ((size_t)P * 4 + 1)));
+    if (chunk >= 4) chunk &= ~(size_t)3;  // (the row-score path takes queries four at a time)
     if ((rc = dq.ensure(chunk * d * 4))) return rc;
     if ((rc = dbits.ensure(chunk * wpq * 4))) return rc;
     if (out_dots && (rc = ddots.ensure(chunk * P * 4))) return rc;
@@ -1706,9 +1707,27 @@ extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *o
     for (size_t b0 = 0; b0 < b; b0 += chunk) {
         size_t nb = std::min(chunk, b - b0);
         HIPCHK(hipMemcpyAsync(dq.p, q + b0 * d, nb * d * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(zh_launch_hash_dense(dq.as<float>(), (uint32_t)nb, ix->planes.as<float>(), ix->consts.as<float>(), P, d,
-                                    dbits.as<uint32_t>(), wpq, out_dots ? ddots.as<float>() : nullptr, s));
-        HIPCHK(hipMemcpyAsync(hb.data(), dbits.p, nb * wpq * 4, hipMemcpyDeviceToHost, s));
+        // zh_set_hash_mode(2): the signs (not the dots) through the row-score path where the forest allows -- the whole sign matrix of
+        // both paths can then be compared bit for bit (tests/test_gpu_score_hash.py)
+        if (!out_dots && ix->hash_mode == 2 && use_score_hash(ix, nb, P)) {
+            zh_search_ctx *c = &ix->dctx;
+            if (c->state == 2 && (rc = ctx_wait(c))) return rc;
+            c->wpq = wpq;
+            if ((rc = c->wTotals.ensure(sizeof(ZhTotals))) || (rc = c->wBits.ensure(nb * wpq * 4))) return rc;
+            HIPCHK(hipMemsetAsync(c->wTotals.p, 0, sizeof(ZhTotals), s));
+            if ((rc = launch_score_hash(c, dq.as<float>(), nb, s))) return rc;
+            HIPCHK(hipMemcpyAsync(hb.data(), c->wBits.p, nb * wpq * 4, hipMemcpyDeviceToHost, s));
+            ZhTotals ht;
+            HIPCHK(hipMemcpyAsync(&ht, c->wTotals.p, sizeof ht, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            std::lock_guard<std::mutex> lks(ix->stats_mu);
+            ix->stats.hash_from_scores = 1;
+            ix->stats.hash_exact_fixups = ht.hash_fixups;
+        } else {
+            HIPCHK(zh_launch_hash_dense(dq.as<float>(), (uint32_t)nb, ix->planes.as<float>(), ix->consts.as<float>(), P, d,
+                                        dbits.as<uint32_t>(), wpq, out_dots ? ddots.as<float>() : nullptr, s));
+            HIPCHK(hipMemcpyAsync(hb.data(), dbits.p, nb * wpq * 4, hipMemcpyDeviceToHost, s));
+        }
         if (out_dots) HIPCHK(hipMemcpyAsync(out_dots + b0 * P, ddots.p, nb * P * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         for (size_t i = 0; i < nb; i++) {
