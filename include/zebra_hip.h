@@ -194,7 +194,8 @@ ZH_API int zh_index_read_rows(zh_index *idx, uint64_t first, size_t n, float *ou
 
 /* point_is_above for every plane of the forest (numbered as zh_index_get_forest returns them) and
  * every query: out_bits is b x ceil(n_planes/32) words, bit p%32 of word p/32 = above.
- * out_dots (may be NULL) is b x n_planes raw f32 dot products.  q is b x dim host memory. */
+ * out_dots (may be NULL) is b x n_planes raw f32 dot products.  q is b x dim host memory.  With zh_set_hash_mode(2) and
+ * out_dots == NULL the signs are taken through the row-score path where the forest allows (b % 4 == 0): same bits. */
 ZH_API int zh_hash_signs(zh_index *idx, const float *q, size_t b, uint32_t *out_bits, float *out_dots);
 
 /* LSHIndex::search for a batch: q is b x dim; out_ids/out_keys are b x k (entries past
