@@ -1454,9 +1454,9 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (c->scan) {
         const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
         if ((rc = c->wVisitBits.ensure((nn + 31) / 32 * 4))) return rc;
-        if ((rc = c->wNodeVisit.ensure(nn * sizeof(uint2)))) return rc;
-        HIPCHK(zh_launch_node_visits(c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(), ix->n_nodes, c->wVisitBits.as<uint32_t>(),
-                                     c->wNodeVisit.as<uint2>(), s));
+        if ((rc = c->wNodeVisit.ensure(nn * sizeof(uint4)))) return rc;
+        HIPCHK(zh_launch_node_visits(c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(), c->wGroups.as<ZhGroup>(), ix->n_nodes,
+                                     c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), s));
     }
     if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
@@ -1468,7 +1468,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
     if (c->scan)
         HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
-                                    c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint2>(), c->wGroups.as<ZhGroup>(), f.group,
+                                    c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group,
                                     c->metric, c->mode, c->wKeys.as<uint64_t>(), hs));
     else
         HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),

@@ -174,11 +174,12 @@ bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric);
 uint32_t zh_scan_rows_per_wave(uint32_t T);
 hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, uint32_t n_nodes, const uint32_t *dLeafIds,
                               uint32_t T, uint64_t n_rows, uint2 *dRowLeaf, hipStream_t s);
-// per batch: bit n of dBits = leaf node n is visited; dNodeVisit[n] = {visits, first group} of the visited leaves
-hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGroupBase, uint32_t n_nodes, uint32_t *dBits,
-                                 uint2 *dNodeVisit, hipStream_t s);
+// per batch (after the groups are filled): bit n of dBits = leaf node n is visited; dNodeVisit[n] = {visits, first group, query and
+// key slice of the first visit} of the visited leaves
+hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGroupBase, const ZhGroup *dGroups, uint32_t n_nodes,
+                                 uint32_t *dBits, uint4 *dNodeVisit, hipStream_t s);
 hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
-                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint4 *dNodeVisit,
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);

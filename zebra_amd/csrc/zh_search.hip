@@ -1588,24 +1588,31 @@ hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, 
 
 // Per batch, for the table scan: bit n of `bits` = leaf node n is visited by the batch (a 16-KB bitmap for the 130k nodes of
 // cfg3: it stays in L1, and two thirds of a row's T entries are answered by it without an L2 request), and the visited
-// leaves' {visits, first group} side by side (one 8-byte load instead of two 4-byte ones in different arrays).
+// leaves' {visits, first group, first visit's query and key slice} in ONE 16-byte record: a leaf with a single visit -- most of
+// them -- needs no look-up in the group array.
 __global__ __launch_bounds__(256) void node_visit_kernel(const uint32_t *__restrict__ leafCount, const uint32_t *__restrict__ groupBase,
-                                                          uint32_t n_nodes, uint32_t *__restrict__ bits, uint2 *__restrict__ nodeVisit) {
+                                                          const ZhGroup *__restrict__ groups, uint32_t n_nodes,
+                                                          uint32_t *__restrict__ bits, uint4 *__restrict__ nodeVisit) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // one 32-node word per thread
     const uint32_t n0 = w * 32;
     if (n0 >= n_nodes) return;
     uint32_t word = 0;
     for (uint32_t i = 0; i < 32 && n0 + i < n_nodes; i++) {
         const uint32_t c = leafCount[n0 + i];
-        if (c) { word |= 1u << i; nodeVisit[n0 + i] = make_uint2(c, groupBase[n0 + i]); }
+        if (c) {  // {visits | bits 32..35 of the first visit's key slice << 28, first group, first visit's query, its key slice (low 32)}
+            word |= 1u << i;
+            const uint32_t gb = groupBase[n0 + i];
+            const uint64_t k0 = groups[gb].key_off[0];
+            nodeVisit[n0 + i] = make_uint4(c | ((uint32_t)(k0 >> 32) << 28), gb, groups[gb].b[0], (uint32_t)k0);
+        }
     }
     bits[w] = word;
 }
-hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGroupBase, uint32_t n_nodes, uint32_t *dBits,
-                                 uint2 *dNodeVisit, hipStream_t s) {
+hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGroupBase, const ZhGroup *dGroups, uint32_t n_nodes,
+                                 uint32_t *dBits, uint4 *dNodeVisit, hipStream_t s) {
     const uint32_t words = (n_nodes + 31) / 32;
     if (!words) return hipSuccess;
-    hipLaunchKernelGGL(node_visit_kernel, dim3((words + 255) / 256), dim3(256), 0, s, dLeafCount, dGroupBase, n_nodes, dBits, dNodeVisit);
+    hipLaunchKernelGGL(node_visit_kernel, dim3((words + 255) / 256), dim3(256), 0, s, dLeafCount, dGroupBase, dGroups, n_nodes, dBits, dNodeVisit);
     return hipGetLastError();
 }
 
@@ -1654,7 +1661,7 @@ template <int D, int KIND>
 __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
                                                           const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
                                                           uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
-                                                          const uint2 *__restrict__ nodeVisit,
+                                                          const uint4 *__restrict__ nodeVisit,
                                                           const ZhGroup *__restrict__ groups, uint32_t GRP, uint64_t row_begin,
                                                           uint64_t row_end, int metric, int param,
                                                           uint64_t *__restrict__ keys) {
@@ -1670,19 +1677,21 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
     const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
     // ---- phase 1: the wave's nr * T (row, tree) entries, lane-parallel: visits of the entry's leaf -> pairs; the pairs of
     // the whole wave go to an LDS list in (row, tree, visit) order ----
-    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
+    uint64_t eK0[ZH_SCAN_NE];
     uint32_t P = 0;
 #pragma unroll
     for (int j = 0; j < ZH_SCAN_NE; j++) {
         const uint32_t e = lane + 64u * j;
-        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0;
+        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0; eB0[j] = 0; eK0[j] = 0;
         if (e < n_ent) {
             const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));  // streamed once
             const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
             eWithin[j] = rl.y;
             if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
-                const uint2 nv = nodeVisit[rl.x];
-                eC[j] = nv.x; eGb[j] = nv.y;
+                const uint4 nv = nodeVisit[rl.x];
+                eC[j] = nv.x & 0x0FFFFFFFu; eGb[j] = nv.y; eB0[j] = nv.z;
+                eK0[j] = ((uint64_t)(nv.x >> 28) << 32) | nv.w;
             }
         }
         uint32_t incl = eC[j];  // inclusive scan over the lanes
@@ -1732,7 +1741,11 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
             if (c) {
                 const uint32_t rl = (lane + 64u * j) / T, gb = eGb[j];
                 mrows |= 1u << rl;
-                for (uint32_t sidx = 0; sidx < c; sidx++) {
+                {   // the first visit comes with the node's record; further visits of a hot leaf from the group array
+                    const uint64_t slot = eK0[j] + eWithin[j];
+                    list[off[j]] = make_uint4(rl, eB0[j], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+                for (uint32_t sidx = 1; sidx < c; sidx++) {
                     const ZhGroup *g = groups + gb + sidx / GRP;
                     const uint64_t slot = g->key_off[sidx % GRP] + eWithin[j];
                     list[off[j] + sidx] = make_uint4(rl, g->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
@@ -1829,7 +1842,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void scan128_sweep_kernel(const float *__restrict__ X, const float *__restrict__ Q,
                                                              const float *__restrict__ QQ, const uint2 *__restrict__ rowLeaf,
                                                              uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
-                                                             const uint2 *__restrict__ nodeVisit,
+                                                             const uint4 *__restrict__ nodeVisit,
                                                              const ZhGroup *__restrict__ groups, uint32_t GRP, uint64_t row_begin,
                                                              uint64_t row_end, int metric, int param,
                                                              uint64_t *__restrict__ keys) {
@@ -1848,19 +1861,21 @@ __global__ __launch_bounds__(256) void scan128_sweep_kernel(const float *__restr
     const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
     const float4 *__restrict__ Q4 = reinterpret_cast<const float4 *>(Q);
     // ---- phase 1 (as scan_sweep_kernel): entries -> pairs, plus where every row's pairs start in the list ----
-    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE];
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
+    uint64_t eK0[ZH_SCAN_NE];
     uint32_t P = 0;
 #pragma unroll
     for (int j = 0; j < ZH_SCAN_NE; j++) {
         const uint32_t e = lane + 64u * j;
-        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0;
+        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0; eB0[j] = 0; eK0[j] = 0;
         if (e < n_ent) {
             const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));
             const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
             eWithin[j] = rl.y;
             if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
-                const uint2 nv = nodeVisit[rl.x];
-                eC[j] = nv.x; eGb[j] = nv.y;
+                const uint4 nv = nodeVisit[rl.x];
+                eC[j] = nv.x & 0x0FFFFFFFu; eGb[j] = nv.y; eB0[j] = nv.z;
+                eK0[j] = ((uint64_t)(nv.x >> 28) << 32) | nv.w;
             }
         }
         uint32_t incl = eC[j];
@@ -1885,7 +1900,11 @@ __global__ __launch_bounds__(256) void scan128_sweep_kernel(const float *__restr
             if (e < n_ent && e % T == 0) rstart[e / T] = off[j];  // the first entry of a row: its pairs start here
             if (c) {
                 const uint32_t rl = e / T, gb = eGb[j];
-                for (uint32_t sidx = 0; sidx < c; sidx++) {
+                {   // the first visit comes with the node's record; further visits of a hot leaf from the group array
+                    const uint64_t slot = eK0[j] + eWithin[j];
+                    list[off[j]] = make_uint4(rl, eB0[j], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+                for (uint32_t sidx = 1; sidx < c; sidx++) {
                     const ZhGroup *g = groups + gb + sidx / GRP;
                     const uint64_t slot = g->key_off[sidx % GRP] + eWithin[j];
                     list[off[j] + sidx] = make_uint4(rl, g->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
@@ -2015,7 +2034,7 @@ bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric) {
 
 template <int D, int KIND>
 static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *dQ, const float *dQQ, const uint2 *dRowLeaf,
-                                 uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit, const ZhGroup *dGroups,
+                                 uint32_t T, const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups,
                                  uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
     const uint32_t RW = zh_scan_rows_per_wave(T);
     uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
@@ -2039,7 +2058,7 @@ static hipError_t launch_scan_dk(const float *dX, uint64_t n_rows, const float *
 }
 template <int KIND>
 static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
-                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint4 *dNodeVisit,
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
 #define ZH_SCAN_CASE(DD) \
     case DD: return launch_scan_dk<DD, KIND>(dX, n_rows, dQ, dQQ, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, param, dKeys, s)
@@ -2056,7 +2075,7 @@ static hipError_t launch_scan_k(const float *dX, uint32_t d, uint64_t n_rows, co
 #undef ZH_SCAN_CASE
 }
 hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
-                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint2 *dNodeVisit,
+                                const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint4 *dNodeVisit,
                                 const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s) {
     if (!n_rows) return hipSuccess;
 #define ZH_KIND_CASE(K) \
