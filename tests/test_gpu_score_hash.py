@@ -21,6 +21,8 @@ def za():
     (8000, 768, 8, 3, 40, 8, 0),
     (15000, 128, 5, 5, 10, 24, 1),    # integer-valued rows: many exact ties (w.x + c == 0) -> the exact path decides
     (6000, 100, 4, 3, 5, 12, 0),      # d not a multiple of 4: the score GEMM's scalar staging
+    (12000, 384, 5, 4, 10, 7, 0),     # a batch that is not a multiple of four: padded with zero queries
+    (12000, 64, 5, 4, 10, 1, 0),      # a single query
 ])
 def test_score_hash_equals_oracle_and_dense_hash(za, n, d, M, T, k, B, kind):
     X = zo.synth_rows(n, d, kind=kind)
@@ -110,6 +112,7 @@ def test_score_hash_on_adversarial_rows(za):
     (50000, 64, 3, 8, 128, 2, 1.0),     # clustered rows
     (30000, 256, 5, 6, 64, 0, 1e-3),    # small magnitudes
     (30000, 256, 5, 6, 64, 0, 3e4),     # large magnitudes
+    (30000, 384, 5, 6, 13, 0, 1.0),     # odd batch
 ])
 def test_whole_sign_matrix_equals_the_per_plane_hash(za, n, d, M, T, B, kind, scale):
     """every sign of every plane for every query, row-score path vs one dot product per plane (zh_hash_signs honours

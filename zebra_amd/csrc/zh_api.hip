@@ -91,7 +91,7 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wFixList, wLogPool, wLogHead, wLogCtl;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -112,7 +112,7 @@ struct zh_search_ctx {
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     void release_all() {
         DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wFixList,
+                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
                         &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
         for (DevBuf *b : ws) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
@@ -1237,9 +1237,16 @@ static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense) {
     static const int forced = [] { const char *e = getenv("ZH_HASH_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
     const int mode = ix->hash_mode ? ix->hash_mode : forced;
     if (mode == 1 || !ix->samples_valid || ix->n_planes == 0 || P_dense < ix->n_planes) return false;
-    if (B % 4 || (uint64_t)ix->n_rows * B * 4 > (4ull << 30) || ix->n_rows > 0xFFFFFFF0ull) return false;
+    const size_t Bp = (B + 3) & ~(size_t)3;  // (the kernels take queries four at a time: the batch is padded with zero queries)
+    if ((uint64_t)ix->n_rows * Bp * 4 > (4ull << 30) || ix->n_rows > 0xFFFFFFF0ull) return false;
     if (mode == 2) return true;
-    return (uint64_t)ix->n_planes >= 2 * ix->n_rows && 2.0 * (double)B * ix->n_planes * ix->opt.dim > 2e10;
+    // per-plane hash: MFMA-bound for real batches, a plane-streaming GEMV for a handful of queries; row scores: the same two
+    // bounds over the ROWS, + the gather of two score rows per plane (>= one 64-byte sector each) + the exact fix-ups
+    const double d = ix->opt.dim, P = ix->n_planes, N = ix->n_rows;
+    const double t_dense = std::max(2.0 * B * P * d / 9e13, P * d * 4.0 / 5e12);
+    const double t_score = std::max(2.0 * Bp * N * d / 9e13, N * d * 4.0 / 5e12) + P * 2.0 * std::max(64.0, Bp * 4.0) / 4e12 +
+                           0.003 * B * P * 0.55e-9 + 30e-6;
+    return t_score < 0.7 * t_dense;
 }
 
 static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStream_t s) {
@@ -1254,6 +1261,14 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
             HIPCHK(hipStreamSynchronize(ix->stream));
             ix->norm_rows = ix->n_rows;
         }
+    }
+    if (B % 4) {  // pad the batch with zero queries to a multiple of four (their signs are computed and never read)
+        const size_t Bp = (B + 3) & ~(size_t)3;
+        if ((rc = c->wQpad.ensure(Bp * d * 4)) || (rc = c->wBits.ensure(Bp * c->wpq * 4))) return rc;
+        HIPCHK(hipMemcpyAsync(c->wQpad.p, dQ, B * d * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemsetAsync(c->wQpad.as<float>() + B * d, 0, (Bp - B) * d * 4, s));
+        dQ = c->wQpad.as<float>();
+        B = Bp;
     }
     const uint32_t wq = (uint32_t)((B + 63) / 64 * 2);  // sign words per ROW of the score GEMM's (unused) bit output
     const uint64_t cap64 = (uint64_t)B * ix->n_planes / 64 + (1u << 16);  // ~1.6 % of the signs: 4x the share seen on ~N(0,1) rows
