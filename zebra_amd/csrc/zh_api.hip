@@ -1281,9 +1281,13 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
         if ((rc = c->wZeros.ensure(B * 4))) return rc;
         HIPCHK(hipMemsetAsync(c->wZeros.p, 0, c->wZeros.cap, s));
     }
-    // S[row][q] = row . query: the MFMA hash kernel with the roles swapped (stored rows as "queries", the batch as B "planes")
-    HIPCHK(zh_launch_hash_dense(ix->X.as<float>(), (uint32_t)ix->n_rows, dQ, c->wZeros.as<float>(), (uint32_t)B, d, c->wJunkBits.as<uint32_t>(), wq,
-                                c->wScore.as<float>(), s));
+    // S[row][q] = row . query: the MFMA hash kernel with the roles swapped (stored rows as "queries", the batch as B "planes");
+    // a batch of <= 4 queries: one stream over the stored rows
+    if (B == 4)
+        HIPCHK(zh_launch_row_scores4(ix->X.as<float>(), ix->n_rows, d, dQ, c->wScore.as<float>(), s));
+    else
+        HIPCHK(zh_launch_hash_dense(ix->X.as<float>(), (uint32_t)ix->n_rows, dQ, c->wZeros.as<float>(), (uint32_t)B, d, c->wJunkBits.as<uint32_t>(), wq,
+                                    c->wScore.as<float>(), s));
     HIPCHK(zh_launch_row_norms(dQ, B, d, nullptr, c->wQnorm.as<float>(), s));
     ZhTotals *tot = c->wTotals.as<ZhTotals>();
     HIPCHK(zh_launch_score_signs(c->wScore.as<float>(), (uint32_t)B, ix->plane_samples.as<uint2>(), ix->n_planes, ix->row_hn2.as<float>(),

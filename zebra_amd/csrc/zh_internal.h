@@ -202,6 +202,8 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
 
 // ---- launchers (zh_score.hip): every sign of a forest built from stored rows, from N row scores per query --------
 hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *dHalfN2 /* may be null */, float *dNorm, hipStream_t s);
+// the score table of exactly four queries (dQ4: 4 x d): dS[row][0..3]
+hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const float *dQ4, float *dS, hipStream_t s);
 // dS: scores [n_rows][B] (row . query, from zh_launch_hash_dense with the roles swapped); dSamples: the two sample rows of every
 // plane (UINT32_MAX = a default zero vector); writes the sign words of all P planes for the B queries (B % 4 == 0), the signs
 // inside the rounding bound recomputed exactly (list of fix_cap entries; *dFixCount must be 0 on entry and receives their number)

@@ -51,6 +51,37 @@ hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *d
     return hipGetLastError();
 }
 
+// S[row][0..3] = row . q_j for a batch of at most four queries: a wave per row, the queries in registers -- the table of a small batch
+// is a stream over the stored rows (HBM-bound), not a GEMM with 124 idle plane columns.  Any summation order: the bound covers it.
+__global__ __launch_bounds__(256) void row_scores4_kernel(const float *__restrict__ X, uint64_t n, uint32_t d, const float *__restrict__ Q,
+                                                           float *__restrict__ S) {
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float *row = X + r * d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (uint32_t k = lane; k < d; k += 64) {
+        const float x = row[k];
+        s0 = __builtin_fmaf(x, Q[k], s0);
+        s1 = __builtin_fmaf(x, Q[d + k], s1);
+        s2 = __builtin_fmaf(x, Q[2 * (size_t)d + k], s2);
+        s3 = __builtin_fmaf(x, Q[3 * (size_t)d + k], s3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o);
+    }
+    if (lane == 0) *reinterpret_cast<float4 *>(S + r * 4) = make_float4(s0, s1, s2, s3);
+}
+hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const float *dQ4, float *dS, hipStream_t s) {
+    if (!n) return hipSuccess;
+    for (uint64_t r0 = 0; r0 < n; r0 += (1ull << 24)) {
+        const uint64_t nr = n - r0 < (1ull << 24) ? n - r0 : (1ull << 24);
+        hipLaunchKernelGGL(row_scores4_kernel, dim3((uint32_t)((nr + 3) / 4)), dim3(256), 0, s, dX + r0 * d, nr, d, dQ4, dS + r0 * 4);
+    }
+    return hipGetLastError();
+}
+
 // signs of 32 consecutive planes (one output word) for every query, from the score table S[row][B]: a wave per word, lane l
 // takes queries 4l .. 4l+3 of each 256-query chunk (one float4 of both sample rows' score rows per plane).  Signs inside the
 // bound are flagged in `unc` (same layout as `bits`) and appended to the fix-up list, one atomic per wave and chunk.
@@ -124,6 +155,61 @@ __global__ __launch_bounds__(256) void score_signs_kernel(const float *__restric
     }
 }
 
+// the same for a batch of exactly four queries (a padded single query, a handful of queries): a LANE per plane -- with a lane per
+// query group 63 of 64 lanes would idle and every plane would be a dependent-load chain of its own
+__global__ __launch_bounds__(256) void score_signs4_kernel(const float *__restrict__ S, const uint2 *__restrict__ samples, uint32_t P,
+                                                            const float *__restrict__ hn2, const float *__restrict__ rnorm,
+                                                            const float *__restrict__ qnorm, float K, uint32_t *__restrict__ bits,
+                                                            uint32_t wpq, uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                            unsigned long long *__restrict__ fix_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;  // this wave's 64 planes = two output words per query
+    if (p0 >= P) return;
+    const uint32_t p = p0 + lane;
+    bool sg[4] = {false, false, false, false}, un[4] = {false, false, false, false};
+    if (p < P) {
+        const uint2 ab = samples[p];
+        if (ab.x == 0xFFFFFFFFu || ab.y == 0xFFFFFFFFu) {
+            un[0] = un[1] = un[2] = un[3] = true;
+        } else {
+            const float A = rnorm[ab.x] + rnorm[ab.y], ha = hn2[ab.x], hb = hn2[ab.y];
+            const float4 sa = *reinterpret_cast<const float4 *>(S + (size_t)ab.x * 4), sb = *reinterpret_cast<const float4 *>(S + (size_t)ab.y * 4);
+            const float4 xn = *reinterpret_cast<const float4 *>(qnorm);
+            const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float diff = (bv[c] - hb) - (av[c] - ha);
+                sg[c] = diff >= 0.0f;
+                un[c] = !(fabsf(diff) > K * (2.0f * A * xv[c] + A * A));
+            }
+        }
+    }
+    const uint32_t mine = (un[0] ? 1u : 0u) + (un[1] ? 1u : 0u) + (un[2] ? 1u : 0u) + (un[3] ? 1u : 0u);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (total) {
+        if (lane == 63) base = atomicAdd(fix_count, (unsigned long long)total);
+        base = __shfl(base, 63);
+    }
+    unsigned long long pos = base + incl - mine;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long m = __ballot(sg[c]);
+        if (lane == 0) bits[(size_t)c * wpq + (p0 >> 5)] = (uint32_t)m;
+        if (lane == 32 && p0 + 32 < P) bits[(size_t)c * wpq + (p0 >> 5) + 1] = (uint32_t)(m >> 32);
+        if (un[c]) {
+            if (pos < fix_cap) fix_list[pos] = make_uint2((uint32_t)c, p);
+            pos++;
+        }
+    }
+}
+
 // the exact value of every listed sign: the reference's own arithmetic (zh_plane_above: k-ascending fma chain, f64 test)
 __global__ __launch_bounds__(256) void score_fixup_kernel(const float *__restrict__ Q, uint32_t d, const float *__restrict__ planes,
                                                            const float *__restrict__ consts, uint32_t *__restrict__ bits,
@@ -176,8 +262,12 @@ hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamp
     if (!B || !P) return hipSuccess;
     const uint32_t words = (P + 31) / 32;
     const float K = zh_score_bound_factor(d);
-    hipLaunchKernelGGL(score_signs_kernel, dim3((words + 3) / 4), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm, dQNorm, K,
-                       dBits, wpq, dFixList, fix_cap, dFixCount);
+    if (B == 4)
+        hipLaunchKernelGGL(score_signs4_kernel, dim3((P + 255) / 256), dim3(256), 0, s, dS, dSamples, P, dHalfN2, dRowNorm, dQNorm, K, dBits, wpq,
+                           dFixList, fix_cap, dFixCount);
+    else
+        hipLaunchKernelGGL(score_signs_kernel, dim3((words + 3) / 4), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm, dQNorm, K,
+                           dBits, wpq, dFixList, fix_cap, dFixCount);
     hipLaunchKernelGGL(score_fixup_kernel, dim3(4096), dim3(256), 0, s, dQ, d, dPlanes, dConsts, dBits, wpq, dFixList, fix_cap, dFixCount);
     const unsigned long long n = (unsigned long long)B * words;
     hipLaunchKernelGGL(score_overflow_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm,
