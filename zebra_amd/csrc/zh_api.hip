@@ -1181,7 +1181,7 @@ static int build_row_leaf(zh_index *ix) {
 
 // Leaf by leaf or the whole table once?  The leaf-major sweep gathers group_rows rows from HBM (5.9-6.1 TB/s of 3-KB rows,
 // 5.5 TB/s of 512-byte ones); the table scan streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and
-// fetches one query from L2 per scored (row, query) pair -- measured 0.144 + 0.000175 d ns per pair chip-wide (3.7 G pairs/s
+// fetches one query from L2 per scored (row, query) pair -- measured 0.075 + 0.00022 d ns per pair chip-wide (4.1 G pairs/s
 // at d = 768 = what the L2s deliver; 10 G pairs/s at d = 128 with the paired kernel, where the leaf-major sweep still wins at the BASELINE shapes), slower once the window's queries no
 // longer fit beside the stream in the 8 x 4 MB of L2.  zh_set_sweep_mode / ZH_SWEEP_MODE=leaf|scan force one of them.
 static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B) {
@@ -1194,7 +1194,7 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
     const double row_b = 4.0 * d;
     const double t_leaf = (double)tot.group_rows * row_b / (d >= 256 ? 6.0e12 : 5.5e12);
     const double q_bytes = (double)B * row_b;
-    const double pair_s = d == 128 ? 0.10e-9 : 0.144e-9 + 0.000175e-9 * d;  // (d = 128: the paired kernel, two pairs per step)
+    const double pair_s = d == 128 ? 0.10e-9 : 0.075e-9 + 0.00022e-9 * d;  // (d = 128: the paired kernel, two pairs per step)
     const double t_pairs = (double)tot.rows * pair_s * (q_bytes > 8e6 ? 1.25 : 1.0);
     const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 6.0e12, t_pairs) + 20e-6;
     return t_scan < 0.92 * t_leaf;
