@@ -2369,17 +2369,9 @@ hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uin
     if (max_leaf_len <= 1024)
         hipLaunchKernelGGL(select_kernel<1024>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
-    else if (max_leaf_len > ZH_SORT_N && max_leaf_len <= 8192) {
-        // leaves of 4097..8192 rows (max_node_size 8192: the 1B x 128-d configuration): 96 KB of the CU's 160 KB of LDS hold
-        // the whole leaf, so its keys cross HBM once instead of once per histogram round (8 bytes per row against the 512-byte
-        // row the sweep read: each extra pass costs the sweep beside it 1.5 % of the memory system)
-        static const bool attr = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel<8192>), hipFuncAttributeMaxDynamicSharedMemorySize, 0) == hipSuccess;
-        }();
-        (void)attr;
-        hipLaunchKernelGGL(select_kernel<8192>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
-                           dLeafIds, dKeys, dCandKeys, dCandIds);
-    } else
+    else  // (leaves longer than ZH_SORT_N re-read their keys from the L2-resident scratch per histogram round; a variant that held
+          // leaves of up to 8192 rows in 96 KB of LDS -- one block per CU -- measured slower alone, 4.6 against 2.7 ms per cfg5 batch,
+          // and beside the sweep, 142 k against 150 k QPS: profiles/r02_ab_select_lds.txt)
         hipLaunchKernelGGL(select_kernel<ZH_SORT_N>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
     return hipGetLastError();
