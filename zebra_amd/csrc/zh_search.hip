@@ -2369,10 +2369,14 @@ hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uin
     if (max_leaf_len <= 1024)
         hipLaunchKernelGGL(select_kernel<1024>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
-    else  // (leaves longer than ZH_SORT_N re-read their keys from the L2-resident scratch per histogram round; a variant that held
-          // leaves of up to 8192 rows in 96 KB of LDS -- one block per CU -- measured slower alone, 4.6 against 2.7 ms per cfg5 batch,
-          // and beside the sweep, 142 k against 150 k QPS: profiles/r02_ab_select_lds.txt)
+    else if (getenv("ZH_SELECT_4096") != nullptr)  // A/B: the round-1 LDS footprint (48 KB per block)
         hipLaunchKernelGGL(select_kernel<ZH_SORT_N>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
+                           dLeafIds, dKeys, dCandKeys, dCandIds);
+    else  // Leaves longer than the LDS buffer re-read their keys from the L2-resident scratch per histogram round.  Small buffers win:
+          // 2048 entries (24 KB per block, six blocks per CU) against 4096: 0.33 / 0.46 ms alone at cfg3, 0.4 / 3.8 ms beside the sweep;
+          // a variant that held leaves of up to 8192 rows in 96 KB -- one block per CU -- 4.6 against 2.7 ms per cfg5 batch alone and
+          // 142 k against 150 k QPS beside the sweep (profiles/r02_ab_select_lds.txt)
+        hipLaunchKernelGGL(select_kernel<2048>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk,
                            dLeafIds, dKeys, dCandKeys, dCandIds);
     return hipGetLastError();
 }
