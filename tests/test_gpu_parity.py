@@ -561,6 +561,28 @@ def test_remove_and_deduplicate(za):
     assert g["leaf_ids"].size == T * (n + 200 - 6) and not ({7, 8, 2500, 1000} & set(g["leaf_ids"].tolist()))
 
 
+def test_clear_refill_remove_resamples_the_live_rows(za):
+    """the hyperplane sampler's list of live rows was cached on (stored rows, removed rows) alone; clear, a
+    refill to the same count and the removal of the same NUMBER of different rows reused the old list, so later splits drew
+    sample points from removed rows.  The forest after clear / add / remove / add must equal the oracle's."""
+    n, d, M, T = 3000, 32, 24, 5
+    X1, X2 = zo.synth_rows(n, d), zo.synth_rows(n, d, row0=10**6)
+    more = zo.synth_rows(600, d, row0=2 * 10**6)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=11)
+    ix.add(X1)
+    ix.remove(np.arange(1, 51, dtype=np.uint64))
+    ix.add(more)                       # splits sample the live rows of X1: the list is built for (3600 stored, 50 removed)
+    ix.clear()
+    ix.add(X2)
+    ix.remove(np.arange(100, 150, dtype=np.uint64))   # same number of removals, other rows
+    ix.add(more)
+    f = zo.Forest.build(X2, M, T, seed=11)
+    f.remove(np.arange(100, 150, dtype=np.uint64))
+    f.insert(np.concatenate([X2, more]), n)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d)
+    ix.close()
+
+
 def test_three_deep_pipeline_matches_blocking_calls(za):
     """30 batches, three in flight, sweeps on the index's shared stream: every batch equals the blocking call"""
     import torch

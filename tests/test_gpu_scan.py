@@ -123,3 +123,39 @@ def test_table_scan_with_rows_appended_but_not_yet_in_a_tree(za):
     c = ix.search_batch(Q, k, m)
     assert all((x == y).all() for x, y in zip(a, b)) and all((x == y).all() for x, y in zip(a, c))
     ix.close()
+
+
+def test_injected_forest_with_a_row_listed_twice_in_one_tree_is_swept_leaf_by_leaf(za):
+    """rowLeaf keeps ONE {leaf, position} per (row, tree); an injected forest that lists a row twice inside a
+    tree (legal input for zh_index_set_forest) would leave the second occurrence's key slot unwritten under the table scan.
+    The library detects it and serves such a forest leaf by leaf whatever the sweep mode says: results equal the oracle's and
+    do not depend on zh_set_sweep_mode."""
+    n, d, M, T, k, B = 6000, 128, 64, 4, 10, 32
+    X = zo.synth_rows(n, d)
+    f0 = zo.Forest.build(X, M, T)
+    arr = {k_: np.array(v, copy=True) for k_, v in f0.arrays().items()}
+    plane, left, right = arr["plane"], arr["left"], arr["right"]
+    leaves = [i for i in range(plane.size) if plane[i] < 0 and right[i] >= 4]
+    for node in leaves[:40]:  # repeat the first id of forty leaves inside the same leaf
+        off = int(np.uint32(left[node]))
+        arr["leaf_ids"][off + 1] = arr["leaf_ids"][off]
+    f = zo.Forest.from_arrays(X, M, arr)
+    Q = zo.synth_queries(B, d, n)
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X)
+    ix.set_forest(arr)
+    for mode in ("scan", "leaf", "auto"):
+        ix.set_sweep_mode(mode)
+        for _ in range(4):  # (auto builds the row -> leaf table only for a forest that has served a few batches)
+            ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+        assert ix.stats()["table_scan"] == 0, mode
+        assert (counts == oc).all(), mode
+        for b in range(B):
+            assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all(), (mode, b)
+    # the same forest without the repeats takes the scan when asked to
+    ix.set_forest(f0.arrays())
+    ix.set_sweep_mode("scan")
+    ix.search_batch(Q, k, za.L2SquaredDistance())
+    assert ix.stats()["table_scan"] == 1
+    ix.close()

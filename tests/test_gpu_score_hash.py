@@ -131,3 +131,35 @@ def test_whole_sign_matrix_equals_the_per_plane_hash(za, n, d, M, T, B, kind, sc
     assert bits_dense.shape == bits_score.shape and bits_dense.size > 0
     assert (bits_dense == bits_score).all(), int((bits_dense != bits_score).sum())
     ix.close()
+
+
+def test_clear_then_refill_to_the_same_count_recomputes_the_row_norms(za):
+    """zh_index_clear left the row-score hash's |r|^2/2 and |r| of the OLD rows behind; a refill to the same row
+    count found them 'valid' (the cache was keyed on the count alone) and derived wrong signs without any error.  The whole sign
+    matrix of the refilled index must equal the per-plane hash and the oracle's search."""
+    n, d, M, T, k, B = 20000, 256, 5, 5, 10, 32
+    X1 = zo.synth_rows(n, d)
+    X2 = (zo.synth_rows(n, d, seed=0x1234567) * np.float32(3.0)).astype(np.float32)  # same count, other rows, other norms
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.set_hash_mode("scores")
+    ix.add(X1)
+    ix.set_dense_levels(100)
+    ix.search_batch(zo.synth_queries(B, d, n), k, za.L2SquaredDistance())   # takes the norms of X1
+    assert ix.stats()["hash_from_scores"] == 1
+    ix.clear()
+    assert len(ix) == 0
+    ix.add(X2)
+    Q = (zo.synth_queries(B, d, n) * np.float32(3.0)).astype(np.float32)
+    bits_score = ix.hash_signs(Q)
+    assert ix.stats()["hash_from_scores"] == 1
+    ix.set_hash_mode("dense")
+    bits_dense = ix.hash_signs(Q)
+    assert (bits_dense == bits_score).all(), int((bits_dense != bits_score).sum())
+    ix.set_hash_mode("scores")
+    f = zo.Forest.from_arrays(X2, M, ix.get_forest())
+    ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+    assert (counts == oc).all()
+    for b in range(B):
+        assert (ids[b, :oc[b]] == oi[b, :oc[b]]).all() and (keys[b, :oc[b]] == ok[b, :oc[b]]).all(), b
+    ix.close()

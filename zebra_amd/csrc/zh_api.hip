@@ -56,8 +56,16 @@ extern "C" const char *zh_version(void) { return "zebra-hip 0.1 (gfx950)"; }
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // hipFree waits for EVERY stream of the device to drain.  A per-batch scratch buffer that outgrows its capacity while other
+    // batches are in flight would stall the host until their sweeps, selects and finals have run -- and the sweep queue runs dry
+    // meanwhile (rocprofv3 kernel trace, r03: a 1.3-2.9 ms hole in front of the next window's sweep each time).  Buffers of a
+    // search context therefore keep the outgrown allocation (geometric growth: at most twice the final size in total) until
+    // the context is released, and ask for 1/8 more than a batch needs so that batch-to-batch variation rarely grows them at all.
+    bool defer = false;
+    std::vector<void *> old;
     int ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
         if (bytes <= cap) return ZH_OK;
+        if (defer) bytes += bytes / 8;
         size_t ncap = std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~size_t(255);
         void *np = nullptr;
@@ -72,13 +80,15 @@ struct DevBuf {
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) { hipFree(np); return fail(ZH_EHIP, "grow copy: %s", hipGetErrorString(e)); }
         }
-        if (p) hipFree(p);
+        if (p) { if (defer) old.push_back(p); else hipFree(p); }
         p = np;
         cap = ncap;
         return ZH_OK;
     }
     void release() {
         if (p) hipFree(p);
+        for (void *o : old) hipFree(o);
+        old.clear();
         p = nullptr;
         cap = 0;
     }
@@ -110,11 +120,13 @@ struct zh_search_ctx {
     ZhTotals tot{};
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
+    std::vector<DevBuf *> all_bufs() {
+        return {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
+                &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
+                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
+    }
     void release_all() {
-        DevBuf *ws[] = {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
-                        &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
-                        &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
-        for (DevBuf *b : ws) b->release();
+        for (DevBuf *b : all_bufs()) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
         if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
     }
@@ -142,8 +154,13 @@ struct zh_index {
     std::vector<uint8_t> h_dead;               // rows removed by zh_index_remove (their vectors stay in X)
     uint64_t n_dead = 0;
     std::vector<uint32_t> h_live;              // ascending live rows, for hyperplane sampling once rows were removed
-    uint64_t h_live_rows = ~0ull;              // n_rows / n_dead h_live was built for
+    uint64_t h_live_rows = ~0ull;              // n_rows / n_dead / dead_gen h_live was built for
     uint64_t h_live_dead = ~0ull;
+    uint64_t h_live_gen = ~0ull;
+    // Caches derived from the stored rows are keyed on a generation as well as on a count: clear() followed by a refill to the
+    // same count must not find them valid.  rows_gen: bumped whenever the CONTENT of rows [0, n_rows) may have changed (clear);
+    // dead_gen: whenever the set of removed rows changed (remove, clear).
+    uint64_t rows_gen = 1, dead_gen = 1;
     uint32_t max_leaf_len = 0;
     // blocked view of the forest (ZhBlocksDev) for all-dense walks: built on first use, dropped whenever the trees change
     DevBuf blk_recs, blk_upper, blk_roots;
@@ -171,8 +188,9 @@ struct zh_index {
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
     DevBuf plane_samples;
     bool samples_valid = false;
-    DevBuf row_hn2, row_norm;  // |r|^2 / 2 and |r| of the stored rows, for the first norm_rows rows
-    uint64_t norm_rows = 0;
+    DevBuf row_hn2, row_norm;  // |r|^2 / 2 and |r| of the stored rows, for the first norm_rows rows of generation norm_gen
+    uint64_t norm_rows = 0, norm_gen = 0;
+    bool scan_unsafe = false;  // an injected forest lists a row twice in one tree: rowLeaf holds one slot per (row, tree) -> leaf-major only
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
     std::mutex stats_mu;
@@ -204,6 +222,7 @@ static ZhForestDev forest_dev(const zh_index *ix) {
 
 static int ctx_init(zh_search_ctx *c, zh_index *ix) {
     c->ix = ix;
+    for (DevBuf *b : c->all_bufs()) b->defer = true;  // never hipFree (a device-wide drain) between batches
     hipError_t e = hipHostMalloc((void **)&c->h_totals, sizeof(ZhTotals), hipHostMallocDefault);
     if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
@@ -277,7 +296,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
-    ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false;
+    ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     ix->plane_samples.release(); ix->samples_valid = false;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
@@ -298,6 +317,7 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (ix->sweep_stream) hipStreamSynchronize(ix->sweep_stream);
     free_forest(ix);
     ix->X.release();
+    ix->row_hn2.release(); ix->row_norm.release();
     ix->dctx.release_all();
     DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
@@ -317,6 +337,13 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->n_rows = 0;
     ix->h_dead.clear();
     ix->n_dead = 0;
+    // everything derived from the rows that were just dropped: the row norms of the row-score hash, the live-row list of
+    // the hyperplane sampler (both were keyed on counts alone: a refill to the same count found them "valid")
+    ix->rows_gen++; ix->dead_gen++;
+    ix->norm_rows = 0; ix->norm_gen = 0;
+    ix->row_hn2.release(); ix->row_norm.release();
+    ix->h_live.clear(); ix->h_live.shrink_to_fit();
+    ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
     return ZH_OK;
 }
 
@@ -442,6 +469,7 @@ extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
     std::vector<int32_t> level(nn, -1);
     std::vector<uint32_t> order;  // inner nodes in (level, tree, bfs) order
     std::vector<std::vector<uint32_t>> by_level;
+    std::vector<std::pair<uint32_t, uint32_t>> tree_leaves;  // (tree, leaf node)
     for (uint32_t t = 0; t < nt; t++) {
         if (fv->roots[t] >= nn) return fail(ZH_EINVAL, "set_forest: root %u out of range", t);
         std::vector<uint32_t> cur{fv->roots[t]}, nxt;
@@ -461,6 +489,7 @@ extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
                 } else {
                     uint64_t off = (uint32_t)fv->left[n], len = (uint32_t)fv->right[n];
                     if (fv->right[n] < 0 || off + len > fv->n_leaf_ids) return fail(ZH_EINVAL, "set_forest: leaf range out of bounds at node %u", n);
+                    tree_leaves.push_back({t, n});
                 }
             }
             cur.swap(nxt);
@@ -471,6 +500,22 @@ extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
     }
     for (uint64_t i = 0; i < fv->n_leaf_ids; i++)
         if (fv->leaf_ids[i] >= ix->n_rows) return fail(ZH_EINVAL, "set_forest: leaf id %u >= stored rows %llu", fv->leaf_ids[i], (unsigned long long)ix->n_rows);
+    // A row listed twice inside ONE tree (a repeated id, or two leaves of a tree over the same leaf_ids range) is legal input --
+    // the leaf-major sweep scores every listed occurrence -- but the table scan keeps one {leaf, position} per (row, tree): such
+    // a forest is served leaf by leaf only, whatever the cost model or zh_set_sweep_mode say, so results never depend on the sweep.
+    bool dup_in_tree = false;
+    {
+        std::vector<uint32_t> stamp(ix->n_rows, 0xFFFFFFFFu);
+        for (size_t i = 0; i < tree_leaves.size() && !dup_in_tree; i++) {
+            const uint32_t t = tree_leaves[i].first, n = tree_leaves[i].second;
+            const uint32_t off = (uint32_t)fv->left[n], len = (uint32_t)fv->right[n];
+            for (uint32_t j = 0; j < len; j++) {
+                const uint32_t r = fv->leaf_ids[(size_t)off + j];
+                if (stamp[r] == t) { dup_in_tree = true; break; }
+                stamp[r] = t;
+            }
+        }
+    }
     // renumber planes level-major
     std::vector<int32_t> new_of_old(np, -1);
     std::vector<uint32_t> old_of_new;
@@ -507,6 +552,7 @@ extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
     ix->n_planes = np_used;
     ix->n_leaf_ids = fv->n_leaf_ids;
     ix->planes_below_level = below;
+    ix->scan_unsafe = dup_in_tree;
     return upload_nodes(ix);
 }
 
@@ -556,12 +602,12 @@ static void sample_pair(uint64_t seed, uint32_t tree, uint64_t path, uint64_t n_
 // defines a plane.  Returns the live count (< 2: default zero vectors, lsh.rs:203-220).  Same mapping as the oracle's.
 static uint64_t sample_live_pair(zh_index *ix, uint32_t tree, uint64_t path, uint64_t n_sample, uint64_t *si, uint64_t *sj) {
     if (ix->n_dead == 0) { sample_pair(ix->opt.seed, tree, path, n_sample, si, sj); return n_sample; }
-    if (ix->h_live_rows != ix->n_rows || ix->h_live_dead != ix->n_dead) {
+    if (ix->h_live_rows != ix->n_rows || ix->h_live_dead != ix->n_dead || ix->h_live_gen != ix->dead_gen) {
         ix->h_live.clear();
         ix->h_live.reserve(ix->n_rows - ix->n_dead);
         for (uint64_t r = 0; r < ix->n_rows; r++)
             if (!(r < ix->h_dead.size() && ix->h_dead[r])) ix->h_live.push_back((uint32_t)r);
-        ix->h_live_rows = ix->n_rows; ix->h_live_dead = ix->n_dead;
+        ix->h_live_rows = ix->n_rows; ix->h_live_dead = ix->n_dead; ix->h_live_gen = ix->dead_gen;
     }
     const uint64_t n_live = (uint64_t)(std::lower_bound(ix->h_live.begin(), ix->h_live.end(), n_sample,
                                                         [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - ix->h_live.begin());
@@ -914,7 +960,7 @@ static int remove_rows_locked(zh_index *ix, const std::vector<uint32_t> &rows, s
         for (size_t r = 0; r < rows.size(); r++) found[r] = 1;  // vectors without trees: just forget them
     }
     for (size_t r = 0; r < rows.size(); r++)
-        if (found[r] && !ix->h_dead[rows[r]]) { ix->h_dead[rows[r]] = 1; ix->n_dead++; }
+        if (found[r] && !ix->h_dead[rows[r]]) { ix->h_dead[rows[r]] = 1; ix->n_dead++; ix->dead_gen++; }
     return ZH_OK;
 }
 
@@ -1188,7 +1234,7 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
     const int mode = ix->sweep_mode ? ix->sweep_mode : forced;
-    if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed) return false;
+    if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
     if (mode == 2) return true;
     if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
     const double row_b = 4.0 * d;
@@ -1253,13 +1299,13 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
     zh_index *ix = c->ix;
     const uint32_t d = ix->opt.dim;
     int rc;
-    if (ix->norm_rows != ix->n_rows) {  // rows were added since the norms were taken
+    if (ix->norm_rows != ix->n_rows || ix->norm_gen != ix->rows_gen) {  // rows were added (or replaced: clear) since the norms were taken
         std::lock_guard<std::mutex> lk(ix->blk_mu);
-        if (ix->norm_rows != ix->n_rows) {
+        if (ix->norm_rows != ix->n_rows || ix->norm_gen != ix->rows_gen) {
             if ((rc = ix->row_hn2.ensure(ix->n_rows * 4)) || (rc = ix->row_norm.ensure(ix->n_rows * 4))) return rc;
             HIPCHK(zh_launch_row_norms(ix->X.as<float>(), ix->n_rows, d, ix->row_hn2.as<float>(), ix->row_norm.as<float>(), ix->stream));
             HIPCHK(hipStreamSynchronize(ix->stream));
-            ix->norm_rows = ix->n_rows;
+            ix->norm_rows = ix->n_rows; ix->norm_gen = ix->rows_gen;
         }
     }
     if (B % 4) {  // pad the batch with zero queries to a multiple of four (their signs are computed and never read)

@@ -1048,24 +1048,34 @@ hipError_t zh_launch_batch_init(uint32_t *dLeafCount, uint32_t *dLeafFill, uint3
     return hipGetLastError();
 }
 
-// exclusive scans of the three per-pair counts: one block walks the pairs 1024 at a time (coalesced 16-byte loads and
-// 8-byte stores), wave scans by shuffle + one LDS hop across the 16 waves, a running total carried between chunks.
+// exclusive scans of the three per-pair counts: ONE 256-thread block walks the pairs 1024 at a time -- four consecutive pairs
+// per thread (64 contiguous bytes), a serial scan of the four in registers, wave scans by shuffle + one LDS hop across the 4
+// waves, a running total carried between chunks.  256 threads, not 1024: beside a sweep every CU is full of 256-thread sweep
+// blocks, and a work-group only starts when ALL its waves fit at once -- a 16-wave group waited 6-8 ms for four sweep blocks of
+// one CU to retire together (rocprofv3 kernel trace, r03: 0.1 ms alone, 7.7 ms beside the table scan, and the host's finish()
+// waits for exactly this kernel's totals), a 4-wave group takes the first slot any sweep block leaves.
 // Also finishes the totals: groups / group rows out of the leaf allocation's packed counter, the log's overflow flag.
-__global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__restrict__ counts, uint32_t n,
-                                                          uint64_t *__restrict__ rowBase,
-                                                          uint64_t *__restrict__ candBase,
-                                                          uint64_t *__restrict__ visitBase,
-                                                          ZhTotals *__restrict__ totals,
-                                                          const ZhLogCtl *__restrict__ logCtl) {
-    __shared__ uint64_t wr[16], wc[16], wv[16];
+__global__ __launch_bounds__(256) void pair_scan_kernel(const ZhPairCounts *__restrict__ counts, uint32_t n,
+                                                         uint64_t *__restrict__ rowBase,
+                                                         uint64_t *__restrict__ candBase,
+                                                         uint64_t *__restrict__ visitBase,
+                                                         ZhTotals *__restrict__ totals,
+                                                         const ZhLogCtl *__restrict__ logCtl) {
+    __shared__ uint64_t wr[4], wc[4], wv[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint64_t run_r = 0, run_c = 0, run_v = 0;
     for (uint32_t base = 0; base < n; base += 1024) {  // block-uniform
-        const uint32_t i = base + tid;
-        ZhPairCounts pc;
-        pc.visits = 0; pc.rows = 0; pc.takes = 0; pc.pad = 0;
-        if (i < n) pc = counts[i];
-        uint64_t r = pc.rows, c = pc.takes, v = pc.visits;  // inclusive scans inside the wave
+        const uint32_t i0 = base + 4 * tid;
+        ZhPairCounts pc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            pc[j].visits = 0; pc[j].rows = 0; pc[j].takes = 0; pc[j].pad = 0;
+            if (i0 + j < n) pc[j] = counts[i0 + j];
+        }
+        uint64_t r = 0, c = 0, v = 0;  // the thread's four pairs, then inclusive scans of the thread totals inside the wave
+#pragma unroll
+        for (int j = 0; j < 4; j++) { r += pc[j].rows; c += pc[j].takes; v += pc[j].visits; }
+        const uint64_t tr4 = r, tc4 = c, tv4 = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint64_t a = __shfl_up(r, o), b2 = __shfl_up(c, o), d2 = __shfl_up(v, o);
@@ -1075,15 +1085,16 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__r
         __syncthreads();
         uint64_t pr = 0, pcn = 0, pv = 0, tr = 0, tc = 0, tv = 0;  // totals of the waves before mine / of the chunk
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) {
+        for (uint32_t j = 0; j < 4; j++) {
             const uint64_t a = wr[j], b2 = wc[j], d2 = wv[j];
             if (j < w) { pr += a; pcn += b2; pv += d2; }
             tr += a; tc += b2; tv += d2;
         }
-        if (i < n) {
-            rowBase[i] = run_r + pr + r - pc.rows;
-            candBase[i] = run_c + pcn + c - pc.takes;
-            visitBase[i] = run_v + pv + v - pc.visits;
+        uint64_t er = run_r + pr + r - tr4, ec = run_c + pcn + c - tc4, evv = run_v + pv + v - tv4;  // exclusive, at the thread's first pair
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < n) { rowBase[i0 + j] = er; candBase[i0 + j] = ec; visitBase[i0 + j] = evv; }
+            er += pc[j].rows; ec += pc[j].takes; evv += pc[j].visits;
         }
         run_r += tr; run_c += tc; run_v += tv;
         __syncthreads();
@@ -1101,7 +1112,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const ZhPairCounts *__r
 hipError_t zh_launch_pair_scan(const ZhPairCounts *dCounts, uint32_t n_pairs, uint64_t *dRowBase,
                                uint64_t *dCandBase, uint64_t *dVisitBase, ZhTotals *dTotals, const ZhLogCtl *dLogCtl,
                                hipStream_t s) {
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, dCounts, n_pairs, dRowBase, dCandBase, dVisitBase,
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(256), 0, s, dCounts, n_pairs, dRowBase, dCandBase, dVisitBase,
                        dTotals, dLogCtl);
     return hipGetLastError();
 }

@@ -2,14 +2,32 @@
 // communicator; one search over the sharded index = local search -> ONE in-place ncclAllGather of the packed
 // [ids | keys | counts] result -> merge kernel on every rank (what replaces the query loop of
 // /root/reference/src/database/core.rs:299-303 when the stored rows are sharded, README.md:31).
-// Built on the public entry points of zebra_hip.h only (zh_search_begin / finish / wait, zh_merge_topk_packed_device),
-// so the single-GPU pipeline is exactly the one the parity tests exercise.  Host code; no kernels here.
+// The local search goes through the public entry points of zebra_hip.h (zh_search_begin / finish / wait), so the single-GPU
+// pipeline is exactly the one the parity tests exercise.  Host code; no kernels here.
+//
+// FAILING TOGETHER.  A collective cannot swallow a per-rank error the way core.rs:303 swallows a per-query one: a rank that
+// returned before the all-gather would leave its peers inside it for ever.  So a rank whose local search fails (ZH_ELIMIT: its
+// shard passed 2^28 visits; ZH_ENOMEM: its scratch) STILL joins the exchange, with an empty slot (every count 0) and its code
+// in a STATUS WORD that travels with the packed result (slot = zh_packed_result_words(b, k) + 1 words,
+// zh_shard_exchange_words).  After the all-gather every rank holds every status: zh_shard_search_wait returns the rank's own
+// code, or ZH_EPEER when only other ranks failed -- the same verdict everywhere, nobody hangs, the communicator stays usable.
+// The blocking entry points use the same words to split an over-long batch IDENTICALLY on every rank: if every failure of a
+// chunk is ZH_ELIMIT, all ranks halve the chunk and repeat it (they all see the same words); the first chunk size comes from the
+// largest visits-per-query any rank has reported so far (the word's upper half).  What a status word cannot cover -- a rank
+// that dies, or cannot even allocate its gather buffer -- is bounded by a timeout in zh_shard_search_wait
+// (ZH_SHARD_TIMEOUT_MS, default 300000): the waiting rank aborts its communicator (ncclCommAbort), returns ZH_EPEER, and the
+// group is dead (every later call fails fast, zh_shard_group_destroy aborts instead of ncclCommDestroy, which would block).
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "zh_internal.h"
@@ -37,6 +55,8 @@ struct zh_shard_group {
     zh_shard_ctx *dctx = nullptr;  // the blocking entry points run on this context
     void *dQ = nullptr, *dOut = nullptr;  // staging of the host-pointer variant
     size_t capQ = 0, capOut = 0;
+    std::atomic<bool> dead{false};        // a collective may be outstanding for ever (timeout, RCCL async error, a rank that could not join)
+    std::atomic<uint32_t> peer_vpq{0};    // largest leaf-visits-per-query any rank has reported (status words): sizes the blocking calls' chunks
 };
 
 struct zh_shard_ctx {
@@ -52,7 +72,58 @@ struct zh_shard_ctx {
     size_t cap_merged = 0;
     bool xused = false;
     int state = 0;  // 0 idle, 1 begun, 2 finished
+    // status words (pinned host memory): [0, n_ranks) every rank's word as gathered, [n_ranks] this rank's outgoing word
+    uint64_t *h_status = nullptr;
+    int begin_rc = 0;        // a failed local begin: finish still joins the exchange, with this code
+    int verdict = 0;         // of the last waited batch: ZH_OK, this rank's own code, or ZH_EPEER
+    bool all_elimit = false; // ... and every failing rank said ZH_ELIMIT (the blocking calls retry with a smaller chunk)
 };
+
+// ---- status words: pure host arithmetic (callable without a GPU; tests/test_sharding_gloo.py carries them over gloo) ----
+extern "C" size_t zh_shard_exchange_words(size_t b, size_t k) { return zh_packed_result_words(b, k) + 1; }
+extern "C" uint64_t zh_shard_status_word(int code, uint32_t visits_per_query) {
+    return (uint64_t)(uint32_t)(int32_t)code | ((uint64_t)visits_per_query << 32);
+}
+extern "C" int zh_shard_verdict(const uint64_t *status_words, uint32_t n_ranks, uint32_t rank, uint32_t *out_first_failed_rank,
+                                uint32_t *out_max_visits_per_query, int *out_all_elimit) {
+    if (!status_words || rank >= n_ranks) return FAIL(ZH_EINVAL, "zh_shard_verdict: bad argument");
+    int own = (int)(int32_t)(uint32_t)status_words[rank], first_code = 0;
+    uint32_t first = n_ranks, vmax = 0;
+    bool all_el = true;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        const int code = (int)(int32_t)(uint32_t)status_words[r];
+        vmax = std::max(vmax, (uint32_t)(status_words[r] >> 32));
+        if (code != ZH_OK) {
+            if (first == n_ranks) { first = r; first_code = code; }
+            if (code != ZH_ELIMIT) all_el = false;
+        }
+    }
+    if (out_first_failed_rank) *out_first_failed_rank = first;
+    if (out_max_visits_per_query) *out_max_visits_per_query = vmax;
+    if (out_all_elimit) *out_all_elimit = (first != n_ranks && all_el) ? 1 : 0;
+    if (first == n_ranks) return ZH_OK;
+    if (own != ZH_OK) return FAIL(own, "this rank's (%u) local search of the sharded batch failed with status %d; every rank of the group was told", rank, own);
+    return FAIL(ZH_EPEER, "rank %u of the shard group failed its local search with status %d: the batch's results are not valid on any rank", first, first_code);
+}
+
+// test hook (like ZH_WALK_LOG_FIXED): ZH_SHARD_INJECT="code[,count[,skip]]" makes `count` (default 1) local searches of this
+// process fail with `code` after letting `skip` (default 0) pass; read on every call, counted from the value's first appearance
+static int injected_failure() {
+    static std::string last;
+    static int seen = 0;
+    const char *e = getenv("ZH_SHARD_INJECT");
+    if (!e || !*e) { last.clear(); seen = 0; return 0; }
+    if (last != e) { last = e; seen = 0; }
+    int code = 0, count = 1, skip = 0;
+    if (sscanf(e, "%d,%d,%d", &code, &count, &skip) < 1) return 0;
+    const int i = seen++;
+    return (i >= skip && i < skip + count) ? code : 0;
+}
+
+static void kill_group(zh_shard_group *g) {  // a collective of this communicator may never complete: abort it (frees the queued work)
+    bool was = g->dead.exchange(true);
+    if (!was && g->comm) { ncclCommAbort(g->comm); g->comm = nullptr; }
+}
 
 static int set_dev(const zh_shard_group *g) {
     hipError_t e = hipSetDevice(g->device);
@@ -94,17 +165,17 @@ extern "C" void zh_shard_group_destroy(zh_shard_group *g) {
     zh_shard_ctx_destroy(g->dctx);
     if (g->dQ) hipFree(g->dQ);
     if (g->dOut) hipFree(g->dOut);
-    if (g->comm) ncclCommDestroy(g->comm);
+    if (g->comm) ncclCommDestroy(g->comm);  // (a dead group's communicator was aborted -- and nulled -- by kill_group: destroy would block)
     delete g;
 }
 
 extern "C" uint32_t zh_shard_group_ranks(const zh_shard_group *g) {
-    if (!g) return 0;
+    if (!g || !g->comm) return 0;
     int n = 0;
     return ncclCommCount(g->comm, &n) == ncclSuccess ? (uint32_t)n : 0;
 }
 extern "C" uint32_t zh_shard_group_rank(const zh_shard_group *g) {
-    if (!g) return 0;
+    if (!g || !g->comm) return g ? g->rank : 0;
     int r = 0;
     return ncclCommUserRank(g->comm, &r) == ncclSuccess ? (uint32_t)r : 0;
 }
@@ -124,7 +195,9 @@ extern "C" int zh_shard_ctx_create(zh_shard_group *g, zh_shard_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_final, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_xdone, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_status, ((size_t)g->n_ranks + 1) * 8, hipHostMallocDefault);
     if (e != hipSuccess) return bail(FAIL(ZH_EHIP, "shard context streams / events: %s", hipGetErrorString(e)));
+    memset(c->h_status, 0, ((size_t)g->n_ranks + 1) * 8);
     *out = c;
     return ZH_OK;
 }
@@ -137,6 +210,7 @@ extern "C" void zh_shard_ctx_destroy(zh_shard_ctx *c) {
     zh_search_ctx_destroy(c->sc);
     if (c->gathered) hipFree(c->gathered);
     if (c->merged) hipFree(c->merged);
+    if (c->h_status) hipHostFree(c->h_status);
     if (c->ev_final) hipEventDestroy(c->ev_final);
     if (c->ev_xdone) hipEventDestroy(c->ev_xdone);
     if (c->xs) hipStreamDestroy(c->xs);
@@ -146,7 +220,7 @@ extern "C" void zh_shard_ctx_destroy(zh_shard_ctx *c) {
 
 extern "C" void *zh_shard_ctx_stream(const zh_shard_ctx *c) { return c ? (void *)c->xs : nullptr; }
 extern "C" const uint64_t *zh_shard_ctx_local_result(const zh_shard_ctx *c) {
-    return (c && c->gathered) ? c->gathered + (size_t)c->g->rank * c->W : nullptr;
+    return (c && c->gathered) ? c->gathered + (size_t)c->g->rank * (c->W + 1) : nullptr;
 }
 
 static int shard_begin(zh_shard_ctx *c, const float *const *d_q, size_t nwin, size_t b, size_t k, int metric, int mode) {
