@@ -43,6 +43,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md "Indexed rows: gather into LDS", row "2,048 rows shared by every workgroup (the XCD's L2)": 66-73 GB/s per
+# CU = 16.8-18.8 TB/s chip-wide for whole rows gathered from L2 -- the operand path that binds the table scan (one query per
+# (row, query) pair from L2).  The upper end is the peak, so that frac never flatters.
+L2_GATHER_PEAK_GBS = 18800.0
+L2_GATHER_RANGE_GBS = [16800.0, 18800.0]
 SEED_ROWS, SEED_Q, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
 
 WORKLOADS = {
@@ -101,6 +106,12 @@ def parse():
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority stream (N = 1)")
     ap.add_argument("--pmc-summary", default=None, help="profiles/*_pmc_hbm_bytes.json to take roofline.traffic from")
+    ap.add_argument("--serial-windows", action="store_true",
+                    help="profiling: the pipelined calls and the same --window, but ONE window on the GPU at a time (drained before the next "
+                         "begins): kernels do not overlap, so per-kernel PMC counters are the kernel's own, at the timed run's window size")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="profiling: nothing but full windows of the bench workload (warm-up rounded up to whole windows, no R_unique "
+                         "pass, no host-buffer leg, no recall): every launch of the sweep kernel in the process is comparable")
     return ap.parse_args()
 
 
@@ -203,6 +214,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         uid = env.unique_id() if real else za.shard_unique_id()
         group = za.ShardGroup(ix, uid, env.world if real else 1, env.rank if real else 0)
 
+    pipelined = not args.no_pipeline
+    NS = max(2, args.in_flight)
+    WIN = max(1, args.window) if pipelined else 1
+    if args.profile_run and pipelined:
+        warmup = (warmup + WIN - 1) // WIN * WIN  # whole windows only: every sweep launch of the process is a full-window launch
     n_batches = steps + warmup
     queries = []
     for i in range(n_batches):
@@ -225,9 +241,6 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             r["h_keys"].copy_(r["keys"], non_blocking=True)
             r["h_counts"].copy_(r["counts"], non_blocking=True)
 
-    pipelined = not args.no_pipeline
-    NS = max(2, args.in_flight)
-    WIN = max(1, args.window) if pipelined else 1
     r0 = make_results()
     cur = torch.cuda.current_stream()
     if group is None:
@@ -290,8 +303,29 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             to_host(r0, cur)
 
     look = {"ahead": args.lookahead == "on"}
+    # Per-window latency inside the pipelined run: two events on the window's own (light, high-priority) stream -- one recorded
+    # right before begin() is called (the stream is idle then: the slot's previous window completed long ago, so the event's
+    # timestamp is the submission time), one behind the D2H copies of the window's last batch.  Only the single-GPU loop: the
+    # sharded loop's results complete on a stream the library owns.
+    lat_store = {"on": False, "ms": []}
+    lat = None
+
+    def _mark_begin(sl):
+        if "ev_b" not in sl:
+            sl["ev_b"], sl["ev_e"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sl["ev_b"].record(sl["stream"])
+        sl["t_begin"] = True
+
+    def _mark_end(sl):
+        sl["ev_e"].record(sl["stream"])
+
+    def _window_latency(sl):
+        sl["ev_e"].synchronize()
+        return sl["ev_b"].elapsed_time(sl["ev_e"])
 
     def run(first, n):
+        nonlocal lat
+        lat = lat_store["ms"] if (lat_store["on"] and group is None and not look["ahead"]) else None
         if not pipelined:
             for i in range(first, first + n):
                 blocking(i)
@@ -307,10 +341,28 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             nw = min(WIN, first + n - i)
             wins.append((i, nw))
             i += nw
-        if not look["ahead"]:  # begin + finish of a window back to back, NS windows in flight
+        if args.serial_windows:  # profiling: one window on the GPU at a time
             for w in range(len(wins)):
-                begin(slots[w % NS], *wins[w])
-                finish(slots[w % NS])
+                begin(slots[0], *wins[w])
+                finish(slots[0])
+                drain(slots[0])
+        elif not look["ahead"]:  # begin + finish of a window back to back, NS windows in flight
+            for w in range(len(wins)):
+                sl = slots[w % NS]
+                if lat is not None:
+                    if "t_begin" in sl:  # the window this slot held before (two windows ago) is done by now
+                        lat.append(_window_latency(sl))
+                    _mark_begin(sl)
+                begin(sl, *wins[w])
+                finish(sl)
+                if lat is not None:
+                    _mark_end(sl)
+            if lat is not None:
+                for sl in slots[:NS]:
+                    drain(sl)
+                    if "t_begin" in sl:
+                        lat.append(_window_latency(sl))
+                        del sl["t_begin"]
         else:                  # one more slot: a window begun ahead, one being finished, NS - 1 sweeping
             begin(slots[0], *wins[0])
             for w in range(len(wins)):
@@ -342,8 +394,10 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     torch.cuda.synchronize()
     env.barrier()
     torch.cuda.synchronize()
+    lat_store["on"] = pipelined and not args.serial_windows
     t0 = time.perf_counter()
     run(warmup, steps)
+    lat_store["on"] = False
     torch.cuda.synchronize()
     env.barrier()
     torch.cuda.synchronize()
@@ -360,7 +414,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     # counts once, so `achieved` never exceeds what the kernel really moved) ---------------------------------------
     ix.set_profiling(2)
     uniq = tot = 0
-    for i in range(max(1, min(steps // WIN, 4))):
+    for i in range(0 if args.profile_run else max(1, min(steps // WIN, 4))):
         ix.stats(reset=True)
         if pipelined:
             begin(slots[0], warmup + i * WIN, min(WIN, steps - i * WIN))
@@ -372,7 +426,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         s2 = ix.stats()
         uniq += s2["rows_unique"]
         tot += s2["rows_scored"]
-    uniq_frac = uniq / max(tot, 1)
+    uniq_frac = uniq / max(tot, 1) if tot else 1.0
     ix.set_profiling(0)
 
     # one batch's sweep is issued as several launches of the same kernel (~12 GB each): per-launch figures
@@ -390,28 +444,43 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     scan = st["scan_batches_accum"] > 0
     kind = 1 if wl["metric"] == "cosine" else 0
     kname = ("scan_sweep_kernel<%d, %d>" if scan else "sweep_kernel<%d, %d, ...>") % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
-    achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch,
-            "unique_row_fraction": uniq_frac, "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch,
-            "launches_per_batch": launches_per_batch, "bytes_per_launch": bytes_alg,
-            "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0}
-    if scan:
-        # The table scan does not move s8(d)'s bytes through HBM: a stored row is wanted by several leaves (one per tree) and is
-        # read ONCE for all of them, so `achieved` -- the s8(d) bytes over the launch time, the figure comparable with the
-        # leaf-major sweep and with round 1 -- can exceed the HBM peak.  What the kernel moves through HBM by design: the launch's
-        # stored rows once (4*d bytes, address order) + their T row->leaf entries (8 bytes each) + an 8-byte key per pair; what
-        # binds it is the L2 -> CU operand traffic, one query (4*d bytes) per pair (measured L2 row-gather ceiling: 16.8-18.8 TB/s,
-        # MI355X_MICROARCH.md 'Indexed rows').
+    s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
+              "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
+              "window_batches": WIN}
+    if not scan:
+        # Leaf-major sweep: SURVEY s8(d)'s bytes ARE what the kernel moves through HBM (PMC traffic 0.99-1.01x): HBM roofline.
+        roof = {"bound": "hbm", "achieved": s8d_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s8d_GBps / HBM_PEAK_GBS,
+                "traffic": None, "bytes_per_launch": bytes_alg,
+                "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0}
+        roof.update(common)
+    else:
+        # Table scan: the stored rows cross HBM ONCE per window (address order) and every (row, query) pair fetches its query
+        # (4*d bytes) from L2.  The binding resource is the L2 -> CU operand path, not HBM, so that is the roofline quoted:
+        #   achieved = (pairs + stored rows of a launch) * 4*d bytes / launch time   [what the CUs pull through L1 misses]
+        #   peak     = the guide's measured ceiling for whole rows gathered from L2 (MI355X_MICROARCH.md, 'Indexed rows', L2 row)
+        # beside it: the HBM side of the same launch (hbm_frac: bytes that cross HBM BY DESIGN / launch time / 8 TB/s; `traffic`
+        # is the PMC figure for the same launch) and, without a frac, SURVEY s8(d)'s numerator over the launch time -- the figure
+        # comparable with the leaf-major sweep and round 1, which exceeds the HBM peak because one HBM read of a row serves every
+        # tree that wants it: those bytes are not bytes this kernel moves.
         stored = st["swept_rows_accum"] / n_launch
+        l2_bytes = 4.0 * d * (rows_per_launch + stored)
         by_design = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
-        roof["sweep_mode"] = "table scan: stored rows streamed once per batch window, each scored against every query that visits one of its leaves (queries from L2)"
-        roof["frac_note"] = ("achieved = SURVEY s8(d) bytes / launch time; above the HBM peak because one HBM read of a row serves every tree "
-                             "that wants it -- see hbm_bytes_by_design_per_launch / hbm_frac_by_design for what crosses HBM")
-        roof["hbm_bytes_by_design_per_launch"] = by_design
-        roof["hbm_frac_by_design"] = by_design / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms else 0.0
-        roof["l2_operand_GBps"] = (4.0 * d * (rows_per_launch + stored)) / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
-        roof["l2_gather_ceiling_GBps"] = [16800, 18800]
+        l2_GBps = l2_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
+        roof = {"bound": "l2", "achieved": l2_GBps, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_GBps / L2_GATHER_PEAK_GBS,
+                "traffic": None, "bytes_per_launch": l2_bytes,
+                "peak_source": "MI355X_MICROARCH.md 'Indexed rows: gather into LDS', rows served from the XCD's L2: 66-73 GB/s per CU = "
+                               "16.8-18.8 TB/s chip-wide (upper end used)",
+                "peak_range_GBps": L2_GATHER_RANGE_GBS,
+                "hbm_bytes_by_design_per_launch": by_design,
+                "hbm_frac": by_design / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms else 0.0,
+                "hbm_peak_GBps": HBM_PEAK_GBS,
+                "s8d_equivalent_GBps": s8d_GBps, "s8d_bytes_per_launch": bytes_alg,
+                "s8d_note": "SURVEY s8(d) numerator / launch time: comparable with the leaf-major sweep, NOT a roofline fraction (a stored row "
+                            "is read once for every tree that wants it)",
+                "sweep_mode": "table scan: stored rows streamed once per batch window, each scored against every query that visits one of "
+                              "its leaves (queries from L2)"}
+        roof.update(common)
 
     out = {
         "qps": B * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
@@ -427,8 +496,29 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         "window_batches": WIN,
         "setup_s": {"fill": t_fill, "build": t_build},
     }
+    if lat_store["ms"]:
+        ls = sorted(lat_store["ms"])
+        out["latency_ms"] = {"p50_window_submit_to_host": ls[len(ls) // 2], "max_window_submit_to_host": ls[-1], "windows": len(ls),
+                             "batches_per_window": WIN, "windows_in_flight": NS,
+                             "note": "hipEvent span on the window's own stream, recorded before begin() (stream idle = submission time) and behind "
+                                     "the D2H copy of the window's last batch; no batch of a window completes before the whole window"}
     if group is not None:
         out["ranks_seen"] = group.ranks()  # ncclCommCount of the communicator the exchange ran on
+        # every rank must have run the same host loop on the same shapes, or the collectives were not the same sequence:
+        # (ranks RCCL connected, world, window, windows in flight, look-ahead, batch, top_k; the sweep kind is a rank's own business)
+        mine = [out["ranks_seen"], env.world if (env.world > 1 and S == env.world) else 1, WIN, NS, int(look["ahead"]), B, k]
+        out["preflight"] = {"ranks_seen": mine[0], "expected_ranks": mine[1], "ok": mine[0] == mine[1]}
+        if env.dist and S == env.world:
+            allv = [None] * env.world
+            env.dist.all_gather_object(allv, mine)
+            same = all(v == allv[0] for v in allv)
+            out["preflight"].update({"all_ranks_same_loop": same, "per_rank": allv if not same else None})
+            out["preflight"]["ok"] = out["preflight"]["ok"] and same
+            if not same and env.rank == 0:
+                print("bench.py preflight: the ranks did NOT run the same loop [ranks_seen, world, window, in_flight, lookahead, B, k]: %s"
+                      % allv, file=sys.stderr)
+        if not out["preflight"]["ok"] and env.rank == 0:
+            print("bench.py preflight FAILED: %s" % out["preflight"], file=sys.stderr)
 
     if recall and args.recall_queries > 0:
         nq = min(args.recall_queries, B)
@@ -476,13 +566,22 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     # sanity of the last timed batch as it arrived on the host
     assert (last_host[1] <= k).all() and (last_host[1] > 0).all(), "empty results in the last timed batch"
     # PCIe-inclusive rate through the host-buffer entry point: reported beside, never as, `value`
-    if group is None and S == 1:
+    if group is None and S == 1 and not args.profile_run:
         qh = [queries[warmup + i % max(steps, 1)].cpu().numpy() for i in range(3)]
         ix.search_batch(qh[0], k, metric)
         th = time.perf_counter()
         for q_ in qh:
             ix.search_batch(q_, k, metric)
         out["host_buffers_qps"] = 3 * B / (time.perf_counter() - th)
+        # what a latency-bound caller sees: ONE batch through the blocking device-pointer call, results on the host
+        lb = []
+        for i in range(5):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            blocking(warmup + i % max(steps, 1))
+            torch.cuda.synchronize()
+            lb.append((time.perf_counter() - tb) * 1e3)
+        out.setdefault("latency_ms", {})["p50_blocking_single_batch"] = sorted(lb)[len(lb) // 2]
     return out, ix, group, wl, M_shard
 
 
@@ -545,11 +644,26 @@ def cpu_baselines(env, ix, wl, M_shard, seconds):
     return legs
 
 
+def kernel_sources_sha():
+    """content hash of the kernel / host-pipeline sources (zebra_amd/csrc/*.hip, *.h, *.cpp): a PMC summary records the hash it
+    was collected at, bench.py the hash it runs at -- equal means the counters describe THESE kernels (.git does not travel
+    to the GPU box, a content hash does)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "zebra_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args, name, S, roof):
-    """roofline.traffic: HBM bytes per sweep launch from the rocprofv3 PMC passes of THIS command (separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), summarised under profiles/ by profiles/summarize.py.
-    bench.py cannot collect counters on itself: it quotes the newest committed summary, and only when that summary was
-    taken at the same launch granularity (rows per launch within 10 %); the summary's own commit travels with it."""
+    """roofline.traffic: HBM-side (fabric) bytes per sweep launch from the rocprofv3 PMC passes of THIS command -- separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section), collected with
+    --serial-windows at the SAME --window as the timed run (kernels must not overlap for per-kernel counters) and summarised
+    under profiles/ by profiles/summarize.py.  bench.py cannot collect counters on itself: it quotes the newest committed
+    summary, and only when that summary was taken at the same launch granularity AND window; the commit it was collected at
+    travels with it, next to the last commit that touched the kernel sources."""
     cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3_pmc.json")))
     if not cands or name != "cfg3" or S != 1 or args.rows:
         return
@@ -559,19 +673,23 @@ def pmc_traffic(args, name, S, roof):
         ent = [v for k_, v in pm.items() if k_.startswith(kn)][0]
         meta = pm.get("_meta", {})
         traffic = ent["hbm_bytes_per_launch"]
-        # the PMC passes run the blocking call, where the last launch of a batch is partial: compare per ROW
-        # (table scan: a launch is a range of STORED rows -- rows_loaded_per_launch -- whatever the window's pair count)
-        key = "rows_loaded_per_launch" if "sweep_mode" in roof else "rows_per_launch"
-        prof_rows = ((meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}).get(key)
-        if prof_rows and abs(prof_rows / roof[key] - 1) > 0.10:
+        prof = (meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}
+        key = "rows_loaded_per_launch" if roof["bound"] == "l2" else "rows_per_launch"
+        if prof.get(key) and abs(prof[key] / roof[key] - 1) > 0.10:
             return  # collected at another launch granularity
+        if roof["bound"] == "l2" and prof.get("window_batches", 1) != roof["window_batches"]:
+            return  # collected at another window (other pairs per launch)
         roof["traffic"] = traffic
-        roof["traffic_over_algorithmic"] = traffic / roof["bytes_per_launch"]
-        if "hbm_bytes_by_design_per_launch" in roof:
-            roof["traffic_over_by_design"] = traffic / roof["hbm_bytes_by_design_per_launch"]
+        if roof["bound"] == "l2":
+            roof["traffic_over_hbm_by_design"] = traffic / roof["hbm_bytes_by_design_per_launch"]
+        else:
+            roof["traffic_over_algorithmic"] = traffic / roof["bytes_per_launch"]
         roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
-                                  "note": "committed PMC summary of this command (separate rocprofv3 --pmc passes with --no-pipeline, i.e. window 1: "
-                                          "for the table scan half the pairs per launch of the pipelined run; not collected by this run).  FETCH_SIZE "
+                                  "collected_at_kernel_sources_sha": meta.get("kernel_sources_sha"),
+                                  "kernel_sources_sha_now": kernel_sources_sha(),
+                                  "counters_describe_these_kernels": meta.get("kernel_sources_sha") == kernel_sources_sha(),
+                                  "note": "committed PMC summary of this command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with "
+                                          "--serial-windows: same window, one window on the GPU at a time; not collected by this run).  FETCH_SIZE "
                                           "counts what L2 fetches from the fabric: for the table scan that includes queries evicted from L2 and "
                                           "re-fetched from the Infinity Cache, which are not HBM reads"}
     except Exception:
@@ -612,11 +730,12 @@ def main():
             torch.cuda.empty_cache()
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
-                                                              ("kernel", "achieved", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch", "rows_per_launch",
-                                                               "rows_loaded_per_launch", "sweep_mode", "hbm_bytes_by_design_per_launch", "hbm_frac_by_design", "l2_operand_GBps")
+                                                              ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",
+                                                               "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
+                                                               "hbm_frac", "s8d_equivalent_GBps")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
-                          "rows_scored_per_batch": r["rows_scored_per_batch"]}
+                          "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms")}
         if not only or "recall_clustered" in only:
             # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative
             r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=2)
@@ -634,6 +753,8 @@ def main():
             "pipelined_batches_in_flight": max(2, args.in_flight) if not args.no_pipeline else 1,
             "timed_span": "queries resident in HBM -> merged top-k in pinned host memory (D2H inside the span)",
             "config": res["config"],
+            "latency_ms": res.get("latency_ms"),
+            "recall": None,  # filled below
             f"recall_at_{k}": res.get(f"recall_at_{k}"), f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
             "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
             "roofline": res["roofline"], "cpu_baseline": cpu[1] if cpu else None, "cpu_baseline_bitexact": cpu[0] if cpu else None,
@@ -649,8 +770,27 @@ def main():
         if S > 1:
             out["series_note"] = ("N > 1 default series = scale64m (64M x 768 cosine top-10, strong scaling); its N = 1 point is "
                                   "other_configs.scale64m_n1 of the N = 1 run (whose `value` is cfg3, the largest single-GPU BASELINE config)")
+        if "preflight" in res:
+            out["preflight"] = res["preflight"]
         if other is not None:
             out["other_configs"] = other
+        # BASELINE's metric is "queries/sec + recall@k": the recall that says something first.  On the bench line's iid ~N(0,1)
+        # rows in 768-d every non-planted neighbour is indistinguishable from a random row, so recall@k against brute force is
+        # ~(rows scanned / rows) for ANY index -- the planted neighbour (query = stored row + 0.3 noise) is the informative part
+        # there; on clustered rows (same shape, same speed) recall@k itself is informative.
+        rc = (other or {}).get("recall_clustered") or {}
+        cos_literal = wl["metric"] == "cosine"
+        out["recall"] = {
+            "informative": {"data": "clustered rows (128 consecutive rows share a centre), cfg3 shape", f"recall_at_{k}": rc.get("recall_at_100") if k == 100 else None,
+                            "planted_neighbour_hit_rate": rc.get("planted_neighbour_hit_rate"), "queries_per_s": rc.get("queries_per_s_this_gpu")}
+            if rc else None,
+            "bench_data_iid": {f"recall_at_{k}": res.get(f"recall_at_{k}"), "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
+                               "note": "iid Gaussian rows: recall@k vs brute force is uninformative by construction (see comment in bench.py); "
+                                       "the planted neighbour is what an index can find"},
+            "cosine_key_note": ("this workload's metric is cosine with the reference's LITERAL key (distance.rs:23-25 sorts by similarity, SURVEY F4): "
+                                f"recall_at_{k}_reference_key is ~0 by construction; recall_at_{k} is measured with the corrected key, same cost")
+            if cos_literal else None,
+        }
     # RCCL writes a version banner through C stdio: every rank flushes it before the last barrier, so that rank 0's JSON
     # line is the LAST line of the job's stdout
     sys.stdout.flush()

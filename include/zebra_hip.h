@@ -62,7 +62,9 @@ typedef enum zh_status {
     ZH_EHIP = -3,         /* HIP runtime / no usable gfx950 device */
     ZH_ESTATE = -4,       /* call not valid in the index's current state */
     ZH_ELIMIT = -5,       /* a documented limit was exceeded (e.g. top_k > ZH_MAX_TOPK) */
-    ZH_EUNSUPPORTED = -6
+    ZH_EUNSUPPORTED = -6,
+    ZH_EPEER = -7         /* sharded search: ANOTHER rank of the group failed its part of the batch (or died); the exchange
+                           * completed (or was aborted after a timeout), the batch's results are not valid on any rank */
 } zh_status;
 
 /* the 13 metric structs of src/distance.rs.  0-2 are the simsimd path (key = f64 bits); 3-11 the `distances`
@@ -274,7 +276,17 @@ ZH_API int zh_merge_topk_packed_device(int device, uint32_t n_shards, size_t b, 
  * reference searching S independent LSHIndex instances and merging by (key, id).
  * The library links librccl itself; the caller only moves the 128-byte unique id from rank 0 to the other ranks
  * (any host channel: a file, MPI, a torch.distributed store).
- * Calls on one group must come from one thread at a time and in the same order on every rank (they are collectives). */
+ * Calls on one group must come from one thread at a time and in the same order on every rank (they are collectives).
+ *
+ * Errors are a GROUP outcome (the reference swallows a failed query, core.rs:303; a collective cannot): a rank whose local
+ * search fails still joins the all-gather, with an empty slot and its code in a status word that travels with the packed
+ * result (zh_shard_exchange_words = zh_packed_result_words + 1).  zh_shard_search_wait -- and the blocking calls -- then
+ * return the rank's own code, or ZH_EPEER where only other ranks failed: the same verdict everywhere, nobody hangs, the group
+ * stays usable.  The blocking calls split a batch that passes a per-launch limit IDENTICALLY on every rank (a ZH_ELIMIT
+ * anywhere makes every rank halve the chunk and repeat it; the first size comes from the largest visits-per-query any rank
+ * reported).  Pipelined calls: after a begin that returned an error, STILL call finish (it joins the exchange and returns the
+ * error) and wait.  A rank that dies or cannot join is bounded by ZH_SHARD_TIMEOUT_MS (environment, default 300000): wait
+ * aborts the communicator, returns ZH_EPEER, and the group is dead (later calls fail fast; destroy it). */
 typedef struct zh_shard_group zh_shard_group;
 #define ZH_UNIQUE_ID_BYTES 128
 ZH_API int zh_shard_unique_id(uint8_t out_id[ZH_UNIQUE_ID_BYTES]); /* rank 0: ncclGetUniqueId */
@@ -310,6 +322,14 @@ ZH_API int zh_shard_search_finish_window(zh_shard_ctx *ctx, uint64_t *const *d_o
 ZH_API void *zh_shard_ctx_stream(const zh_shard_ctx *ctx);
 /* this rank's own (unmerged) packed result of the context's last finished batch: zh_packed_result_words(b, k) words */
 ZH_API const uint64_t *zh_shard_ctx_local_result(const zh_shard_ctx *ctx);
+/* The status protocol, as pure host arithmetic (no GPU needed; tests carry it over gloo).  Words per rank in the exchange;
+ * a rank's status word = its local status (low 32 bits, sign-extended zh_status) | leaf visits per query it has seen << 32;
+ * the verdict every rank derives from the n_ranks gathered words: ZH_OK, status_words[rank]'s own code, or ZH_EPEER.
+ * out_* may be NULL: first failed rank (n_ranks if none), largest visits-per-query reported, 1 if every failure is ZH_ELIMIT. */
+ZH_API size_t zh_shard_exchange_words(size_t b, size_t k);
+ZH_API uint64_t zh_shard_status_word(int status, uint32_t visits_per_query);
+ZH_API int zh_shard_verdict(const uint64_t *status_words, uint32_t n_ranks, uint32_t rank, uint32_t *out_first_failed_rank,
+                            uint32_t *out_max_visits_per_query, int *out_all_elimit);
 
 /* synthetic queries on the device (bit-identical to oracle zo_synth_queries) */
 ZH_API int zh_synth_queries_device(int device, float *d_out, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows,
@@ -337,6 +357,22 @@ ZH_API void zh_ref_forest_free(zh_ref_forest *forest);
  * size needed) is written. */
 ZH_API int zh_ref_tree_encode(const zh_forest_view *forest, uint32_t dim, uint32_t tree, const uint8_t *uuids,
                               uint64_t n_rows, uint8_t *out, size_t cap, size_t *out_len);
+
+/* The database header, the `.zebra` file (core.rs:19-29 DatabaseInner, written by save_database core.rs:183-190, read by open
+ * core.rs:92-102): bincode(legacy) { uuid, model: Mod, metric: Met, index_options }.  Met and Mod are type parameters of the
+ * crate, so the file does not record them: the caller states the metric (only MinkowskiDistance / PNormDistance carry bytes:
+ * their i32 power) and the length of the model's serialisation (0 for the reference's three unit-struct models).  Host code. */
+typedef struct zh_ref_header {
+    uint8_t uuid[16];         /* DatabaseInner::uuid: the prefix of the two partition names "<uuid>-embeddings" / "<uuid>-trees" */
+    uint64_t max_node_size;   /* LSHIndexOptions (lsh.rs:124-129), usize as u64 */
+    uint64_t num_trees;
+    int32_t metric;           /* zh_metric as stated by the caller */
+    int32_t power;            /* MinkowskiDistance / PNormDistance { power } (distance.rs:160-190); 0 for the other metrics */
+    uint64_t model_off, model_len; /* where the model's own bytes sit inside the file */
+} zh_ref_header;
+ZH_API int zh_ref_header_decode(const uint8_t *bytes, size_t len, int metric, size_t model_len, zh_ref_header *out);
+/* out == NULL: only *out_len (the size needed) is written */
+ZH_API int zh_ref_header_encode(const zh_ref_header *header, const uint8_t *model_bytes, uint8_t *out, size_t cap, size_t *out_len);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 ZH_API int zh_set_profiling(zh_index *idx, int level); /* 0 off, 1 per-stage hipEvent timing, 2 + unique-row count */

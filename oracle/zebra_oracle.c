@@ -245,6 +245,10 @@ static inline double root_p(double s, int p) { /* s^(1/p), p >= 1, deterministic
 }
 
 static inline uint32_t bits32(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+// memcpy / qsort with a count of zero and a null pointer (an empty leaf, an empty index) are undefined behaviour by the letter
+// of the standard, and -fsanitize=undefined says so (tests/test_sanitizers.py): nothing is called for nothing
+static inline void copy_n(void *dst, const void *src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); }
+static inline void sort_n(void *base, size_t n, size_t size, int (*cmp)(const void *, const void *)) { if (n > 1) qsort(base, n, size, cmp); }
 
 typedef struct { float s0, s1; } zo_pairsum;
 
@@ -371,7 +375,7 @@ static uint64_t push_leaf(zo_forest *f, const uint32_t *ids, uint32_t n) {
         f->leaf_ids = realloc(f->leaf_ids, f->cap_leaf_ids * sizeof(uint32_t));
     }
     uint64_t off = f->n_leaf_ids;
-    memcpy(f->leaf_ids + off, ids, n * sizeof(uint32_t));
+    copy_n(f->leaf_ids + off, ids, n * sizeof(uint32_t));
     f->n_leaf_ids += n;
     return off;
 }
@@ -461,8 +465,8 @@ static int32_t build_node_into(zo_forest *f, uint32_t me, const float *X, uint32
             else below[nb++] = ids[i + r];
         }
     }
-    memcpy(ids, below, nb * sizeof(uint32_t));
-    memcpy(ids + nb, above, na * sizeof(uint32_t));
+    copy_n(ids, below, nb * sizeof(uint32_t));
+    copy_n(ids + nb, above, na * sizeof(uint32_t));
     f->plane[me] = (int32_t)p;
     /* lsh.rs:257-264: above first, then below; left = below, right = above */
     int32_t r = build_node(f, X, tree, 2 * path + 1, depth + 1, ids + nb, na, scratch);
@@ -493,7 +497,7 @@ static void insert_one(zo_forest *f, const float *X, uint32_t tree, uint32_t id)
     }
     uint32_t off = (uint32_t)f->left[node], len = (uint32_t)f->right[node];
     uint32_t *ids = malloc((len + 1) * sizeof(uint32_t));
-    memcpy(ids, f->leaf_ids + off, len * sizeof(uint32_t));
+    copy_n(ids, f->leaf_ids + off, len * sizeof(uint32_t));
     ids[len] = id;
     if (len + 1 > f->M) { /* lsh.rs:368-377 */
         uint32_t *scratch = malloc((size_t)(len + 1) * 2 * sizeof(uint32_t));
@@ -524,8 +528,8 @@ static int remove_from_leaf(zo_forest *f, uint32_t node, uint32_t id) {
     for (uint32_t i = 0; i < len; i++)
         if (f->leaf_ids[off + i] == id) {
             uint32_t *ids = malloc((len ? len : 1) * sizeof(uint32_t));
-            memcpy(ids, f->leaf_ids + off, i * sizeof(uint32_t));
-            memcpy(ids + i, f->leaf_ids + off + i + 1, (len - i - 1) * sizeof(uint32_t));
+            copy_n(ids, f->leaf_ids + off, i * sizeof(uint32_t));
+            copy_n(ids + i, f->leaf_ids + off + i + 1, (len - i - 1) * sizeof(uint32_t));
             f->left[node] = (int32_t)push_leaf(f, ids, len - 1);
             f->right[node] = (int32_t)(len - 1);
             free(ids);
@@ -591,7 +595,7 @@ ZO_EXPORT uint64_t zo_find_duplicates(const float *X, uint64_t n, uint32_t d, co
     uint64_t m = 0, dups = 0;
     for (uint64_t i = 0; i < n; i++) { out_dup[i] = 0; if (!alive || alive[i]) order[m++] = (uint32_t)i; }
     g_rc.bits = (const uint32_t *)X; g_rc.d = d;
-    qsort(order, m, sizeof(uint32_t), rowcmp);
+    sort_n(order, m, sizeof(uint32_t), rowcmp);
     for (uint64_t i = 1; i < m; i++)
         if (memcmp(X + (size_t)order[i] * d, X + (size_t)order[i - 1] * d, (size_t)d * 4) == 0) { out_dup[order[i]] = 1; dups++; }
     free(order);
@@ -622,16 +626,16 @@ ZO_EXPORT zo_forest *zo_forest_from_arrays(uint64_t n_rows, uint32_t d, uint32_t
     zo_forest *f = calloc(1, sizeof *f);
     f->n_rows = n_rows; f->d = d; f->M = M; f->T = T;
     f->n_nodes = f->cap_nodes = n_nodes;
-    f->plane = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->plane, plane, n_nodes * sizeof(int32_t));
-    f->left = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->left, left, n_nodes * sizeof(int32_t));
-    f->right = malloc((n_nodes + 1) * sizeof(int32_t)); memcpy(f->right, right, n_nodes * sizeof(int32_t));
+    f->plane = malloc((n_nodes + 1) * sizeof(int32_t)); copy_n(f->plane, plane, n_nodes * sizeof(int32_t));
+    f->left = malloc((n_nodes + 1) * sizeof(int32_t)); copy_n(f->left, left, n_nodes * sizeof(int32_t));
+    f->right = malloc((n_nodes + 1) * sizeof(int32_t)); copy_n(f->right, right, n_nodes * sizeof(int32_t));
     f->depth = calloc(n_nodes + 1, 1);
-    f->roots = malloc((T + 1) * sizeof(uint32_t)); memcpy(f->roots, roots, T * sizeof(uint32_t));
+    f->roots = malloc((T + 1) * sizeof(uint32_t)); copy_n(f->roots, roots, T * sizeof(uint32_t));
     f->n_planes = f->cap_planes = n_planes;
-    f->planes = malloc(((size_t)n_planes * d + 1) * sizeof(float)); memcpy(f->planes, planes, (size_t)n_planes * d * sizeof(float));
-    f->consts = malloc((n_planes + 1) * sizeof(float)); memcpy(f->consts, consts, n_planes * sizeof(float));
+    f->planes = malloc(((size_t)n_planes * d + 1) * sizeof(float)); copy_n(f->planes, planes, (size_t)n_planes * d * sizeof(float));
+    f->consts = malloc((n_planes + 1) * sizeof(float)); copy_n(f->consts, consts, n_planes * sizeof(float));
     f->n_leaf_ids = f->cap_leaf_ids = n_leaf_ids;
-    f->leaf_ids = malloc((n_leaf_ids + 1) * sizeof(uint32_t)); memcpy(f->leaf_ids, leaf_ids, n_leaf_ids * sizeof(uint32_t));
+    f->leaf_ids = malloc((n_leaf_ids + 1) * sizeof(uint32_t)); copy_n(f->leaf_ids, leaf_ids, n_leaf_ids * sizeof(uint32_t));
     return f;
 }
 
@@ -666,13 +670,13 @@ ZO_EXPORT void zo_forest_sizes(const zo_forest *f, uint32_t *n_nodes, uint32_t *
 }
 ZO_EXPORT void zo_forest_export(const zo_forest *f, int32_t *plane, int32_t *left, int32_t *right, uint32_t *roots,
                                 float *planes, float *consts, uint32_t *leaf_ids) {
-    memcpy(plane, f->plane, f->n_nodes * sizeof(int32_t));
-    memcpy(left, f->left, f->n_nodes * sizeof(int32_t));
-    memcpy(right, f->right, f->n_nodes * sizeof(int32_t));
-    memcpy(roots, f->roots, f->T * sizeof(uint32_t));
-    memcpy(planes, f->planes, (size_t)f->n_planes * f->d * sizeof(float));
-    memcpy(consts, f->consts, f->n_planes * sizeof(float));
-    memcpy(leaf_ids, f->leaf_ids, f->n_leaf_ids * sizeof(uint32_t));
+    copy_n(plane, f->plane, f->n_nodes * sizeof(int32_t));
+    copy_n(left, f->left, f->n_nodes * sizeof(int32_t));
+    copy_n(right, f->right, f->n_nodes * sizeof(int32_t));
+    copy_n(roots, f->roots, f->T * sizeof(uint32_t));
+    copy_n(planes, f->planes, (size_t)f->n_planes * f->d * sizeof(float));
+    copy_n(consts, f->consts, f->n_planes * sizeof(float));
+    copy_n(leaf_ids, f->leaf_ids, f->n_leaf_ids * sizeof(uint32_t));
 }
 
 /* --------------------------------------------------------------------------- walk (lsh.rs:290-348) */
@@ -751,7 +755,7 @@ static int32_t walk(zo_ctx *c, int32_t node, int32_t n) {
             ctx_reserve_buf(c, len);
             for (uint32_t i = 0; i < len; i++) { c->buf[i].id = ids[i]; c->buf[i].key = ctx_key(c, ids[i]); }
             c->rows_scored += len;
-            qsort(c->buf, len, sizeof(zo_pair), pair_cmp);
+            sort_n(c->buf, len, sizeof(zo_pair), pair_cmp);
             for (int32_t i = 0; i < n; i++) cand_insert(c, c->buf[i].id);
             ret = n;
         }
@@ -801,7 +805,7 @@ static uint32_t search_one(zo_ctx *c, const float *q, uint32_t k, uint64_t *out_
     if (f->n_rows == 0) return 0; /* core.rs:295-297 */
     for (uint32_t t = 0; t < f->T; t++) walk(c, (int32_t)f->roots[t], (int32_t)k);
     if (!c->stamp && c->n_cand > 1) { /* the union of the trees' candidates as a set (lsh.rs:550 DashSet) */
-        qsort(c->cand, c->n_cand, sizeof(uint32_t), u32_cmp);
+        sort_n(c->cand, c->n_cand, sizeof(uint32_t), u32_cmp);
         uint64_t m = 1;
         for (uint64_t i = 1; i < c->n_cand; i++) if (c->cand[i] != c->cand[m - 1]) c->cand[m++] = c->cand[i];
         c->n_cand = m;
@@ -810,7 +814,7 @@ static uint32_t search_one(zo_ctx *c, const float *q, uint32_t k, uint64_t *out_
     zo_pair *r = c->buf;
     for (uint64_t i = 0; i < c->n_cand; i++) { r[i].id = c->cand[i]; r[i].key = ctx_key(c, c->cand[i]); }
     c->rows_scored += c->n_cand;
-    qsort(r, c->n_cand, sizeof(zo_pair), pair_cmp);
+    sort_n(r, c->n_cand, sizeof(zo_pair), pair_cmp);
     uint32_t m = c->n_cand < k ? (uint32_t)c->n_cand : k;
     for (uint32_t i = 0; i < m; i++) { out_ids[i] = r[i].id; out_keys[i] = r[i].key; }
     return m;
@@ -990,7 +994,7 @@ ZO_EXPORT int32_t zo_tree_result(const zo_forest *f, const float *X, uint32_t tr
     c.q = q; c.epoch = 1; c.qq = metric == ZO_COSINE ? sum_prod(q, q, f->d) : 0.0f;
     c.visits = visits_out; c.cap_visits = cap_visits;
     int32_t r = walk(&c, (int32_t)f->roots[tree], n);
-    if (cand_out) memcpy(cand_out, c.cand, c.n_cand * sizeof(uint32_t));
+    if (cand_out) copy_n(cand_out, c.cand, c.n_cand * sizeof(uint32_t));
     if (n_cand_out) *n_cand_out = c.n_cand;
     if (n_visits_out) *n_visits_out = c.n_visits;
     ctx_free(&c);
@@ -1044,7 +1048,7 @@ ZO_EXPORT void zo_brute_force(const float *X, uint64_t n, uint32_t d, const floa
         r[i].key = metric == ZO_COSINE ? key_from_sums(metric, mode, sum_prod(a, q, d), sum_prod(a, a, d), qq, 0.0f)
                                        : key_from_sums(metric, mode, 0, 0, 0, sum_l2sq(a, q, d));
     }
-    qsort(r, n, sizeof(zo_pair), pair_cmp);
+    sort_n(r, n, sizeof(zo_pair), pair_cmp);
     for (uint32_t i = 0; i < k && i < n; i++) { out_ids[i] = r[i].id; out_keys[i] = r[i].key; }
     free(r);
 }

@@ -36,8 +36,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        san = os.environ.get("ZEBRA_ORACLE_SAN_LIB")  # tests/test_sanitizers.py: the same source built with -fsanitize=address,undefined
+        if not san:
+            build()
+        L = C.CDLL(san or _SO)
         vp, u64, u32, i32, f32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float
         L.zo_synth_rows.argtypes = [u64, u64, u64, u32, C.c_int, vp]
         L.zo_synth_query_row.argtypes = [u64, u64, u64]

@@ -3,13 +3,17 @@
 # `--`, as MI355X_MICROARCH.md prescribes):   gpurun -- bash profiles/collect.sh r02 <commit> [configs...]
 # then, back in the container:                python profiles/summarize.py r02 <commit>
 # Every configuration is its own command, so that a kernel name in a stats file belongs to ONE workload.
-TAG=${1:-r02}; COMMIT=${2:-unknown}; shift 2
+TAG=${1:-r03}; COMMIT=${2:-unknown}; shift 2
 CFGS=${@:-"cfg3 cfg2 cfg4shard cfg5shard refdefault scale64m hashbig"}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "$COMMIT" > $OUT/commit.txt
-common="--cpu-seconds 0 --no-recall --no-other-configs"
+python3 profiles/summarize.py --sha > $OUT/kernel_sources.sha
+# --profile-run: nothing but full windows of the workload (every sweep launch of the process is comparable with bench.py's
+# launch_ms); the PMC passes add --serial-windows: the SAME window as the timed run, one window on the GPU at a time (per-kernel
+# counters need kernels that do not overlap)
+common="--cpu-seconds 0 --no-recall --no-other-configs --profile-run"
 for c in $CFGS; do
   case $c in
     cfg3)       args="bench.py --steps 5 --warmup 2 $common" ;;
@@ -26,12 +30,16 @@ for c in $CFGS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$c/stats -- python3 $args > $OUT/$c.stats.log 2>&1
   tail -1 $OUT/$c.stats.log | cut -c1-300
   [ "$c" = hashbig ] && { rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/$c/mfma -- python3 $args > $OUT/$c.mfma.log 2>&1; continue; }
-  # counters per kernel need kernels that do not overlap: the blocking call
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$c/fetch -- python3 $args --no-pipeline > $OUT/$c.fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$c/write -- python3 $args --no-pipeline > $OUT/$c.write.log 2>&1
+  # counters per kernel need kernels that do not overlap: one window at a time, same window size
+  echo "$args --serial-windows" > $OUT/$c.pmccmd
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$c/fetch -- python3 $args --serial-windows > $OUT/$c.fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$c/write -- python3 $args --serial-windows > $OUT/$c.write.log 2>&1
+  if [ "$c" = cfg3 ]; then  # the scan's L2 side: requests, hit rate
+    rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/$c/l2 -- python3 $args --serial-windows > $OUT/$c.l2.log 2>&1
+  fi
   if [ "$c" = refdefault ]; then
-    rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/$c/sq -- python3 $args --no-pipeline > $OUT/$c.sq.log 2>&1
-    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/$c/mfma -- python3 $args --no-pipeline > $OUT/$c.mfma.log 2>&1
+    rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/$c/sq -- python3 $args --serial-windows > $OUT/$c.sq.log 2>&1
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/$c/mfma -- python3 $args --serial-windows > $OUT/$c.mfma.log 2>&1
   fi
   # keep what travels back small: the per-dispatch traces are summarised on the box
   python3 profiles/summarize.py --box $OUT/$c $OUT/$c.summary.json > $OUT/$c.summary.log 2>&1

@@ -45,19 +45,24 @@ def agg_counters(d):
 def box(cfg_dir, out_json):
     fetch, write = agg_counters(os.path.join(cfg_dir, "fetch")), agg_counters(os.path.join(cfg_dir, "write"))
     sq, mfma = agg_counters(os.path.join(cfg_dir, "sq")), agg_counters(os.path.join(cfg_dir, "mfma"))
+    l2 = agg_counters(os.path.join(cfg_dir, "l2"))
     out = {}
-    for k in sorted(set(fetch) | set(write) | set(sq) | set(mfma)):
+    for k in sorted(set(fetch) | set(write) | set(sq) | set(mfma) | set(l2)):
         f, w = fetch.get(k), write.get(k)
-        e = {"launches": (f or w or sq.get(k) or mfma.get(k))["launches"]}
+        e = {"launches": (f or w or sq.get(k) or mfma.get(k) or l2.get(k))["launches"]}
         if f:
             e.update(FETCH_SIZE_KiB_raw=f["FETCH_SIZE"], read_bytes_corrected_x2=2 * f["FETCH_SIZE"] * 1024, avg_ns_under_pmc=f["avg_ns_under_pmc"])
         if w:
             e.update(WRITE_SIZE_KiB=w["WRITE_SIZE"], write_bytes=w["WRITE_SIZE"] * 1024)
         if f or w:
             e["hbm_bytes_per_launch"] = (2 * f["FETCH_SIZE"] * 1024 if f else 0) + (w["WRITE_SIZE"] * 1024 if w else 0)
-        for src in (sq.get(k), mfma.get(k)):
+        for src in (sq.get(k), mfma.get(k), l2.get(k)):
             if src:
                 e.update({c: v for c, v in src.items() if c not in ("launches",)})
+        if l2.get(k) and "TCC_REQ_sum" in l2[k]:  # L2 requests are 128-byte lines
+            e["l2_request_bytes_per_launch"] = l2[k]["TCC_REQ_sum"] * 128.0
+            hm = l2[k].get("TCC_HIT_sum", 0) + l2[k].get("TCC_MISS_sum", 0)
+            e["l2_hit_rate"] = l2[k].get("TCC_HIT_sum", 0) / hm if hm else None
         out[k] = e
     json.dump(out, open(out_json, "w"), indent=1)
     for k, v in out.items():
@@ -83,15 +88,23 @@ def container(tag, commit):
             for ln in open(log):
                 if ln.startswith('{"metric"'):
                     line = json.loads(ln)
+        shaf = os.path.join(root, "kernel_sources.sha")
+        pmcf = os.path.join(root, f"{cfg}.pmccmd")
         pm["_meta"] = {"commit": commit, "command": "python3 " + open(cmdf).read().strip(),
-                       "pmc_passes": "the same command + --no-pipeline, one rocprofv3 --pmc pass per counter group",
+                       "kernel_sources_sha": open(shaf).read().strip() if os.path.exists(shaf) else None,
+                       "pmc_passes": ("python3 " + open(pmcf).read().strip() + "  (one rocprofv3 --pmc pass per counter group)") if os.path.exists(pmcf)
+                                     else "the same command + --no-pipeline, one rocprofv3 --pmc pass per counter group",
                        "bench_line_under_kernel_trace": line and {k: line[k] for k in ("value", "ms_per_step", "roofline", "stage_ms_per_batch", "config") if k in line}}
         json.dump(pm, open(os.path.join(here, f"{tag}_{cfg}_pmc.json"), "w"), indent=1)
         print("wrote", cfg)
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--box":
+    if sys.argv[1] == "--sha":  # content hash of the kernel sources (the same function bench.py reports)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        print(bench.kernel_sources_sha())
+    elif sys.argv[1] == "--box":
         box(sys.argv[2], sys.argv[3])
     else:
         container(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -269,12 +269,19 @@ impl<const N: usize> LSHIndex<N> {
     pub fn add(&self, embeddings: &Vec<Embedding<N>>) -> anyhow::Result<Vec<Uuid>> {
         let ids: Vec<Uuid> = embeddings.iter().map(|_| Uuid::now_v7()).collect();
         let mut t = self.ids.write().unwrap(); // rows are numbered in insertion order: hold the table across the call
-        check(unsafe { ffi::zh_index_add(self.hip.0, embeddings.as_ptr() as *const f32, embeddings.len(), std::ptr::null_mut()) })?;
-        for u in &ids {
-            let row = t.of_row.len() as u64;
-            t.of_row.push(*u);
-            t.row_of.insert(*u, row);
+        // The C layer stores the rows BEFORE it touches the trees and writes a row's id only once the row is stored; a failure
+        // after that (a first build or an incremental insert that runs out of memory) keeps the rows -- their ids were handed
+        // out.  So the row -> Uuid table follows what was STORED, not what succeeded: otherwise every later row would be
+        // shifted against its Uuid (or `of_row[id]` would panic) once the index is rebuilt with zh_index_build.
+        let mut rows = vec![u64::MAX; embeddings.len()];
+        let rc = unsafe { ffi::zh_index_add(self.hip.0, embeddings.as_ptr() as *const f32, embeddings.len(), rows.as_mut_ptr()) };
+        for (u, r) in ids.iter().zip(rows.iter()) {
+            if *r != u64::MAX {
+                t.row_of.insert(*u, t.of_row.len() as u64);
+                t.of_row.push(*u);
+            }
         }
+        check(rc)?;
         Ok(ids)
     }
 

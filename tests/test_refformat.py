@@ -158,3 +158,31 @@ def test_random_trees_decode_and_reencode(seed, d, T, depth):
         got.append(out)
     assert got == [_leaves_py(t) for t in trees]
     assert rf.encode_trees(f, d, u) == blobs
+
+
+def test_known_answer_bytes_of_the_database_header():
+    """The `.zebra` file (core.rs:19-29 DatabaseInner, save_database core.rs:183-190), assembled by hand: the uuid as a byte
+    string (u64 16 + 16 bytes), nothing for the unit-struct model (model/text.rs:11) and the unit-struct metric
+    (distance.rs:15-17), LSHIndexOptions { max_node_size: usize, num_trees: usize } as two u64 (lsh.rs:124-129)."""
+    u = uuid.UUID("0192f0c5-7b1e-7cc3-9d4a-2f1e0a3b5c7d")
+    kat = struct.pack("<Q", 16) + u.bytes + struct.pack("<QQ", 5, 15)          # the defaults of lsh.rs:131-138
+    assert len(kat) == 40
+    h = rf.decode_header(kat, "cosine")
+    assert h == dict(uuid=u.bytes, max_node_size=5, num_trees=15, metric=0, power=0, model=b"")
+    assert rf.encode_header(u.bytes) == kat
+    # MinkowskiDistance { power: i32 } (distance.rs:160-165) sits between the model and the options
+    kat_p = struct.pack("<Q", 16) + u.bytes + struct.pack("<i", 3) + struct.pack("<QQ", 4096, 15)
+    h = rf.decode_header(kat_p, "minkowski")
+    assert (h["power"], h["max_node_size"], h["num_trees"]) == (3, 4096, 15)
+    assert rf.encode_header(u.bytes, 4096, 15, "minkowski", 3) == kat_p
+    assert rf.encode_header(u.bytes, 4096, 15, "pnorm", 3) == kat_p              # same layout, another type parameter
+    # a model that carries bytes (none of the reference's does): opaque, passed through
+    kat_m = struct.pack("<Q", 16) + u.bytes + b"\x01\x02\x03" + struct.pack("<QQ", 5, 15)
+    assert rf.decode_header(kat_m, "l2", model_len=3)["model"] == b"\x01\x02\x03"
+    assert rf.encode_header(u.bytes, 5, 15, "l2", model=b"\x01\x02\x03") == kat_m
+    # stating the wrong metric type is detected by the length
+    for bad, metric in ((kat, "minkowski"), (kat_p, "cosine"), (kat[:-1], "cosine"), (kat + b"\0", "cosine"),
+                        (struct.pack("<Q", 15) + kat[8:], "cosine")):
+        with pytest.raises(Exception) as e:
+            rf.decode_header(bad, metric)
+        assert getattr(e.value, "code", None) == -1

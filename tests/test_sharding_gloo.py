@@ -70,6 +70,32 @@ def _worker(rank, world, port, out):
     for r in range(world):
         a, b_, c = sharding.packed_views(torch, g_packed[r], B, K)
         assert torch.equal(a, g_ids[r]) and torch.equal(b_, g_keys[r]) and torch.equal(c, g_counts[r])
+    # the exchange as libzebra_hip.so issues it: W + 1 words per rank, the last one the rank's STATUS word.  Rank 1 plays a rank
+    # whose local search failed with ZH_ELIMIT: an empty slot (counts 0) + its code; every rank derives the same verdict from
+    # the gathered words (zh_shard_verdict is pure arithmetic: the real function, no GPU)
+    import ctypes
+    SW = int(_ffi.lib().zh_shard_exchange_words(B, K))
+    assert SW == W + 1
+    for failing, code in ((None, 0), (1, _ffi.ZH_ELIMIT), (0, _ffi.ZH_ENOMEM)):
+        slot = torch.zeros(SW, dtype=torch.int64)
+        my_code = code if rank == failing else 0
+        if my_code == 0:
+            slot[:W] = packed
+        word = int(_ffi.lib().zh_shard_status_word(my_code, 1000 * (rank + 1)))
+        slot[W] = word - (1 << 64) if word >= (1 << 63) else word
+        g_slots = torch.empty((world, SW), dtype=torch.int64)
+        dist.all_gather_into_tensor(g_slots.view(-1), slot.view(-1))
+        words = (ctypes.c_uint64 * world)(*[int(g_slots[r, W].item()) & ((1 << 64) - 1) for r in range(world)])
+        first, vmax, all_el = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+        verdict = _ffi.lib().zh_shard_verdict(words, world, rank, ctypes.byref(first), ctypes.byref(vmax), ctypes.byref(all_el))
+        assert vmax.value == 1000 * world  # the largest visits-per-query any rank reported: sizes the next chunk everywhere
+        if failing is None:
+            assert verdict == 0 and first.value == world and all_el.value == 0
+        else:
+            assert first.value == failing and all_el.value == (1 if code == _ffi.ZH_ELIMIT else 0)
+            assert verdict == (code if rank == failing else _ffi.ZH_EPEER)  # own code on the failing rank, ZH_EPEER elsewhere
+            _, _, c = sharding.packed_views(torch, g_slots[failing][:W], B, K)
+            assert int(c.sum()) == 0  # nothing for the merge to read from the failed rank
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libzebra_hip.so")
 
 ZH_OK = 0
+ZH_EINVAL, ZH_ENOMEM, ZH_EHIP, ZH_ESTATE, ZH_ELIMIT, ZH_EUNSUPPORTED, ZH_EPEER = -1, -2, -3, -4, -5, -6, -7
 COSINE, L2SQ, L2 = 0, 1, 2
 CHEBYSHEV, CANBERRA, BRAY_CURTIS, MANHATTAN, L3, L4, HAMMING, MINKOWSKI, PNORM = 3, 4, 5, 6, 7, 8, 9, 10, 11
 COSINE_PARITY, COSINE_CORRECTED = 0, 1
@@ -34,6 +35,11 @@ class ForestView(C.Structure):
 class ForestSizes(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_planes", C.c_uint32), ("n_trees", C.c_uint32),
                 ("n_leaf_ids", C.c_uint64)]
+
+
+class RefHeader(C.Structure):
+    _fields_ = [("uuid", C.c_uint8 * 16), ("max_node_size", C.c_uint64), ("num_trees", C.c_uint64), ("metric", C.c_int32),
+                ("power", C.c_int32), ("model_off", C.c_uint64), ("model_len", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -106,11 +112,16 @@ SYMBOLS = [
     ("zh_shard_search_finish_window", _i, [_vp, _vp, _vp, _vp]),
     ("zh_shard_ctx_stream", _vp, [_vp]),
     ("zh_shard_ctx_local_result", _vp, [_vp]),
+    ("zh_shard_exchange_words", _sz, [_sz, _sz]),
+    ("zh_shard_status_word", _u64, [_i, _u32]),
+    ("zh_shard_verdict", _i, [_vp, _u32, _u32, _vp, _vp, _vp]),
     ("zh_synth_queries_device", _i, [_i, _vp, _u64, _u64, _u64, _u64, _sz, _u32, _i, _vp]),
     ("zh_ref_forest_decode", _i, [_u32, _sz, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("zh_ref_forest_view", _i, [_vp, _vp]),
     ("zh_ref_forest_free", None, [_vp]),
     ("zh_ref_tree_encode", _i, [_vp, _u32, _u32, _vp, _u64, _vp, _sz, _vp]),
+    ("zh_ref_header_decode", _i, [_vp, _sz, _i, _sz, _vp]),
+    ("zh_ref_header_encode", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("zh_set_profiling", _i, [_vp, _i]),
     ("zh_stats", _i, [_vp, _vp]),
     ("zh_stats_reset", _i, [_vp]),

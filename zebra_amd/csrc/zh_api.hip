@@ -1717,6 +1717,13 @@ extern "C" int zh_search_finish_window(zh_search_ctx *c, uint64_t *const *d_out_
     if (rc) return rc;
     return ctx_finish(c, d_out_ids, d_out_keys, d_out_counts, (hipStream_t)sweep_stream);
 }
+double zh_index_visits_per_pair(zh_index *ix) {
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    return ix->visits_per_pair;
+}
+void zh_search_ctx_abandon(zh_search_ctx *c) {
+    if (c && c->state == 1) c->state = 0;  // what was enqueued by begin completes on its stream; its results are never used
+}
 extern "C" int zh_search_wait(zh_search_ctx *c) {
     if (!c) return fail(ZH_EINVAL, "zh_search_wait: null context");
     int rc = set_device(c->ix);

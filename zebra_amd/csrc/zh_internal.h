@@ -8,6 +8,10 @@
 
 // sets zh_last_error() for the calling thread and returns `code`
 int zh_set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// (zh_shard.hip) leaf visits per (query, tree) pair, running mean of the index's batches so far (0 before the first)
+double zh_index_visits_per_pair(zh_index *ix);
+// (zh_shard.hip) a context whose batch was begun and will never be finished goes back to idle
+void zh_search_ctx_abandon(zh_search_ctx *c);
 
 // ---- one leaf visit of the walk (tree_result, lsh.rs:290-348): score `len` rows of a leaf for
 // query `b`, keep the `take` smallest.  row_off / cand_off are the visit's slices of the key

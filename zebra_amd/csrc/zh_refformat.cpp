@@ -17,6 +17,16 @@
 //   InnerNode<N>   { hyperplane, left_node, right_node } in that order (pre-order, left = BELOW side, lsh.rs:260-264)
 //   LeafNode       newtype around Vec<Uuid>: u64 count, then per id the uuid crate's binary form = a byte string:
 //                  u64 length (16) + 16 bytes
+//
+// The database HEADER, the `.zebra` file itself (/root/reference/src/database/core.rs:19-29 DatabaseInner, written by
+// save_database core.rs:183-190, read by open core.rs:92-102), same bincode-legacy configuration:
+//   DatabaseInner<N, Met, Mod> { uuid: Uuid, model: Mod, metric: Met, index_options: LSHIndexOptions<N> } in that order
+//     uuid           byte string: u64 length (16) + 16 bytes                                                   (24 bytes)
+//     model          the reference's three models are unit structs (model/text.rs:11, image.rs:50, audio.rs:106) (0 bytes)
+//     metric         a unit struct for 11 of the 13 metrics (distance.rs:15-158)                                (0 bytes);
+//                    MinkowskiDistance / PNormDistance { power: i32 } (distance.rs:160-190)                     (4 bytes)
+//     index_options  { max_node_size: usize, num_trees: usize } (lsh.rs:124-129), usize as u64                  (16 bytes)
+// Met and Mod are TYPE parameters: the file does not say which they are, the opener states them (as `Database::open::<..>` does).
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -24,7 +34,11 @@
 #include <unordered_map>
 #include <vector>
 
-#include "zh_internal.h"
+// Only the public header: this file has no HIP in it, so that it also builds stand-alone with gcc -fsanitize=address,undefined
+// (tests/asan/Makefile) -- it parses untrusted on-disk bytes.
+#include "../../include/zebra_hip.h"
+
+int zh_set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));  // zh_api.hip (tests/asan: a stub)
 
 namespace {
 
@@ -190,5 +204,46 @@ extern "C" int zh_ref_tree_encode(const zh_forest_view *v, uint32_t dim, uint32_
     }
     *out_len = pos;
     if (out && pos > cap) return zh_set_error(ZH_EINVAL, "zh_ref_tree_encode: buffer of %zu bytes, %zu needed", cap, pos);
+    return ZH_OK;
+}
+
+static bool metric_has_power(int metric) { return metric == ZH_MINKOWSKI || metric == ZH_PNORM; }
+
+extern "C" int zh_ref_header_decode(const uint8_t *bytes, size_t len, int metric, size_t model_len, zh_ref_header *out) {
+    if (!bytes || !out) return zh_set_error(ZH_EINVAL, "zh_ref_header_decode: null argument");
+    if (metric < ZH_COSINE || metric > ZH_PNORM) return zh_set_error(ZH_EINVAL, "zh_ref_header_decode: unknown metric %d", metric);
+    Reader r{bytes, len};
+    zh_ref_header h;
+    memset(&h, 0, sizeof h);
+    uint64_t blen;
+    if (!r.take(&blen, 8) || blen != 16 || !r.take(h.uuid, 16)) return zh_set_error(ZH_EINVAL, "header: bad uuid at byte %zu", r.pos);
+    if (len - r.pos < model_len) return zh_set_error(ZH_EINVAL, "header: truncated inside the model (%zu bytes stated)", model_len);
+    h.model_off = r.pos; h.model_len = model_len;
+    r.pos += model_len;
+    h.metric = metric;
+    if (metric_has_power(metric) && !r.take(&h.power, 4)) return zh_set_error(ZH_EINVAL, "header: truncated at byte %zu (metric power)", r.pos);
+    if (!r.take(&h.max_node_size, 8) || !r.take(&h.num_trees, 8)) return zh_set_error(ZH_EINVAL, "header: truncated at byte %zu (index options)", r.pos);
+    if (r.pos != r.n) return zh_set_error(ZH_EINVAL, "header: %zu trailing bytes (wrong metric or model type stated?)", r.n - r.pos);
+    *out = h;
+    return ZH_OK;
+}
+
+extern "C" int zh_ref_header_encode(const zh_ref_header *h, const uint8_t *model_bytes, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!h || !out_len || (h->model_len && !model_bytes)) return zh_set_error(ZH_EINVAL, "zh_ref_header_encode: null argument");
+    if (h->metric < ZH_COSINE || h->metric > ZH_PNORM) return zh_set_error(ZH_EINVAL, "zh_ref_header_encode: unknown metric %d", h->metric);
+    size_t pos = 0;
+    auto put = [&](const void *src, size_t k) {
+        if (out && pos + k <= cap) memcpy(out + pos, src, k);
+        pos += k;
+    };
+    const uint64_t sixteen = 16;
+    put(&sixteen, 8);
+    put(h->uuid, 16);
+    if (h->model_len) put(model_bytes, (size_t)h->model_len);
+    if (metric_has_power(h->metric)) put(&h->power, 4);
+    put(&h->max_node_size, 8);
+    put(&h->num_trees, 8);
+    *out_len = pos;
+    if (out && pos > cap) return zh_set_error(ZH_EINVAL, "zh_ref_header_encode: buffer of %zu bytes, %zu needed", cap, pos);
     return ZH_OK;
 }

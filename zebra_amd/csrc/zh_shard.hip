@@ -227,13 +227,17 @@ static int shard_begin(zh_shard_ctx *c, const float *const *d_q, size_t nwin, si
     if (c->state == 1) return FAIL(ZH_ESTATE, "zh_shard_search_begin: the context already has a batch begun");
     if (k == 0 || k > ZH_MAX_TOPK) return FAIL(ZH_ELIMIT, "top_k must be in 1..%u", ZH_MAX_TOPK);
     if (b == 0) return FAIL(ZH_EINVAL, "zh_shard_search_begin: empty batch");
+    if (c->g->dead.load()) return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it");
     int rc = set_dev(c->g);
     if (rc) return rc;
-    if (c->state == 2 && (rc = zh_shard_search_wait(c))) return rc;
-    if ((rc = zh_search_begin_window(c->sc, d_q, nwin, b, k, metric, mode, c->light))) return rc;
+    if (c->state == 2) zh_shard_search_wait(c);  // retire the previous batch (its verdict was the caller's to collect)
+    if (c->g->dead.load()) return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it");
+    // From here on the call is part of a collective sequence: whatever happens locally, this rank joins the exchange in
+    // finish.  A failed local begin is remembered and travels in the status word.
     c->B = nwin * b; c->k = k; c->nwin = nwin; c->bwin = b;
+    c->begin_rc = zh_search_begin_window(c->sc, d_q, nwin, b, k, metric, mode, c->light);
     c->state = 1;
-    return ZH_OK;
+    return c->begin_rc;
 }
 extern "C" int zh_shard_search_begin(zh_shard_ctx *c, const float *d_q, size_t b, size_t k, int metric, int mode) {
     if (!c || !d_q) return FAIL(ZH_EINVAL, "zh_shard_search_begin: null argument");
@@ -245,34 +249,46 @@ extern "C" int zh_shard_search_begin_window(zh_shard_ctx *c, const float *const 
     return shard_begin(c, d_q, n_batches, b, k, metric, mode);
 }
 
-// local results of the whole window land in this rank's slot of the gather buffer ([ids B*k | keys B*k | counts B], B =
-// every query of the window), ONE all-gather and ONE merge per window; a window's merged results are handed out per batch
+// local results of the whole window land in this rank's slot of the gather buffer ([ids B*k | keys B*k | counts B | status],
+// B = every query of the window), ONE all-gather and ONE merge per window; a window's merged results are handed out per batch.
+// A local failure still joins: an empty slot (counts 0) and the code in the status word; the call then returns that code
+// (state 2: zh_shard_search_wait completes the exchange and reports the group's verdict).
 static int shard_finish(zh_shard_ctx *c, uint64_t *const *out_ids, uint64_t *const *out_keys, uint32_t *const *out_counts) {
     if (c->state != 1) return FAIL(ZH_ESTATE, "zh_shard_search_finish without zh_shard_search_begin");
     zh_shard_group *g = c->g;
+    if (g->dead.load()) { c->state = 0; return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it"); }
     int rc = set_dev(g);
     if (rc) return rc;
     const size_t B = c->B, k = c->k, nwin = c->nwin, b = c->bwin;
-    const size_t W = zh_packed_result_words(B, k), need = W * g->n_ranks;
+    const size_t W = zh_packed_result_words(B, k), SW = W + 1, need = SW * g->n_ranks;
+    // a rank that cannot even hold the gather buffer cannot join: it kills the group (peers time out in wait -> ZH_EPEER)
+    auto cannot_join = [&](int code, const char *what, hipError_t e) {
+        c->state = 0;
+        kill_group(g);
+        return FAIL(code, "%s: %s -- this rank cannot join the exchange; the shard group is dead", what, hipGetErrorString(e));
+    };
     if (need > c->cap_words) {  // another batch shape: the previous exchange must have read the old buffer
-        if (c->xused) HIPCHK(hipEventSynchronize(c->ev_xdone));
+        if (c->xused) { hipError_t e = hipEventSynchronize(c->ev_xdone); if (e != hipSuccess) return cannot_join(ZH_EHIP, "hipEventSynchronize", e); }
         if (c->gathered) hipFree(c->gathered);
         c->gathered = nullptr; c->cap_words = 0;
-        HIPCHK(hipMalloc((void **)&c->gathered, need * 8));
+        hipError_t e = hipMalloc((void **)&c->gathered, need * 8);
+        if (e != hipSuccess) return cannot_join(ZH_ENOMEM, "hipMalloc of the gather buffer", e);
         c->cap_words = need;
     } else if (c->xused) {
         // the buffer is free again once this context's previous exchange has read it (long done: a batch ago)
-        HIPCHK(hipStreamWaitEvent(c->light, c->ev_xdone, 0));
+        hipError_t e = hipStreamWaitEvent(c->light, c->ev_xdone, 0);
+        if (e != hipSuccess) return cannot_join(ZH_EHIP, "hipStreamWaitEvent", e);
     }
     if (nwin > 1 && W > c->cap_merged) {
-        if (c->xused) HIPCHK(hipEventSynchronize(c->ev_xdone));
+        if (c->xused) { hipError_t e = hipEventSynchronize(c->ev_xdone); if (e != hipSuccess) return cannot_join(ZH_EHIP, "hipEventSynchronize", e); }
         if (c->merged) hipFree(c->merged);
         c->merged = nullptr; c->cap_merged = 0;
-        HIPCHK(hipMalloc((void **)&c->merged, W * 8));
+        hipError_t e = hipMalloc((void **)&c->merged, W * 8);
+        if (e != hipSuccess) return cannot_join(ZH_ENOMEM, "hipMalloc of the merge buffer", e);
         c->cap_merged = W;
     }
     c->W = W;
-    uint64_t *mine = c->gathered + (size_t)g->rank * W;
+    uint64_t *mine = c->gathered + (size_t)g->rank * SW;
     uint64_t *l_ids[ZH_MAX_WINDOW], *l_keys[ZH_MAX_WINDOW];
     uint32_t *l_counts[ZH_MAX_WINDOW];
     for (size_t j = 0; j < nwin; j++) {
@@ -281,25 +297,50 @@ static int shard_finish(zh_shard_ctx *c, uint64_t *const *out_ids, uint64_t *con
         l_counts[j] = reinterpret_cast<uint32_t *>(mine + 2 * B * k) + j * b;
     }
     c->state = 0;
-    if ((rc = zh_search_finish_window(c->sc, l_ids, l_keys, l_counts, zh_index_sweep_stream(g->ix)))) return rc;
-    HIPCHK(hipEventRecord(c->ev_final, c->light));
+    // ---- the local search; its outcome is this rank's status word ----
+    int local = c->begin_rc;
+    std::string local_msg = local ? zh_last_error() : "";
+    if (!local && (local = injected_failure())) {
+        // (test hook) the local search is abandoned exactly as a real ZH_ELIMIT abandons it: begun, never finished
+        local_msg = "injected failure (ZH_SHARD_INJECT)";
+        zh_search_ctx_abandon(c->sc);
+    } else if (!local && (local = zh_search_finish_window(c->sc, l_ids, l_keys, l_counts, zh_index_sweep_stream(g->ix))))
+        local_msg = zh_last_error();
+    const double vpp = zh_index_visits_per_pair(g->ix) * zh_index_num_trees(g->ix);
+    c->h_status[g->n_ranks] = zh_shard_status_word(local, (uint32_t)std::min(vpp + 0.999, 4294967295.0));
+    hipError_t e = hipSuccess;
+    if (local) e = hipMemsetAsync(mine, 0, W * 8, c->light);  // an empty slot: every count 0, nothing for the merge to read
+    if (e == hipSuccess) e = hipMemcpyAsync(mine + W, c->h_status + g->n_ranks, 8, hipMemcpyHostToDevice, c->light);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_final, c->light);
+    if (e != hipSuccess) return cannot_join(ZH_EHIP, "status word / event", e);
     {
         std::lock_guard<std::mutex> lk(g->mu);
-        HIPCHK(hipStreamWaitEvent(c->xs, c->ev_final, 0));
-        NCCLCHK(ncclAllGather(mine, c->gathered, W, ncclUint64, g->comm, c->xs));  // in place: send == recv + rank * W
+        e = hipStreamWaitEvent(c->xs, c->ev_final, 0);
+        if (e != hipSuccess) return cannot_join(ZH_EHIP, "hipStreamWaitEvent", e);
+        ncclResult_t r = ncclAllGather(mine, c->gathered, SW, ncclUint64, g->comm, c->xs);  // in place: send == recv + rank * SW
+        if (r != ncclSuccess) {
+            kill_group(g);
+            return FAIL(ZH_EHIP, "ncclAllGather: %s; the shard group is dead", ncclGetErrorString(r));
+        }
+        // from here on the collective is enqueued: failures below only affect this rank's copy of the results
         uint64_t *m_ids = nwin > 1 ? c->merged : out_ids[0], *m_keys = nwin > 1 ? c->merged + B * k : out_keys[0];
         uint32_t *m_counts = nwin > 1 ? reinterpret_cast<uint32_t *>(c->merged + 2 * B * k) : out_counts[0];
-        if ((rc = zh_merge_topk_packed_device(g->device, g->n_ranks, B, k, c->gathered, m_ids, m_keys, m_counts, c->xs)))
-            return rc;
-        for (size_t j = 0; j < nwin && nwin > 1; j++) {
-            HIPCHK(hipMemcpyAsync(out_ids[j], m_ids + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs));
-            HIPCHK(hipMemcpyAsync(out_keys[j], m_keys + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs));
-            HIPCHK(hipMemcpyAsync(out_counts[j], m_counts + j * b, b * 4, hipMemcpyDeviceToDevice, c->xs));
+        e = zh_launch_merge(g->n_ranks, (uint32_t)B, (uint32_t)k, c->gathered, c->gathered + B * k,
+                            reinterpret_cast<const uint32_t *>(c->gathered + 2 * B * k), m_ids, m_keys, m_counts, SW, 2 * SW, c->xs);
+        for (size_t j = 0; j < nwin && nwin > 1 && e == hipSuccess; j++) {
+            e = hipMemcpyAsync(out_ids[j], m_ids + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_keys[j], m_keys + j * b * k, b * k * 8, hipMemcpyDeviceToDevice, c->xs);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_counts[j], m_counts + j * b, b * 4, hipMemcpyDeviceToDevice, c->xs);
         }
-        HIPCHK(hipEventRecord(c->ev_xdone, c->xs));
+        // every rank's status word to the host (n_ranks words, SW apart)
+        if (e == hipSuccess) e = hipMemcpy2DAsync(c->h_status, 8, c->gathered + W, SW * 8, 8, g->n_ranks, hipMemcpyDeviceToHost, c->xs);
+        hipError_t e2 = hipEventRecord(c->ev_xdone, c->xs);
+        if (e == hipSuccess) e = e2;
     }
     c->xused = true;
     c->state = 2;
+    if (e != hipSuccess) return FAIL(ZH_EHIP, "merge / result copies: %s", hipGetErrorString(e));
+    if (local) return FAIL(local, "%s (this rank still joined the exchange: every rank of the group is told)", local_msg.c_str());
     return ZH_OK;
 }
 extern "C" int zh_shard_search_finish(zh_shard_ctx *c, uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts) {
@@ -315,18 +356,74 @@ extern "C" int zh_shard_search_finish_window(zh_shard_ctx *c, uint64_t *const *d
     return shard_finish(c, d_out_ids, d_out_keys, d_out_counts);
 }
 
+// Blocks until the exchange has completed -- or has not within ZH_SHARD_TIMEOUT_MS (a peer died or could not join): then the
+// communicator is aborted and the group is dead.  Returns the group's verdict on the batch: ZH_OK, this rank's own failure,
+// or ZH_EPEER (the same outcome class on every rank).
 extern "C" int zh_shard_search_wait(zh_shard_ctx *c) {
     if (!c) return FAIL(ZH_EINVAL, "zh_shard_search_wait: null context");
     if (c->state == 1) return FAIL(ZH_ESTATE, "zh_shard_search_wait: the batch was begun but not finished");
     if (c->state != 2) return ZH_OK;
-    int rc = set_dev(c->g);
+    zh_shard_group *g = c->g;
+    int rc = set_dev(g);
     if (rc) return rc;
     c->state = 0;
-    if ((rc = zh_search_wait(c->sc))) return rc;
-    HIPCHK(hipEventSynchronize(c->ev_xdone));
-    ncclResult_t async = ncclSuccess;
-    if (ncclCommGetAsyncError(c->g->comm, &async) == ncclSuccess && async != ncclSuccess)
-        return FAIL(ZH_EHIP, "RCCL asynchronous error: %s", ncclGetErrorString(async));
+    c->verdict = ZH_OK; c->all_elimit = false;
+    const int rc_local = zh_search_wait(c->sc);  // (idle when the local search had failed)
+    static const long timeout_ms = [] { const char *e = getenv("ZH_SHARD_TIMEOUT_MS"); return e ? atol(e) : 300000L; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+        const hipError_t q = hipEventQuery(c->ev_xdone);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { kill_group(g); return c->verdict = FAIL(ZH_EHIP, "exchange: %s; the shard group is dead", hipGetErrorString(q)); }
+        if (g->dead.load()) return c->verdict = FAIL(ZH_EPEER, "the shard group died while this batch was in flight");
+        if ((spin & 63) == 63) {
+            ncclResult_t async = ncclSuccess;
+            if (ncclCommGetAsyncError(g->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                kill_group(g);
+                return c->verdict = FAIL(ZH_EPEER, "RCCL asynchronous error: %s; the shard group is dead", ncclGetErrorString(async));
+            }
+            if (timeout_ms > 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
+                kill_group(g);
+                return c->verdict = FAIL(ZH_EPEER, "the exchange did not complete within %ld ms (ZH_SHARD_TIMEOUT_MS): a rank died or could not join; "
+                                                   "the communicator was aborted, the shard group is dead", timeout_ms);
+            }
+        }
+        if (spin < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    uint32_t vmax = 0;
+    int all_el = 0;
+    const int verdict = zh_shard_verdict(c->h_status, g->n_ranks, g->rank, nullptr, &vmax, &all_el);
+    uint32_t cur = g->peer_vpq.load();
+    while (vmax > cur && !g->peer_vpq.compare_exchange_weak(cur, vmax)) {}
+    c->all_elimit = all_el != 0;
+    if (verdict) return c->verdict = verdict;
+    if (rc_local) return c->verdict = rc_local;
+    return ZH_OK;
+}
+
+// The blocking calls take any batch: the chunks are the SAME on every rank -- sized from the largest visits-per-query any rank
+// has reported (the status words of earlier exchanges), and when a chunk fails with ZH_ELIMIT on any rank (and with nothing
+// else anywhere) every rank halves it and repeats it: all ranks read the same status words, so all take the same decision.
+static int search_chunks(zh_shard_group *g, const float *d_q, size_t b, size_t k, int metric, int mode, uint64_t *d_out_ids,
+                         uint64_t *d_out_keys, uint32_t *d_out_counts) {
+    const size_t T = std::max<uint32_t>(zh_index_num_trees(g->ix), 1), d = zh_index_dim(g->ix);
+    zh_shard_ctx *c = g->dctx;
+    size_t chunk = std::min<size_t>(b, ((1ull << 26) - 1) / T);
+    const uint32_t vpq = g->peer_vpq.load();
+    if (vpq) chunk = std::min<size_t>(chunk, std::max<size_t>(1, (size_t)((1ull << 27) / vpq)));  // half the 2^28-visit cap: headroom
+    if (chunk == 0) chunk = 1;
+    for (size_t b0 = 0; b0 < b;) {
+        const size_t nb = std::min(chunk, b - b0);
+        int rc = zh_shard_search_begin(c, d_q + b0 * d, nb, k, metric, mode);
+        if (c->state != 1) return rc;  // refused before anything collective happened (bad argument, dead group)
+        rc = zh_shard_search_finish(c, d_out_ids + b0 * k, d_out_keys + b0 * k, d_out_counts + b0);
+        if (c->state != 2) return rc;  // this rank could not join: the group is dead
+        rc = zh_shard_search_wait(c);
+        if (rc && c->all_elimit && nb > 1) { chunk = (nb + 1) / 2; continue; }  // every rank repeats [b0, b0 + chunk)
+        if (rc) return rc;
+        b0 += nb;
+    }
     return ZH_OK;
 }
 
@@ -334,10 +431,8 @@ extern "C" int zh_shard_search_batch_device(zh_shard_group *g, const float *d_q,
                                             uint64_t *d_out_ids, uint64_t *d_out_keys, uint32_t *d_out_counts) {
     if (!g) return FAIL(ZH_EINVAL, "zh_shard_search_batch_device: null group");
     if (b == 0) return ZH_OK;
-    int rc = zh_shard_search_begin(g->dctx, d_q, b, k, metric, mode);
-    if (rc) return rc;
-    if ((rc = zh_shard_search_finish(g->dctx, d_out_ids, d_out_keys, d_out_counts))) return rc;
-    return zh_shard_search_wait(g->dctx);
+    if (!d_q || !d_out_ids || !d_out_keys || !d_out_counts) return FAIL(ZH_EINVAL, "zh_shard_search_batch_device: null argument");
+    return search_chunks(g, d_q, b, k, metric, mode, d_out_ids, d_out_keys, d_out_counts);
 }
 
 extern "C" int zh_shard_search_batch(zh_shard_group *g, const float *q, size_t b, size_t k, int metric, int mode,
@@ -361,14 +456,11 @@ extern "C" int zh_shard_search_batch(zh_shard_group *g, const float *q, size_t b
     }
     uint64_t *dIds = (uint64_t *)g->dOut, *dKeys = dIds + b * k;
     uint32_t *dCounts = (uint32_t *)(dKeys + b * k);
-    hipStream_t xs = g->dctx->xs;
     HIPCHK(hipMemcpy(g->dQ, q, qbytes, hipMemcpyHostToDevice));
-    if ((rc = zh_shard_search_begin(g->dctx, (const float *)g->dQ, b, k, metric, mode))) return rc;
-    if ((rc = zh_shard_search_finish(g->dctx, dIds, dKeys, dCounts))) return rc;
-    HIPCHK(hipMemcpyAsync(out_ids, dIds, b * k * 8, hipMemcpyDeviceToHost, xs));
-    HIPCHK(hipMemcpyAsync(out_keys, dKeys, b * k * 8, hipMemcpyDeviceToHost, xs));
-    HIPCHK(hipMemcpyAsync(out_counts, dCounts, b * 4, hipMemcpyDeviceToHost, xs));
-    if ((rc = zh_shard_search_wait(g->dctx))) return rc;
-    HIPCHK(hipStreamSynchronize(xs));
+    if ((rc = search_chunks(g, (const float *)g->dQ, b, k, metric, mode, dIds, dKeys, dCounts))) return rc;
+    // every chunk's exchange has completed (search_chunks waits for each): plain copies
+    HIPCHK(hipMemcpy(out_ids, dIds, b * k * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_keys, dKeys, b * k * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_counts, dCounts, b * 4, hipMemcpyDeviceToHost));
     return ZH_OK;
 }

@@ -5,13 +5,35 @@ C ABI are the raw key / value bytes.
 
     embeddings partition   key = 16 uuid bytes, value = N little-endian f32           -> `decode_embeddings`
     trees partition        key = 16 uuid bytes, value = bincode(legacy) Node<N>      -> `decode_trees` / `encode_trees`
+    the `.zebra` file      bincode(legacy) DatabaseInner (core.rs:19-29,183-190)     -> `decode_header` / `encode_header`
 """
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _ffi
-from ._ffi import check, lib
+from ._ffi import check
+
+_san = None
+
+
+def lib():
+    """libzebra_hip.so -- or, for the sanitizer run of the CPU test-suite only (tests/test_sanitizers.py sets
+    ZEBRA_REFFORMAT_SAN_LIB), this file's codec built stand-alone with gcc -fsanitize=address,undefined."""
+    global _san
+    path = os.environ.get("ZEBRA_REFFORMAT_SAN_LIB")
+    if not path:
+        return _ffi.lib()
+    if _san is None:
+        L = C.CDLL(path)
+        for name, res, args in _ffi.SYMBOLS:
+            if name.startswith("zh_ref_") or name == "zh_last_error":
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+        _ffi._lib = _ffi._lib or L  # check() reads zh_last_error through _ffi.lib()
+        _san = L
+    return _san
 
 FOREST_KEYS = ("plane", "left", "right", "roots", "planes", "consts", "leaf_ids")
 
@@ -79,3 +101,34 @@ def encode_trees(forest, dim, uuids):
         check(lib().zh_ref_tree_encode(C.byref(fv), dim, t, u.ctypes.data, u.shape[0], buf.ctypes.data, buf.size, C.byref(n)))
         out.append(buf.tobytes())
     return out
+
+
+METRIC_IDS = {"cosine": _ffi.COSINE, "l2sq": _ffi.L2SQ, "l2": _ffi.L2, "chebyshev": _ffi.CHEBYSHEV, "canberra": _ffi.CANBERRA,
+              "bray_curtis": _ffi.BRAY_CURTIS, "manhattan": _ffi.MANHATTAN, "l3": _ffi.L3, "l4": _ffi.L4, "hamming": _ffi.HAMMING,
+              "minkowski": _ffi.MINKOWSKI, "pnorm": _ffi.PNORM}
+
+
+def decode_header(blob, metric="cosine", model_len=0):
+    """The `.zebra` file (core.rs:92-102 `Database::open`): bincode(legacy) DatabaseInner { uuid, model, metric, index_options }.
+    `metric` (a name of METRIC_IDS or a zh_metric id) and `model_len` stand for the crate's type parameters Met / Mod, which
+    the file does not record.  -> dict(uuid=16 bytes, max_node_size, num_trees, metric, power, model=bytes)."""
+    m = METRIC_IDS[metric] if isinstance(metric, str) else int(metric)
+    buf = np.frombuffer(bytes(blob), np.uint8)
+    h = _ffi.RefHeader()
+    check(lib().zh_ref_header_decode(buf.ctypes.data if buf.size else None, buf.size, m, model_len, C.byref(h)))
+    return dict(uuid=bytes(h.uuid), max_node_size=int(h.max_node_size), num_trees=int(h.num_trees), metric=int(h.metric),
+                power=int(h.power), model=bytes(blob[h.model_off:h.model_off + h.model_len]))
+
+
+def encode_header(uuid16, max_node_size=5, num_trees=15, metric="cosine", power=0, model=b""):
+    """what `Database::save_database` (core.rs:183-190) writes; defaults = LSHIndexOptions::default (lsh.rs:131-138)"""
+    m = METRIC_IDS[metric] if isinstance(metric, str) else int(metric)
+    h = _ffi.RefHeader()
+    h.uuid[:] = list(bytes(uuid16))
+    h.max_node_size, h.num_trees, h.metric, h.power, h.model_off, h.model_len = max_node_size, num_trees, m, power, 24, len(model)
+    mb = np.frombuffer(bytes(model), np.uint8)
+    n = C.c_size_t()
+    check(lib().zh_ref_header_encode(C.byref(h), mb.ctypes.data if mb.size else None, None, 0, C.byref(n)))
+    out = np.empty(n.value, np.uint8)
+    check(lib().zh_ref_header_encode(C.byref(h), mb.ctypes.data if mb.size else None, out.ctypes.data, out.size, C.byref(n)))
+    return out.tobytes()
