@@ -98,6 +98,9 @@ def parse():
     ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
                     help="host loop: begin window w+1 before finishing window w (its hash runs beside w's walk).  Pays when hash + walk "
                          "outweigh the sweep (reference-default options: -8 %% per batch), costs elsewhere; auto decides from the warm-up's stage times")
+    ap.add_argument("--lookahead-depth", type=int, default=1,
+                    help="windows BEGUN ahead of the one being finished when the look-ahead loop runs (their hash and walk are enqueued on their "
+                         "own streams and run beside the current window's walk / sweep)")
     ap.add_argument("--window", type=int, default=2,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan"], default="auto",
@@ -243,13 +246,14 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     r0 = make_results()
     cur = torch.cuda.current_stream()
+    LA = max(1, args.lookahead_depth)  # extra slots of the look-ahead loop
     if group is None:
         heavy = ix.sweep_stream()
         if args.debug_normal_priority_sweeps:
             _hs = torch.cuda.Stream(device=dev, priority=0)
             heavy = _hs.cuda_stream
         slots = [dict(ctx=ix.search_context(), stream=torch.cuda.Stream(device=dev, priority=-1), res=[make_results() for _ in range(WIN)])
-                 for _ in range(NS + 1)] if pipelined else []
+                 for _ in range(NS + LA)] if pipelined else []
 
         def begin(sl, i, nw):
             sl["nw"] = nw
@@ -277,7 +281,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         hip = ctypes.CDLL("libamdhip64.so.7")
         hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
-        slots = [dict(ctx=group.search_context(), res=[make_results() for _ in range(WIN)]) for _ in range(NS + 1 if pipelined else 0)]
+        slots = [dict(ctx=group.search_context(), res=[make_results() for _ in range(WIN)]) for _ in range(NS + LA if pipelined else 0)]
 
         def begin(sl, i, nw):
             sl["nw"] = nw
@@ -363,12 +367,13 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                     if "t_begin" in sl:
                         lat.append(_window_latency(sl))
                         del sl["t_begin"]
-        else:                  # one more slot: a window begun ahead, one being finished, NS - 1 sweeping
-            begin(slots[0], *wins[0])
+        else:                  # LA more slots: LA windows begun ahead, one being finished, NS - 1 sweeping
+            for w in range(min(LA, len(wins))):
+                begin(slots[w % (NS + LA)], *wins[w])
             for w in range(len(wins)):
-                if w + 1 < len(wins):
-                    begin(slots[(w + 1) % (NS + 1)], *wins[w + 1])
-                finish(slots[w % (NS + 1)])
+                if w + LA < len(wins):
+                    begin(slots[(w + LA) % (NS + LA)], *wins[w + LA])
+                finish(slots[w % (NS + LA)])
         for sl in slots:
             drain(sl)
 
@@ -407,7 +412,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ix.stats()
-    last = slots[((steps + WIN - 1) // WIN - 1) % (NS + 1 if look["ahead"] else NS)]["res"][(steps - 1) % WIN] if pipelined else r0
+    last = slots[((steps + WIN - 1) // WIN - 1) % (NS + LA if look["ahead"] else NS)]["res"][(steps - 1) % WIN] if pipelined else r0
     last_host = (last["h_ids"].numpy().copy(), last["h_counts"].numpy().copy())
 
     # ---- untimed: R_unique of the timed batches (per internal batch = per window: a row shared by two batches of a window
@@ -491,7 +496,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                    if S > 1 else "1 GPU")},
         "roofline": roof,
         "stage_ms_per_batch": {s_: st["ms_" + s_] / n_timed for s_ in ("hash", "walk", "sweep", "select", "final")},
-        "host_loop": "look-ahead (window w+1 begun before w is finished)" if look["ahead"] else "begin + finish back to back",
+        "host_loop": ("look-ahead (windows w+1..w+%d begun before w is finished)" % LA) if look["ahead"] else "begin + finish back to back",
         "visits_per_batch": st["visits"] / max(st["window_batches"], 1), "rows_scored_per_batch": st["rows_scored"] / max(st["window_batches"], 1),
         "window_batches": WIN,
         "setup_s": {"fill": t_fill, "build": t_build},

@@ -16,12 +16,12 @@ python3 profiles/summarize.py --sha > $OUT/kernel_sources.sha
 common="--cpu-seconds 0 --no-recall --no-other-configs --profile-run"
 for c in $CFGS; do
   case $c in
-    cfg3)       args="bench.py --steps 5 --warmup 2 $common" ;;
+    cfg3)       args="bench.py --steps 6 --warmup 2 $common" ;;
     cfg2)       args="bench.py --workload cfg2 --steps 20 --warmup 3 $common" ;;
-    cfg4shard)  args="bench.py --workload cfg4 --emulate-ranks 8 --steps 5 --warmup 2 $common" ;;
-    cfg5shard)  args="bench.py --workload cfg5 --emulate-ranks 8 --steps 5 --warmup 2 $common" ;;
-    refdefault) args="bench.py --workload refdefault --steps 5 --warmup 2 $common" ;;
-    scale64m)   args="bench.py --workload scale64m --steps 3 --warmup 1 $common" ;;
+    cfg4shard)  args="bench.py --workload cfg4 --emulate-ranks 8 --steps 6 --warmup 2 $common" ;;
+    cfg5shard)  args="bench.py --workload cfg5 --emulate-ranks 8 --steps 6 --warmup 2 $common" ;;
+    refdefault) args="bench.py --workload refdefault --steps 6 --warmup 2 $common" ;;
+    scale64m)   args="bench.py --workload scale64m --steps 4 --warmup 2 $common" ;;
     hashbig)    args="profiles/hash_dense_microbench.py" ;;
     *) echo "unknown config $c"; continue ;;
   esac

@@ -13,7 +13,8 @@ make_hyperplane of the node's sample pair (lsh.rs:192-267, 411-429).
   cfg3  10M x 768 L2 top-100, batch 1024
   cfg4  100M x 768 cosine top-10, batch 1024: the 8 shards one after another on the one GPU (build, search, keep the
         packed result, destroy), then zh_merge_topk_packed_device == the oracle's 8-shard merge
-  cfg5  one full 125M x 128 shard of the 1B set, L2 top-10, batch 4096
+  cfg5  1B x 128 SIFT-style L2 top-10, batch 4096: the 8 shards of 125M rows one after another + merge, as cfg4; and one
+        full shard through the whole property list
 plus the size-independent properties: result shape, idempotence, batch-split and dense-level invariance, planted
 neighbours."""
 import numpy as np
@@ -144,8 +145,8 @@ def test_cfg3_10m_768_l2_top100_batch1024():
     _check(za, 10_000_000, 768, "l2", 100, 1024, 4096, 15, planted_min=0.6, n_exact=8)
 
 
-def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
-    """The 100M-row configuration END TO END on one GPU: rank r's shard (rows [12.5M r, 12.5M (r+1)), its own forest,
+def _eight_shards_time_multiplexed(N, d, k, B, M, T, metric_name, kind):
+    """An 8-GPU configuration END TO END on one GPU: rank r's shard (rows [N/8 r, N/8 (r+1)), its own forest,
     id_base = first row, seed + r exactly as bench.py builds it) is built, searched with the full batch and destroyed,
     one after another; the eight packed results are laid out as the all-gather would leave them and merged by
     zh_merge_topk_packed_device.  Checked: every shard's answers for 8 queries and its forest against the oracle;
@@ -154,9 +155,9 @@ def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
     import torch
     import zebra_amd as za
     from zebra_amd import sharding
-    S, N, d, k, B, M, T = 8, 100_000_000, 768, 10, 1024, 4096, 15
-    m, om, omode = _metrics(za)["cos_parity"]
-    Q = zo.synth_queries(B, d, N)
+    S = 8
+    m, om, omode = _metrics(za)[metric_name]
+    Q = zo.synth_queries(B, d, N, kind=kind)
     sel = np.unique(np.linspace(0, B - 1, 8).astype(int))
     W = za.packed_result_words(B, k)
     dev = torch.device("cuda", 0)
@@ -169,7 +170,7 @@ def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
         first, n = sharding.shard_rows(N, S, r)
         ix = za.LSHIndex(d, za.LSHIndexOptions(sharding.per_shard_max_node_size(M * S, S, k), T), seed=SEED_INDEX + r,
                          id_base=first, reserve_rows=n)
-        ix.append_synthetic(n, first_row=first)
+        ix.append_synthetic(n, first_row=first, kind=kind)
         ix.build()
         p_ids, p_keys, p_counts = sharding.packed_views(torch, g_packed[r], B, k)
         ix.search_batch_device(dq.data_ptr(), B, k, m, p_ids.data_ptr(), p_keys.data_ptr(), p_counts.data_ptr())
@@ -178,7 +179,7 @@ def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
         keys = p_keys.cpu().numpy().view(np.uint64)
         counts = p_counts.cpu().numpy().view(np.uint32)
         assert (counts == k).all() and ids.min() >= first and ids.max() < first + n
-        o_ids[r], o_keys[r], o_counts[r], _ = _exact_vs_oracle(ix, n, d, M, Q, sel, k, om, omode, ids, keys, counts, first, 0,
+        o_ids[r], o_keys[r], o_counts[r], _ = _exact_vs_oracle(ix, n, d, M, Q, sel, k, om, omode, ids, keys, counts, first, kind,
                                                                index_seed=SEED_INDEX + r, n_sample=8)
         ix.close()
     m_ids = torch.empty((B, k), dtype=torch.int64, device=dev)
@@ -188,18 +189,30 @@ def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
     torch.cuda.synchronize()
     got_i, got_k, got_c = (m_ids.cpu().numpy().view(np.uint64), m_keys.cpu().numpy().view(np.uint64),
                            m_counts.cpu().numpy().view(np.uint32))
-    # (1) the merge kernel on all 1024 queries == the oracle's merge of the eight device results
+    # (1) the merge kernel on all queries == the oracle's merge of the eight device results
     hp = g_packed.cpu().numpy()
     s_ids = np.stack([hp[r, :B * k].reshape(B, k) for r in range(S)]).view(np.uint64)
     s_keys = np.stack([hp[r, B * k:2 * B * k].reshape(B, k) for r in range(S)]).view(np.uint64)
     s_counts = np.stack([hp[r, 2 * B * k:].view(np.uint32)[:B] for r in range(S)])
     wi, wk, wc = zo.merge_topk(s_ids, s_keys, s_counts, k)
     assert (got_c == wc).all() and (got_i == wi).all() and (got_k == wk).all()
-    # (2) the 100M answer of the selected queries == the all-oracle pipeline
+    # (2) the whole set's answer of the selected queries == the all-oracle pipeline
     ai, ak, ac = zo.merge_topk(o_ids, o_keys, o_counts, k)
     assert (got_c[sel] == ac).all() and (got_i[sel] == ai).all() and (got_k[sel] == ak).all()
-    # the merged ids are global rows of the 100M set, from more than one shard overall
+    # the merged ids are global rows of the whole set, from more than one shard overall
     assert got_i.max() < N and len(np.unique(got_i // np.uint64(N // S))) > 1
+    return got_i, got_k
+
+
+def test_cfg4_100m_768_cosine_top10_batch1024_eight_shards_time_multiplexed():
+    _eight_shards_time_multiplexed(100_000_000, 768, 10, 1024, 4096, 15, "cos_parity", 0)
+
+
+def test_cfg5_1b_128d_sift_l2_top10_batch4096_eight_shards_time_multiplexed():
+    """the 1B-row answer formed and compared -- all eight 125M x 128 shards (64 GB each) one after another,
+    merged, against the oracle's eight-shard merge.  Integer-valued rows: every L2^2 is exact in f32 under any order."""
+    ids, keys = _eight_shards_time_multiplexed(1_000_000_000, 128, 10, 4096, 8192, 15, "l2", 1)
+    assert (np.diff(keys.astype(np.float64), axis=1) >= 0).all()
 
 
 def test_cfg5_full_shard_125m_128d_sift_l2_top10_batch4096():

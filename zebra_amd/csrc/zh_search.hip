@@ -26,8 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // The canonical 64-lane xor-butterfly (steps 1,2,4,8,16,32; lane l adds its partner group's value).  After a step
 // every lane of a 2^k group holds the same value, so the partner may be ANY lane of the partner group: steps 1,2 are
-// DPP quad_perm, 4 and 8 DPP row_half_mirror / row_mirror, 16 one ds_swizzle, 32 two v_readlane -- no ds_bpermute,
-// bit-identical to s + __shfl_xor(s, m).
+// DPP quad_perm, 4 and 8 DPP row_half_mirror / row_mirror, 16 and 32 gfx950's v_permlane16_swap / v_permlane32_swap (a
+// register-to-register exchange of 16- / 32-lane rows: both operands = s gives {my row pair's first value, its second} in
+// the two results, and a + b == b + a bit for bit, as is max) -- no LDS round trip (round 2 used ds_swizzle for 16 and two
+// v_readlane for 32: an lgkmcnt wait per scored (row, query) pair), no ds_bpermute; bit-identical to s + __shfl_xor(s, m).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
@@ -35,15 +37,19 @@ __device__ __forceinline__ float dpp_mov(float x) {
 struct OpAdd { __device__ __forceinline__ static float f(float a, float b) { return a + b; } };
 struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
 template <class OP>
+__device__ __forceinline__ float xor16(float s) {  // every lane: OP(value of the even 16-lane row of its pair, value of the odd one)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return OP::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <class OP>
 __device__ __forceinline__ float wave_butterfly(float s) {
     s = OP::f(s, dpp_mov<0xB1>(s));   // quad_perm [1,0,3,2]  : xor 1
     s = OP::f(s, dpp_mov<0x4E>(s));   // quad_perm [2,3,0,1]  : xor 2
     s = OP::f(s, dpp_mov<0x141>(s));  // row_half_mirror      : other quad of the 8
     s = OP::f(s, dpp_mov<0x140>(s));  // row_mirror           : other 8 of the 16
-    s = OP::f(s, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F)));  // xor 16
-    float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
-    float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
-    return OP::f(s, (threadIdx.x & 32) ? lo : hi);  // xor 32
+    s = xor16<OP>(s);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);  // {lanes 0..31's value, lanes 32..63's}
+    return OP::f(__uint_as_float(r[0]), __uint_as_float(r[1]));  // xor 32
 }
 __device__ __forceinline__ float wave_sum_canonical(float s) { return wave_butterfly<OpAdd>(s); }
 __device__ __forceinline__ uint64_t f64_bits(double x) { return (uint64_t)__double_as_longlong(x); }
@@ -1148,7 +1154,8 @@ hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupR
 __device__ __forceinline__ void resolve_flat_rows(uint64_t r0, uint32_t cnt, uint32_t lane, const ZhGroup *__restrict__ groups,
                                                   const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
                                                   const uint32_t *__restrict__ waveGroup, const uint32_t *__restrict__ leaf_ids,
-                                                  uint32_t &my_g, uint32_t &my_id, uint32_t &my_within) {
+                                                  uint32_t &my_g, uint32_t &my_id, uint32_t &my_within,
+                                                  uint32_t *my_leaf_off = nullptr, uint32_t *my_len = nullptr) {
     const uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
     uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
     if (waveGroup) {
@@ -1163,6 +1170,8 @@ __device__ __forceinline__ void resolve_flat_rows(uint64_t r0, uint32_t cnt, uin
     my_g = (uint32_t)lo;
     my_within = (uint32_t)(r - groupRowOff[lo]);
     const uint32_t lo_off = groups[lo].leaf_off;
+    if (my_leaf_off) *my_leaf_off = lo_off;
+    if (my_len) *my_len = groups[lo].len;
     my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
 }
 
@@ -1347,11 +1356,16 @@ __device__ __forceinline__ float half_sum_canonical(float s) {
     s = s + dpp_mov<0x4E>(s);   // xor 2
     s = s + dpp_mov<0x141>(s);  // other quad of the 8
     s = s + dpp_mov<0x140>(s);  // other 8 of the 16
-    s = s + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));  // xor 16 (inside a 32-lane half)
+    s = xor16<OpAdd>(s);        // xor 16 (inside a 32-lane half)
     return s + 0.0f;            // xor 32: lanes 32..63 of a 128-d row hold no elements
 }
 
-template <int KIND, int G, int RG, bool NT>
+// A wave takes CH consecutive 64-row chunks.  Resolving a chunk (wave-start table -> group offsets -> group record -> leaf ids)
+// is a chain of four dependent loads, ~3 us before the first row load can go out -- a third of the life of a wave that then
+// streams 32 KB (profiles/micro/gather512.hip: the bare gather of random 512-byte rows runs at 6.55 TB/s, this kernel with
+// one chunk per wave at 5.3-5.5).  Chunks after the first usually continue in the group the previous chunk ended in (leaves
+// hold thousands of rows): their ids are then ONE independent load, issued before the current chunk is streamed.
+template <int KIND, int G, int RG, bool NT, int CH>
 __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__ X, const float *__restrict__ Q,
                                                         const float *__restrict__ QQ, const ZhGroup *__restrict__ groups,
                                                         const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
@@ -1363,77 +1377,106 @@ __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__
     const uint32_t lane = threadIdx.x & 63, hl = lane & 31;
     const bool up = lane >= 32;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t r0 = row_begin + wave * 64;
+    uint64_t r0 = row_begin + wave * (64 * CH);
     if (r0 >= R_grouped) return;
-    const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
-    uint32_t my_g, my_id, my_within;
-    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
+    uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+    uint32_t my_g, my_id, my_within, my_off, my_len;
+    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
     const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
     const float4 *__restrict__ Q4 = reinterpret_cast<const float4 *>(Q);
-    float mine0[G], mine1 = 0.f;
     float4 q[G];
 #pragma unroll
-    for (int m = 0; m < G; m++) { mine0[m] = 0.f; q[m] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int m = 0; m < G; m++) q[m] = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t cur_g = 0xFFFFFFFFu, gsize = 0;  // per half
-    const uint32_t npair = cnt < 32 ? cnt : 32;  // pair j = flat rows j (lower half) and j + 32 (upper half, if < cnt)
-    for (uint32_t j0 = 0; j0 < npair; j0 += RG) {
-        float4 v[RG];
-#pragma unroll
-        for (int r = 0; r < RG; r++) {
-            const uint32_t j = j0 + r < npair ? j0 + r : npair - 1;
-            const uint32_t jh = j + 32 < cnt ? j + 32 : cnt - 1;
-            const uint32_t idl = __builtin_amdgcn_readlane(my_id, j), idh = __builtin_amdgcn_readlane(my_id, jh);
-            v[r] = ld16<NT>(X4 + (size_t)(up ? idh : idl) * 32 + hl);
+    for (int c = 0; c < CH; c++) {
+        // the next chunk: does it lie entirely in the group this chunk's last row belongs to?  (wave-uniform)
+        const uint64_t r0n = r0 + 64;
+        const bool have_next = c + 1 < CH && r0n < R_grouped;
+        const uint32_t cntn = have_next ? (uint32_t)(R_grouped - r0n < 64 ? R_grouped - r0n : 64) : 0;
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)my_within, (int)cnt - 1) + 1;  // position after this chunk's last row
+        const uint32_t loff = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)cnt - 1);
+        const uint32_t llen = (uint32_t)__builtin_amdgcn_readlane((int)my_len, (int)cnt - 1);
+        const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)cnt - 1);
+        const bool fast = have_next && cnt == 64 && (uint64_t)lw + cntn <= llen;
+        uint32_t nxt_id = 0;
+        if (fast) {
+            const uint32_t wn = lw + (lane < cntn ? lane : cntn - 1);
+            nxt_id = leaf_ids ? leaf_ids[(size_t)loff + wn] : loff + wn;  // in flight while this chunk is streamed
         }
+        float mine0[G], mine1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < RG; r++) {
-            const uint32_t j = j0 + r;
-            if (j < npair) {
+        for (int m = 0; m < G; m++) mine0[m] = 0.f;
+        const uint32_t npair = cnt < 32 ? cnt : 32;  // pair j = flat rows j (lower half) and j + 32 (upper half, if < cnt)
+        for (uint32_t j0 = 0; j0 < npair; j0 += RG) {
+            float4 v[RG];
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const uint32_t j = j0 + r < npair ? j0 + r : npair - 1;
                 const uint32_t jh = j + 32 < cnt ? j + 32 : cnt - 1;
-                const uint32_t gl = __builtin_amdgcn_readlane(my_g, j), gh = __builtin_amdgcn_readlane(my_g, jh);
-                const uint32_t g = up ? gh : gl;
-                if (g != cur_g) {  // uniform inside a half
-                    cur_g = g;
-                    gsize = groups[g].gsize;
+                const uint32_t idl = __builtin_amdgcn_readlane(my_id, j), idh = __builtin_amdgcn_readlane(my_id, jh);
+                v[r] = ld16<NT>(X4 + (size_t)(up ? idh : idl) * 32 + hl);
+            }
 #pragma unroll
-                    for (int m = 0; m < G; m++)
-                        if ((uint32_t)m < gsize) q[m] = Q4[(size_t)groups[g].b[m] * 32 + hl];
-                }
-                float a2 = 0.f;
-                if (KIND == K_COS) {
-                    float4 c;
-                    c.x = __builtin_fmaf(v[r].x, v[r].x, 0.f); c.y = __builtin_fmaf(v[r].y, v[r].y, 0.f);
-                    c.z = __builtin_fmaf(v[r].z, v[r].z, 0.f); c.w = __builtin_fmaf(v[r].w, v[r].w, 0.f);
-                    a2 = half_sum_canonical((c.x + c.y) + (c.z + c.w));
-                }
-                float s0[G];
+            for (int r = 0; r < RG; r++) {
+                const uint32_t j = j0 + r;
+                if (j < npair) {
+                    const uint32_t jh = j + 32 < cnt ? j + 32 : cnt - 1;
+                    const uint32_t gl = __builtin_amdgcn_readlane(my_g, j), gh = __builtin_amdgcn_readlane(my_g, jh);
+                    const uint32_t g = up ? gh : gl;
+                    if (g != cur_g) {  // uniform inside a half
+                        cur_g = g;
+                        gsize = groups[g].gsize;
 #pragma unroll
-                for (int m = 0; m < G; m++) {
-                    s0[m] = 0.f;
-                    if ((uint32_t)m < gsize) {
-                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                        float e = 0.f;
-                        acc_elem<KIND>(v[r].x, q[m].x, a.x, e, param);
-                        acc_elem<KIND>(v[r].y, q[m].y, a.y, e, param);
-                        acc_elem<KIND>(v[r].z, q[m].z, a.z, e, param);
-                        acc_elem<KIND>(v[r].w, q[m].w, a.w, e, param);
-                        s0[m] = half_sum_canonical((a.x + a.y) + (a.z + a.w));
+                        for (int m = 0; m < G; m++)
+                            if ((uint32_t)m < gsize) q[m] = Q4[(size_t)groups[g].b[m] * 32 + hl];
                     }
-                }
-                if (hl == j) {  // lane j holds flat row j, lane 32 + j flat row j + 32
+                    float a2 = 0.f;
+                    if (KIND == K_COS) {
+                        float4 cc;
+                        cc.x = __builtin_fmaf(v[r].x, v[r].x, 0.f); cc.y = __builtin_fmaf(v[r].y, v[r].y, 0.f);
+                        cc.z = __builtin_fmaf(v[r].z, v[r].z, 0.f); cc.w = __builtin_fmaf(v[r].w, v[r].w, 0.f);
+                        a2 = half_sum_canonical((cc.x + cc.y) + (cc.z + cc.w));
+                    }
+                    float s0[G];
 #pragma unroll
-                    for (int m = 0; m < G; m++) mine0[m] = s0[m];
-                    mine1 = a2;
+                    for (int m = 0; m < G; m++) {
+                        s0[m] = 0.f;
+                        if ((uint32_t)m < gsize) {
+                            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                            float e = 0.f;
+                            acc_elem<KIND>(v[r].x, q[m].x, a.x, e, param);
+                            acc_elem<KIND>(v[r].y, q[m].y, a.y, e, param);
+                            acc_elem<KIND>(v[r].z, q[m].z, a.z, e, param);
+                            acc_elem<KIND>(v[r].w, q[m].w, a.w, e, param);
+                            s0[m] = half_sum_canonical((a.x + a.y) + (a.z + a.w));
+                        }
+                    }
+                    if (hl == j) {  // lane j holds flat row j, lane 32 + j flat row j + 32
+#pragma unroll
+                        for (int m = 0; m < G; m++) mine0[m] = s0[m];
+                        mine1 = a2;
+                    }
                 }
             }
         }
-    }
-    if (lane < cnt) {
-        const ZhGroup grp = groups[my_g];
+        if (lane < cnt) {
+            // only the fields the keys need (the 64-byte group record per lane was four 16-byte load instructions per chunk
+            // on a kernel whose texture addresser is ~80 % busy with the rows)
+            const ZhGroup *grp = groups + my_g;
+            const uint32_t gs = grp->gsize;
 #pragma unroll
-        for (int m = 0; m < G; m++)
-            if ((uint32_t)m < grp.gsize)
-                keys[grp.key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1, KIND == K_COS ? QQ[grp.b[m]] : 0.f);
+            for (int m = 0; m < G; m++)
+                if ((uint32_t)m < gs)
+                    keys[grp->key_off[m] + my_within] = key_of(metric, param, mine0[m], mine1, KIND == K_COS ? QQ[grp->b[m]] : 0.f);
+        }
+        if (!have_next) break;
+        r0 = r0n; cnt = cntn;
+        if (fast) {  // the same group continues: nothing to search
+            my_g = lg; my_off = loff; my_len = llen;
+            my_within = lw + (lane < cntn ? lane : cntn - 1);
+            my_id = nxt_id;
+        } else
+            resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
     }
 }
 
@@ -1470,11 +1513,16 @@ static hipError_t launch_sweep_g(const SweepArgs &a) {
         const dim3 grid((uint32_t)blocks), blk(256);
         if constexpr (D == 128 && (KIND == K_L2 || KIND == K_COS)) {
             if (v128 > 0) {
-#define ZH_S128(RG_) hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true>), grid, blk, 0, a.s, a.dX, a.dQ, a.dQQ, a.dGroups, \
-                                        a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys)
-                if (v128 == 4) ZH_S128(4);
-                else if (v128 == 16) ZH_S128(16);
-                else ZH_S128(8);
+                // ZH_SWEEP128_CHUNKS (A/B): 64-row chunks per wave, 1 = the round-2 kernel's shape
+                static const int ch128 = [] { const char *e = getenv("ZH_SWEEP128_CHUNKS"); return e ? atoi(e) : 4; }();
+#define ZH_S128(RG_, CH_) do { const uint64_t w_ = (r_end - r + 64 * CH_ - 1) / (64 * CH_);                                          \
+                               hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true, CH_>), dim3((uint32_t)((w_ + 3) / 4)), blk, 0, a.s, a.dX, a.dQ, a.dQQ, \
+                                                  a.dGroups, a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys); } while (0)
+                if (ch128 == 1) ZH_S128(8, 1);
+                else if (ch128 == 8) ZH_S128(8, 8);
+                else if (v128 == 4) ZH_S128(4, 4);
+                else if (v128 == 16) ZH_S128(16, 4);
+                else ZH_S128(8, 4);
 #undef ZH_S128
                 continue;
             }
