@@ -3,7 +3,9 @@
 // every scored row is a random 512-byte read).  The loop is the sweep's access shape and nothing else: a wave owns 64 row ids;
 // lanes 0..31 load 16 bytes each of row j, lanes 32..63 of row j + 32 (one 1-KiB wave instruction = two 512-byte rows), RG
 // instructions in flight; the data is folded into one register so that the loads cannot be dropped.
-//   hipcc --offload-arch=gfx950 -O3 gather512.hip -o gather512 && ./gather512 [table_GB] > gather512.csv
+//   hipcc --offload-arch=gfx950 -O3 gather512.hip -o gather512 && ./gather512 [table_GB] [t] > gather512.csv
+// A table that fits the L2s (./gather512 0.003 t, 0.006 t, 0.012 t: the 3 / 6 / 12 MB of a window's 768-d queries; `t` = plain
+// temporal loads, as the table scan's query fetches) measures the L2 -> CU operand ceiling of the scan's access shape instead.
 // CSV columns: row_bytes, table_GB, order, rows_in_flight_per_wave, waves_per_block, rows, ms, TB_per_s
 // order: random = every id uniform over the table (what a leaf's ids are); sorted = the same ids of one launch sorted ascending
 // (what sorting a launch's groups by leaf address could at best approach); run64 = random runs of 64 consecutive rows (rows
@@ -18,7 +20,9 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldnt(const float4 *p) {  // global_load_dwordx4 ... nt, as the sweep's row loads
+__constant__ int g_temporal;
+__device__ __forceinline__ float4 ldnt(const float4 *p) {  // global_load_dwordx4 ... nt, as the sweep's row loads (or plain)
+    if (g_temporal) return *p;
     f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
     return make_float4(t.x, t.y, t.z, t.w);
 }
@@ -81,17 +85,19 @@ static void run(const float4 *dX, size_t table_rows, double table_gb, const char
     hipEventElapsedTime(&ms, a, b);
     ms /= reps;
     const int in_flight = ROW16 == 32 ? 2 * RG : RG;
-    printf("%d,%.1f,%s,%d,4,%llu,%.3f,%.3f\n", ROW16 * 16, table_gb, order, in_flight, (unsigned long long)n, ms, (double)n * ROW16 * 16 / (ms * 1e-3) / 1e12);
+    printf("%d,%.4f,%s,%d,4,%llu,%.3f,%.3f\n", ROW16 * 16, table_gb, order, in_flight, (unsigned long long)n, ms, (double)n * ROW16 * 16 / (ms * 1e-3) / 1e12);
     fflush(stdout);
     hipEventDestroy(a); hipEventDestroy(b);
 }
 
 int main(int argc, char **argv) {
     const double table_gb = argc > 1 ? atof(argv[1]) : 64.0;
+    const int temporal = argc > 2 && argv[2][0] == 't';
+    hipMemcpyToSymbol(HIP_SYMBOL(g_temporal), &temporal, sizeof(int));
     const size_t bytes = (size_t)(table_gb * 1e9) / 3072 * 3072;
     float4 *dX;
     if (hipMalloc(&dX, bytes) != hipSuccess) { fprintf(stderr, "hipMalloc(%zu) failed\n", bytes); return 1; }
-    hipMemset(dX, 0, bytes);
+    hipMemset(dX, 0x3c, bytes);  // (any non-zero pattern: nothing compresses or short-cuts a zero page)
     const uint64_t n_ids = 24u << 20;  // rows per launch, as one ~12-GB launch of the sweep at d = 128
     uint32_t *dIds; float *dOut;
     hipMalloc(&dIds, n_ids * 4); hipMalloc(&dOut, (n_ids / 64 + 8) * 4);

@@ -149,6 +149,41 @@ __device__ __forceinline__ void acc_elem(float a, float q, float &x0, float &x1,
         else x0 = x0 + powi_f32(ad, power);
     }
 }
+// Four consecutive elements of a lane (one float4 of the row against one of the query) into the lane's four accumulators.
+// The two simsimd kinds use gfx950's PACKED f32 instructions (v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per lane and
+// instruction, the only way to the f32 VALU peak): (x, y) and (z, w) are aligned register pairs of the loaded float4, every
+// component is the same fused / unfused operation as the scalar form, so the sums are bit-identical -- at half the vector
+// instructions (the table scan spends 13-20 % of its time on them: a build without the arithmetic, profiles/r03_ab_scan_*).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__device__ __forceinline__ void acc4(const float4 &v, const float4 &q, float4 &a, float4 &e, int power) {
+    if constexpr (KIND == K_L2 || KIND == K_COS) {
+        const f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w}, q0 = {q.x, q.y}, q1 = {q.z, q.w};
+        f32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w};
+        if constexpr (KIND == K_L2) {
+            const f32x2 d0 = v0 - q0, d1 = v1 - q1;
+            a0 = __builtin_elementwise_fma(d0, d0, a0);
+            a1 = __builtin_elementwise_fma(d1, d1, a1);
+        } else {
+            a0 = __builtin_elementwise_fma(v0, q0, a0);
+            a1 = __builtin_elementwise_fma(v1, q1, a1);
+        }
+        a.x = a0.x; a.y = a0.y; a.z = a1.x; a.w = a1.y;
+    } else {
+        acc_elem<KIND>(v.x, q.x, a.x, e.x, power);
+        acc_elem<KIND>(v.y, q.y, a.y, e.y, power);
+        acc_elem<KIND>(v.z, q.z, a.z, e.z, power);
+        acc_elem<KIND>(v.w, q.w, a.w, e.w, power);
+    }
+}
+// c += v * v, component-wise (the stored row's squared norm for cosine), packed
+__device__ __forceinline__ void sq4(const float4 &v, float4 &c) {
+    const f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w};
+    f32x2 c0 = {c.x, c.y}, c1 = {c.z, c.w};
+    c0 = __builtin_elementwise_fma(v0, v0, c0);
+    c1 = __builtin_elementwise_fma(v1, v1, c1);
+    c.x = c0.x; c.y = c0.y; c.z = c1.x; c.w = c1.y;
+}
 template <int KIND>
 __device__ __forceinline__ float wave_combine(float x, float y, float z, float w) {
     if (KIND == K_MAX) return wave_butterfly<OpMax>(fmaxf(fmaxf(x, y), fmaxf(z, w)));
@@ -1213,10 +1248,7 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-            if (act) {
-                c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
-                c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
-            }
+            if (act) sq4(v[j], c);
         }
         s1[0] = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
     }
@@ -1227,12 +1259,7 @@ __device__ __forceinline__ void row_sums_group(const float4 *v, const float4 (*q
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-                if (act) {
-                    acc_elem<KIND>(v[j].x, q[m][j].x, a.x, e.x, power);
-                    acc_elem<KIND>(v[j].y, q[m][j].y, a.y, e.y, power);
-                    acc_elem<KIND>(v[j].z, q[m][j].z, a.z, e.z, power);
-                    acc_elem<KIND>(v[j].w, q[m][j].w, a.w, e.w, power);
-                }
+                if (act) acc4<KIND>(v[j], q[m][j], a, e, power);
             }
             s0[m] = wave_combine<KIND>(a.x, a.y, a.z, a.w);
             if (KIND == K_BRAY) s1[m] = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
@@ -1442,12 +1469,8 @@ __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__
                     for (int m = 0; m < G; m++) {
                         s0[m] = 0.f;
                         if ((uint32_t)m < gsize) {
-                            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                            float e = 0.f;
-                            acc_elem<KIND>(v[r].x, q[m].x, a.x, e, param);
-                            acc_elem<KIND>(v[r].y, q[m].y, a.y, e, param);
-                            acc_elem<KIND>(v[r].z, q[m].z, a.z, e, param);
-                            acc_elem<KIND>(v[r].w, q[m].w, a.w, e, param);
+                            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+                            acc4<KIND>(v[r], q[m], a, e, param);
                             s0[m] = half_sum_canonical((a.x + a.y) + (a.z + a.w));
                         }
                     }
@@ -1683,12 +1706,7 @@ __device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, 
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-        if (act) {
-            acc_elem<KIND>(v[j].x, q[j].x, a.x, e.x, power);
-            acc_elem<KIND>(v[j].y, q[j].y, a.y, e.y, power);
-            acc_elem<KIND>(v[j].z, q[j].z, a.z, e.z, power);
-            acc_elem<KIND>(v[j].w, q[j].w, a.w, e.w, power);
-        }
+        if (act) acc4<KIND>(v[j], q[j], a, e, power);
     }
     s0 = wave_combine<KIND>(a.x, a.y, a.z, a.w);
     if (KIND == K_BRAY) s1 = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
@@ -1769,8 +1787,15 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
     auto flush = [&]() {
         // keys are written once and read once, much later, by the select kernel: non-temporal, so that 8-byte stores to
         // 64 different lines do not push the queries out of L2
-        if (lane < npend)
-            __builtin_nontemporal_store(key_of(metric, param, my_s0, my_s1, KIND == K_COS ? QQ[my_b] : 0.f), keys + my_slot);
+        // (the kind is a template parameter: for the two simsimd kinds only their own finaliser is compiled in, not key_of's switch
+        // over every metric)
+        if (lane < npend) {
+            uint64_t key;
+            if constexpr (KIND == K_COS) key = key_cosine(my_s0, my_s1, QQ[my_b], param);
+            else if constexpr (KIND == K_L2) key = key_l2(my_s0, metric);
+            else key = key_of(metric, param, my_s0, my_s1, 0.f);
+            __builtin_nontemporal_store(key, keys + my_slot);
+        }
         npend = 0;
     };
     auto row_norm = [&](const float4 *v) {  // cosine: the stored row's a2, once per row
@@ -1778,10 +1803,7 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-            if (act) {
-                c.x = __builtin_fmaf(v[j].x, v[j].x, c.x); c.y = __builtin_fmaf(v[j].y, v[j].y, c.y);
-                c.z = __builtin_fmaf(v[j].z, v[j].z, c.z); c.w = __builtin_fmaf(v[j].w, v[j].w, c.w);
-            }
+            if (act) sq4(v[j], c);
         }
         return wave_sum_canonical((c.x + c.y) + (c.z + c.w));
     };
@@ -1821,24 +1843,35 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const float *__restrict
             return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)r.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y),
                               (uint32_t)__builtin_amdgcn_readfirstlane((int)r.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w));
         };
-        // Rows with pairs are taken FOUR at a time (their loads go out together: one HBM round trip per four rows, the
-        // in-order return of a wave's loads would otherwise stall every later query load behind each row); the pairs of those
-        // rows follow in list order, the query of pair p + 1 on its way from L2 while pair p is scored.
-        float4 qc[NV], qn[NV];
-        uint4 rec = rd(0), recn = rec;
+        // ---- phase 2: rows with pairs FOUR at a time (one HBM round trip per four rows, as the generic kernel), and the pairs
+        // of a row FOUR at a time: the four queries are requested together and scored as they arrive.  Round 2's loop had ONE
+        // query on its way while the current pair was scored and copied it into place afterwards -- a wait for the younger load
+        // at the end of every pair.  Measured (cfg3, window 2): 6.93 -> 6.83 ms per launch, +1.5 % -- the latency of the pair
+        // loop is NOT what bounds this kernel (profiles/r03_ab_scan_pairs_in_flight.txt).  (A ring that refills a slot right
+        // after its pair was scored keeps four queries in flight ALL the time, but its loads sit in conditional blocks -- row
+        // switches, tails -- where the compiler's static count of outstanding loads collapses to "drain everything", or it
+        // selects between register arrays through temporaries it then waits for: three formulations compiled to a drained
+        // pipeline; this one needs nothing from the compiler but vmcnt(0).)
+        float4 qa[NV], qb[NV], qc[NV], qd[NV];
         uint32_t p = 0;
-        load_row<D>(Q + (size_t)rec.y * D, lane, qc);
         auto segment = [&](const float4 *vr, float a2, uint32_t rowid) {
-            while (p < P && rec.x == rowid) {
-                const bool more = p + 1 < P;
-                if (more) { recn = rd(p + 1); load_row<D>(Q + (size_t)recn.y * D, lane, qn); }
-                score(vr, a2, rec.y, ((uint64_t)rec.w << 32) | rec.z, qc);
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < NV; j++) qc[j] = qn[j];
-                    rec = recn;
-                }
-                p++;
+            for (;;) {
+                // the next four list entries (past the end: the last entry again) and which of them belong to this row
+                const uint4 ra = rd(p < P ? p : P - 1), rb = rd(p + 1 < P ? p + 1 : P - 1), rc = rd(p + 2 < P ? p + 2 : P - 1),
+                            rdd = rd(p + 3 < P ? p + 3 : P - 1);
+                const bool ha = p < P && ra.x == rowid, hb = ha && p + 1 < P && rb.x == rowid, hc = hb && p + 2 < P && rc.x == rowid,
+                           hd = hc && p + 3 < P && rdd.x == rowid;
+                if (!ha) return;
+                load_row<D>(Q + (size_t)ra.y * D, lane, qa);
+                if (hb) load_row<D>(Q + (size_t)rb.y * D, lane, qb);
+                if (hc) load_row<D>(Q + (size_t)rc.y * D, lane, qc);
+                if (hd) load_row<D>(Q + (size_t)rdd.y * D, lane, qd);
+                score(vr, a2, ra.y, ((uint64_t)ra.w << 32) | ra.z, qa);
+                if (hb) score(vr, a2, rb.y, ((uint64_t)rb.w << 32) | rb.z, qb);
+                if (hc) score(vr, a2, rc.y, ((uint64_t)rc.w << 32) | rc.z, qc);
+                if (hd) score(vr, a2, rdd.y, ((uint64_t)rdd.w << 32) | rdd.z, qd);
+                p += hd ? 4u : (hc ? 3u : (hb ? 2u : 1u));
+                if (!hd) return;
             }
         };
         while (rowmask) {
@@ -2011,12 +2044,8 @@ __global__ __launch_bounds__(256) void scan128_sweep_kernel(const float *__restr
                     c.z = __builtin_fmaf(v.z, v.z, 0.f); c.w = __builtin_fmaf(v.w, v.w, 0.f);
                     a2 = half_sum_canonical((c.x + c.y) + (c.z + c.w));
                 }
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                float e1 = 0.f;
-                acc_elem<KIND>(v.x, qc.x, a.x, e1, param);
-                acc_elem<KIND>(v.y, qc.y, a.y, e1, param);
-                acc_elem<KIND>(v.z, qc.z, a.z, e1, param);
-                acc_elem<KIND>(v.w, qc.w, a.w, e1, param);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e1 = a;
+                acc4<KIND>(v, qc, a, e1, param);
                 const float s0 = half_sum_canonical((a.x + a.y) + (a.z + a.w));
                 if (hl == npl) {
                     my_s0 = s0; my_s1 = a2; my_b = rec.y;
