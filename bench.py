@@ -71,10 +71,11 @@ WORKLOADS = {
     "tiny": dict(rows=200_000, dim=768, metric="l2", k=100, batch=256, M=1024, T=15, kind=0,
                  desc="200k x 768-d L2 top-100 (debug)"),
 }
-# what the N = 1 run measures besides `value`: (key, workload, shards it is one of, steps)
+# what the N = 1 run measures besides `value`: (key, workload, shards it is one of, steps[, window])
+# cfg3_window_of_one: the bench line's workload with every batch its own internal batch -- the latency / throughput trade of --window
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
-OTHER_CONFIGS = [("cfg2", "cfg2", 1, 40), ("cfg4_one_of_8_shards", "cfg4", 8, 12), ("cfg5_one_of_8_shards", "cfg5", 8, 12),
-                 ("reference_default_options", "refdefault", 1, 8), ("scale64m_n1", "scale64m", 1, 6)]
+OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg2", "cfg2", 1, 40), ("cfg4_one_of_8_shards", "cfg4", 8, 12),
+                 ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 8), ("scale64m_n1", "scale64m", 1, 6)]
 
 
 def parse():
@@ -182,7 +183,7 @@ class Env:
 
 
 def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_override=None, rows_override=None,
-                 batch_override=None, kind_override=None):
+                 batch_override=None, kind_override=None, window_override=None):
     """Build rank `rank`'s shard of an S-way sharding of workload `name` on this GPU, time `steps` batches, and return
     the result fields.  exchange: a ShardGroup is created (world ranks when S == world > 1, else ONE rank) and every
     batch goes through zh_shard_search_* (local search + all-gather + merge)."""
@@ -219,7 +220,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     pipelined = not args.no_pipeline
     NS = max(2, args.in_flight)
-    WIN = max(1, args.window) if pipelined else 1
+    WIN = max(1, window_override or args.window) if pipelined else 1
     if args.profile_run and pipelined:
         warmup = (warmup + WIN - 1) // WIN * WIN  # whole windows only: every sweep launch of the process is a full-window launch
     n_batches = steps + warmup
@@ -726,10 +727,10 @@ def main():
     if S == 1 and env.world == 1 and not args.no_other_configs and name == "cfg3" and not args.rows:
         other = {}
         only = set(args.only_other.split(",")) if args.only_other else None
-        for key, wname, shards, steps in OTHER_CONFIGS:
+        for key, wname, shards, steps, *win in OTHER_CONFIGS:
             if only and key not in only:
                 continue
-            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=False)
+            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=False, window_override=win[0] if win else None)
             ix2.close()
             del ix2
             torch.cuda.empty_cache()
