@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md "Indexed rows: gather into LDS", row "2,048 rows shared by every workgroup (the XCD's L2)": 66-73 GB/s per
 # CU = 16.8-18.8 TB/s chip-wide for whole rows gathered from L2 -- the operand path that binds the table scan (one query per
 # (row, query) pair from L2).  The upper end is the peak, so that frac never flatters.
+GATHER_CEILING_GBS = [6410.0, 6560.0]  # random 512-byte .. 3-KiB rows gathered from HBM into registers, two boxes (profiles/micro/r03_gather512.csv)
 L2_GATHER_PEAK_GBS = 18800.0
 L2_GATHER_RANGE_GBS = [16800.0, 18800.0]
 SEED_ROWS, SEED_Q, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
@@ -458,7 +459,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # Leaf-major sweep: SURVEY s8(d)'s bytes ARE what the kernel moves through HBM (PMC traffic 0.99-1.01x): HBM roofline.
         roof = {"bound": "hbm", "achieved": s8d_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s8d_GBps / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": bytes_alg,
-                "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0}
+                "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0,
+                # what a bare random whole-row gather into registers reaches on this chip (no arithmetic, same access shape, 64-GB
+                # table; profiles/micro/gather512.hip -> profiles/micro/r03_gather512.csv): the ceiling of a leaf-major sweep
+                "measured_gather_ceiling_GBps": GATHER_CEILING_GBS,
+                "frac_of_measured_gather_ceiling": s8d_GBps / GATHER_CEILING_GBS[0]}
         roof.update(common)
     else:
         # Table scan: the stored rows cross HBM ONCE per window (address order) and every (row, query) pair fetches its query
@@ -738,7 +743,7 @@ def main():
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",
                                                                "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
-                                                               "hbm_frac", "s8d_equivalent_GBps")
+                                                               "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms")}
