@@ -190,6 +190,9 @@ struct zh_index {
     bool samples_valid = false;
     DevBuf row_hn2, row_norm;  // |r|^2 / 2 and |r| of the stored rows, for the first norm_rows rows of generation norm_gen
     uint64_t norm_rows = 0, norm_gen = 0;
+    DevBuf plane_hab;          // the same per PLANE (its two sample rows), for the first hab_planes planes at (hab_rows, hab_gen)
+    uint32_t hab_planes = 0;
+    uint64_t hab_rows = 0, hab_gen = 0;
     bool scan_unsafe = false;  // an injected forest lists a row twice in one tree: rowLeaf holds one slot per (row, tree) -> leaf-major only
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
@@ -298,6 +301,7 @@ static void free_forest(zh_index *ix) {
     ix->n_blocks = 0; ix->blocks_valid = false;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     ix->plane_samples.release(); ix->samples_valid = false;
+    ix->plane_hab.release(); ix->hab_planes = 0; ix->hab_rows = 0; ix->hab_gen = 0;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
     ix->n_leaf_ids = 0;
     ix->h_plane.clear(); ix->h_left.clear(); ix->h_right.clear(); ix->h_roots.clear();
@@ -1308,6 +1312,16 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
             ix->norm_rows = ix->n_rows; ix->norm_gen = ix->rows_gen;
         }
     }
+    if (ix->hab_planes != ix->n_planes || ix->hab_rows != ix->norm_rows || ix->hab_gen != ix->norm_gen) {  // planes were added, or the norms retaken
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if (ix->hab_planes != ix->n_planes || ix->hab_rows != ix->norm_rows || ix->hab_gen != ix->norm_gen) {
+            if ((rc = ix->plane_hab.ensure(std::max<size_t>(ix->n_planes, 1) * sizeof(float4)))) return rc;
+            HIPCHK(zh_launch_plane_hab(ix->plane_samples.as<uint2>(), ix->n_planes, ix->row_hn2.as<float>(), ix->row_norm.as<float>(),
+                                       ix->plane_hab.as<float4>(), ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            ix->hab_planes = ix->n_planes; ix->hab_rows = ix->norm_rows; ix->hab_gen = ix->norm_gen;
+        }
+    }
     if (B % 4) {  // pad the batch with zero queries to a multiple of four (their signs are computed and never read)
         const size_t Bp = (B + 3) & ~(size_t)3;
         if ((rc = c->wQpad.ensure(Bp * d * 4)) || (rc = c->wBits.ensure(Bp * c->wpq * 4))) return rc;
@@ -1337,7 +1351,7 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
     HIPCHK(zh_launch_row_norms(dQ, B, d, nullptr, c->wQnorm.as<float>(), s));
     ZhTotals *tot = c->wTotals.as<ZhTotals>();
     HIPCHK(zh_launch_score_signs(c->wScore.as<float>(), (uint32_t)B, ix->plane_samples.as<uint2>(), ix->n_planes, ix->row_hn2.as<float>(),
-                                 ix->row_norm.as<float>(), c->wQnorm.as<float>(), dQ, d, ix->planes.as<float>(), ix->consts.as<float>(),
+                                 ix->row_norm.as<float>(), ix->plane_hab.as<float4>(), c->wQnorm.as<float>(), dQ, d, ix->planes.as<float>(), ix->consts.as<float>(),
                                  c->wBits.as<uint32_t>(), c->wpq, c->wFixList.as<uint2>(), fix_cap, &tot->hash_fixups, s));
     return ZH_OK;
 }
@@ -1377,7 +1391,7 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if (!ix->blocks_valid && (rc = build_blocks(ix))) { c->state = 0; return rc; }
     }
-    c->wpq = (c->P_dense + 63) / 64 * 2;
+    c->wpq = (c->P_dense + 255) / 256 * 8;  // sign words per query, a multiple of eight: score_signs_kernel stores whole 32-byte sectors
     const size_t nn = std::max<uint32_t>(ix->n_nodes, 1);
     c->state = 0;  // a failure below leaves the context idle
     if (nwin > 1) {  // the window's batches side by side: the kernels address query b of the window as Q + b * d
@@ -1767,7 +1781,7 @@ extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *o
     const uint32_t P = ix->n_planes, d = ix->opt.dim;
     if (!b || !P) return ZH_OK;
     hipStream_t s = ix->stream;
-    const uint32_t wpq = (P + 63) / 64 * 2, words = (P + 31) / 32;
+    const uint32_t wpq = (P + 255) / 256 * 8, words = (P + 31) / 32;
     DevBuf dq, dbits, ddots;
     struct G { DevBuf *a, *b, *c; ~G() { a->release(); b->release(); c->release(); } } g{&dq, &dbits, &ddots};
     size_t chunk = std::max<size_t>(1, std::min<size_t>(b, (size_t)(256u << 20) / ((size_t)P * 4 + 1)));

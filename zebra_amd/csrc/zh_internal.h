@@ -211,8 +211,10 @@ hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const 
 // dS: scores [n_rows][B] (row . query, from zh_launch_hash_dense with the roles swapped); dSamples: the two sample rows of every
 // plane (UINT32_MAX = a default zero vector); writes the sign words of all P planes for the B queries (B % 4 == 0), the signs
 // inside the rounding bound recomputed exactly (list of fix_cap entries; *dFixCount must be 0 on entry and receives their number)
+// dPlaneHab: per plane {|a|^2/2, |b|^2/2, |a| + |b|, 0} of its sample rows (zh_launch_plane_hab), read in plane order by the signs kernel
+hipError_t zh_launch_plane_hab(const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm, float4 *dOut, hipStream_t s);
 hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
-                                 const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
+                                 const float4 *dPlaneHab, const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
                                  uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
                                  hipStream_t s);
 

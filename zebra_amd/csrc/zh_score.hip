@@ -84,74 +84,93 @@ hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const 
 
 // signs of 32 consecutive planes (one output word) for every query, from the score table S[row][B]: a wave per word, lane l
 // takes queries 4l .. 4l+3 of each 256-query chunk (one float4 of both sample rows' score rows per plane).  Signs inside the
-// bound are flagged in `unc` (same layout as `bits`) and appended to the fix-up list, one atomic per wave and chunk.
+// bound are appended to the fix-up list, one atomic per wave, word and chunk.
+// A block produces EIGHT consecutive words (each of its four waves two): the sign matrix is [query][word], so one word of 256
+// queries is 256 four-byte stores a row pitch (hundreds of KB) apart -- every one a read-modify-write of a 32-byte sector
+// (rocprofv3, round 2: 16.7 GB read for 13.3 GB of score rows gathered, 1.2 GB written for 0.2 GB of signs).  The block's
+// 256 x 8 words meet in LDS and thread t stores the eight words of query t as one aligned 32-byte sector (wpq is a multiple
+// of eight words: zh_score_words_per_query).
 __global__ __launch_bounds__(256) void score_signs_kernel(const float *__restrict__ S, uint32_t B, const uint2 *__restrict__ samples,
-                                                           uint32_t P, const float *__restrict__ hn2,
-                                                           const float *__restrict__ rnorm, const float *__restrict__ qnorm,
+                                                           uint32_t P, const float4 *__restrict__ plane_hab,
+                                                           const float *__restrict__ qnorm,
                                                            float K, uint32_t *__restrict__ bits, uint32_t wpq,
                                                            uint2 *__restrict__ fix_list, uint32_t fix_cap,
                                                            unsigned long long *__restrict__ fix_count) {
+    __shared__ uint32_t sbits[256][9];  // [query of the chunk][word of the block] (+1: the eight words of a query start on different banks)
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t W = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t p0 = W * 32;
-    if (p0 >= P) return;
-    const uint32_t np = P - p0 < 32 ? P - p0 : 32;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t Wb = blockIdx.x * 8;
     for (uint32_t q0 = 0; q0 < B; q0 += 256) {
         const uint32_t q = q0 + 4 * lane;
         const bool in = q < B;  // B % 4 == 0: a lane's four queries are in or out together
         float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) xn = *reinterpret_cast<const float4 *>(qnorm + q);
-        uint32_t sw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; j < np; j++) {
-            const uint2 ab = samples[p0 + j];  // wave-uniform
-            if (ab.x == 0xFFFFFFFFu || ab.y == 0xFFFFFFFFu) {  // a default (zero) sample vector, lsh.rs:203-220: exact path
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t W = Wb + wv * 2 + i, p0 = W * 32;
+            const uint32_t np = p0 >= P ? 0u : (P - p0 < 32 ? P - p0 : 32);  // (words past the last plane: zeros)
+            uint32_t sw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
+            for (uint32_t j = 0; j < np; j++) {
+                const uint2 ab = samples[p0 + j];  // wave-uniform
+                if (ab.x == 0xFFFFFFFFu || ab.y == 0xFFFFFFFFu) {  // a default (zero) sample vector, lsh.rs:203-220: exact path
 #pragma unroll
-                for (int c = 0; c < 4; c++) uw[c] |= 1u << j;
-                continue;
+                    for (int c = 0; c < 4; c++) uw[c] |= 1u << j;
+                    continue;
+                }
+                // {|a|^2/2, |b|^2/2, |a| + |b|} of the plane's two sample rows, in PLANE order (plane_hab_kernel): read in sequence
+                // beside the samples -- the per-row norm arrays cost four random sector fetches per plane (3.3 GB per batch)
+                const float4 hab = plane_hab[p0 + j];
+                const float A = hab.z, ha = hab.x, hb = hab.y;
+                float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+                if (in) {
+                    sa = *reinterpret_cast<const float4 *>(S + (size_t)ab.x * B + q);
+                    sb = *reinterpret_cast<const float4 *>(S + (size_t)ab.y * B + q);
+                }
+                const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float diff = (bv[c] - hb) - (av[c] - ha);
+                    const float E = K * (2.0f * A * xv[c] + A * A);
+                    sw[c] |= (diff >= 0.0f ? 1u : 0u) << j;
+                    uw[c] |= (fabsf(diff) > E ? 0u : 1u) << j;  // NaN / inf anywhere -> not certain
+                }
             }
-            const float A = rnorm[ab.x] + rnorm[ab.y], ha = hn2[ab.x], hb = hn2[ab.y];
-            float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+            // the fix-up list: one atomic per wave, word and chunk
+            uint32_t mine = in ? __popc(uw[0]) + __popc(uw[1]) + __popc(uw[2]) + __popc(uw[3]) : 0;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            unsigned long long base = 0;
+            if (total) {
+                if (lane == 63) base = atomicAdd(fix_count, (unsigned long long)total);
+                base = __shfl(base, 63);
+            }
             if (in) {
-                sa = *reinterpret_cast<const float4 *>(S + (size_t)ab.x * B + q);
-                sb = *reinterpret_cast<const float4 *>(S + (size_t)ab.y * B + q);
-            }
-            const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, xv[4] = {xn.x, xn.y, xn.z, xn.w};
+                unsigned long long pos = base + incl - mine;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float diff = (bv[c] - hb) - (av[c] - ha);
-                const float E = K * (2.0f * A * xv[c] + A * A);
-                sw[c] |= (diff >= 0.0f ? 1u : 0u) << j;
-                uw[c] |= (fabsf(diff) > E ? 0u : 1u) << j;  // NaN / inf anywhere -> not certain
-            }
-        }
-        // the fix-up list: one atomic per wave and chunk
-        uint32_t mine = in ? __popc(uw[0]) + __popc(uw[1]) + __popc(uw[2]) + __popc(uw[3]) : 0;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= (uint32_t)o) incl += t;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        unsigned long long base = 0;
-        if (total) {
-            if (lane == 63) base = atomicAdd(fix_count, (unsigned long long)total);
-            base = __shfl(base, 63);
-        }
-        if (in) {
-            unsigned long long pos = base + incl - mine;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                bits[(size_t)(q + c) * wpq + W] = sw[c];
-                uint32_t u = uw[c];
-                while (u) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(u);
-                    u &= u - 1;
-                    if (pos < fix_cap) fix_list[pos] = make_uint2(q + c, p0 + j);
-                    pos++;
+                for (int c = 0; c < 4; c++) {
+                    sbits[4 * lane + c][wv * 2 + i] = sw[c];
+                    uint32_t u = uw[c];
+                    while (u) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(u);
+                        u &= u - 1;
+                        if (pos < fix_cap) fix_list[pos] = make_uint2(q + c, p0 + j);
+                        pos++;
+                    }
                 }
             }
         }
+        __syncthreads();
+        const uint32_t qt = q0 + threadIdx.x;
+        if (qt < B) {  // the eight words of one query: one aligned 32-byte sector
+            uint4 *dst = reinterpret_cast<uint4 *>(bits + (size_t)qt * wpq + Wb);
+            dst[0] = make_uint4(sbits[threadIdx.x][0], sbits[threadIdx.x][1], sbits[threadIdx.x][2], sbits[threadIdx.x][3]);
+            dst[1] = make_uint4(sbits[threadIdx.x][4], sbits[threadIdx.x][5], sbits[threadIdx.x][6], sbits[threadIdx.x][7]);
+        }
+        __syncthreads();
     }
 }
 
@@ -253,10 +272,27 @@ __global__ __launch_bounds__(256) void score_overflow_kernel(const float *__rest
     bits[(size_t)q * wpq + W] = word;
 }
 
+// per plane: {|a|^2 / 2, |b|^2 / 2, |a| + |b|, 0} of its two sample rows (the same float values score_signs4 / the overflow path
+// read from the per-row arrays)
+__global__ __launch_bounds__(256) void plane_hab_kernel(const uint2 *__restrict__ samples, uint32_t P, const float *__restrict__ hn2,
+                                                         const float *__restrict__ rnorm, float4 *__restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint2 ab = samples[p];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ab.x != 0xFFFFFFFFu && ab.y != 0xFFFFFFFFu) v = make_float4(hn2[ab.x], hn2[ab.y], rnorm[ab.x] + rnorm[ab.y], 0.f);
+    out[p] = v;
+}
+hipError_t zh_launch_plane_hab(const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm, float4 *dOut, hipStream_t s) {
+    if (!P) return hipSuccess;
+    hipLaunchKernelGGL(plane_hab_kernel, dim3((P + 255) / 256), dim3(256), 0, s, dSamples, P, dHalfN2, dRowNorm, dOut);
+    return hipGetLastError();
+}
+
 float zh_score_bound_factor(uint32_t d) { return (float)(d + 8) * 5.9604645e-8f * 1.001f; }
 
 hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
-                                 const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
+                                 const float4 *dPlaneHab, const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
                                  uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
                                  hipStream_t s) {
     if (!B || !P) return hipSuccess;
@@ -266,7 +302,7 @@ hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamp
         hipLaunchKernelGGL(score_signs4_kernel, dim3((P + 255) / 256), dim3(256), 0, s, dS, dSamples, P, dHalfN2, dRowNorm, dQNorm, K, dBits, wpq,
                            dFixList, fix_cap, dFixCount);
     else
-        hipLaunchKernelGGL(score_signs_kernel, dim3((words + 3) / 4), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm, dQNorm, K,
+        hipLaunchKernelGGL(score_signs_kernel, dim3((words + 7) / 8), dim3(256), 0, s, dS, B, dSamples, P, dPlaneHab, dQNorm, K,
                            dBits, wpq, dFixList, fix_cap, dFixCount);
     hipLaunchKernelGGL(score_fixup_kernel, dim3(4096), dim3(256), 0, s, dQ, d, dPlanes, dConsts, dBits, wpq, dFixList, fix_cap, dFixCount);
     const unsigned long long n = (unsigned long long)B * words;
