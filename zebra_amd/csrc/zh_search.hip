@@ -804,6 +804,16 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rl(int v, uint32_t lane) { return __builtin_amdgcn_readlane(v, (int)lane); }
 
+#ifdef ZH_WALK_PROF  // tests/probes/walk_prof.py: where a wave of the blocked walk spends its cycles (never defined in the shipped build)
+__device__ uint64_t zh_walk_prof_buf[16 * 8192];
+extern "C" __attribute__((visibility("default"))) int zh_debug_walk_prof(uint64_t *out, uint32_t words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_walk_prof_buf), (size_t)words * 8);
+}
+#define WP(...) __VA_ARGS__
+#else
+#define WP(...)
+#endif
+
 __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
                                                            const uint32_t *__restrict__ bits, uint32_t wpq,
                                                            ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
@@ -820,7 +830,10 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
     uint32_t log_chunk = 0xFFFFFFFFu;
     int32_t log_cn = -1;
     bool log_ok = true;
+    WP(uint64_t p_t0 = clock64(); uint64_t p_w0 = wall_clock64(); uint64_t p_load = 0, p_upper = 0, p_flush = 0, p_dfs = 0;
+       uint32_t p_blocks = 0, p_uppers = 0, p_inner = 0, p_pops = 0, p_upops = 0;)
     auto flush = [&]() {  // as walk_kernel's count-pass flush: visits leave the wave WALK_BUF at a time, one lane each
+        WP(const uint64_t p_f0 = clock64();)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t first = nv - nbuf, vi = first + lane;
@@ -863,6 +876,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         }
         nbuf = 0;
         __builtin_amdgcn_wave_barrier();
+        WP(p_flush += clock64() - p_f0;)
     };
     const int2 root = blk.root[t];
     int32_t ref = __builtin_amdgcn_readfirstlane(root.x), pl = __builtin_amdgcn_readfirstlane(root.y);
@@ -870,6 +884,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
     int usp = 0;
     for (;;) {
         if (ref >= 0) {  // an upper (inner) node: its records and its sign word are requested together
+            WP(const uint64_t p_u0 = clock64(); p_uppers++;)
             const int4 ra = blk.upper[2 * (size_t)ref], rb = blk.upper[2 * (size_t)ref + 1];
             const uint32_t word = qbits[(uint32_t)pl >> 5];
             const int4 a = uni4(ra), c2 = uni4(rb);
@@ -878,9 +893,11 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
             usp++;
             ref = above ? a.z : a.y;  // lsh.rs:335-338: above -> right is main
             pl = above ? c2.y : c2.x;
+            WP(p_upper += clock64() - p_u0;)
             continue;
         }
         // ---- a block: records and signs into registers, then the DFS without memory ----
+        WP(const uint64_t p_l0 = clock64(); p_blocks++;)
         const uint32_t s0 = (uint32_t)(-ref - 1);
         int4 r = blk.recs[s0 + lane];  // the array is padded: 64 records can always be read
         const int r0x = rl(r.x, 0);
@@ -888,30 +905,43 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         if (lane >= cnt) r = make_int4(-1, 0, 0, 0);
         int sgn = 0;
         if (r.x >= 0) sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
+        // everything an INNER step needs in one word per lane -- main child | backup child << 8 (lsh.rs:335-338: above -> right is
+        // main), bit 31 = leaf -- so that a step is ONE v_readlane (round 2: record .x, .y and the sign, three), and a leaf's lane
+        // records its own visit from its own registers (round 2: three more read-lanes for lane 0 to do it)
+        uint32_t pk = 0x80000000u;
+        if (r.x >= 0) {
+            const uint32_t l = (uint32_t)r.y & 0xFFFFu, rr = (uint32_t)r.y >> 16;
+            pk = sgn ? (rr | (l << 8)) : (l | (rr << 8));
+        }
+        WP(if (__builtin_amdgcn_readfirstlane((int)pk) == 12345) p_blocks++; const uint64_t p_d0 = clock64(); p_load += p_d0 - p_l0;
+           const uint64_t p_fl0 = p_flush;)
         int lstk = 0;          // the block's DFS stack: lane j holds entry j = local node | n << 8
         uint32_t lsp = 0, cur = 0;
         int32_t ret = 0;
         for (;;) {
-            const int x = rl(r.x, cur);
-            if (x >= 0) {
-                const int ch = rl(r.y, cur), ab = rl(sgn, cur);
-                const uint32_t l = (uint32_t)ch & 0xFFFFu, rr = (uint32_t)ch >> 16;
-                lstk = lane == lsp ? (int)((ab ? l : rr) | ((uint32_t)n << 8)) : lstk;  // "v_writelane": one compare + select
+            // down the main children to a leaf: a loop of its own, so that the compiler keeps the walk's many other live scalars
+            // (visit counters, log state, n of the upper levels) out of its back edge -- as one loop with `continue` every inner step
+            // carried ~20 s_mov copies of them (37 instructions per inner node, 10 of them work)
+            uint32_t w = (uint32_t)rl((int)pk, cur);
+            while (!(w >> 31)) {
+                lstk = lane == lsp ? (int)(((w >> 8) & 0xFFu) | ((uint32_t)n << 8)) : lstk;  // "v_writelane": one compare + select
                 lsp++;
-                cur = ab ? rr : l;
-                continue;
+                cur = w & 0xFFu;
+                w = (uint32_t)rl((int)pk, cur);
+                WP(p_inner++;)
             }
-            const uint32_t off = (uint32_t)rl(r.y, cur), len = (uint32_t)rl(r.z, cur), node = (uint32_t)rl(r.w, cur);
+            const uint32_t len = (uint32_t)rl(r.z, cur);
             const uint32_t take = n <= 0 ? 0u : (len < (uint32_t)n ? len : (uint32_t)n);
             ret = (int32_t)take;  // lsh.rs:306 / 329
             if (take > 0) {
-                if (lane == 0) { vb_a[nbuf] = make_uint4(node, off, len, take); vb_r[nbuf] = nrows; vb_c[nbuf] = ntakes; }
+                if (lane == cur) { vb_a[nbuf] = make_uint4((uint32_t)r.w, (uint32_t)r.y, len, take); vb_r[nbuf] = nrows; vb_c[nbuf] = ntakes; }
                 nbuf++; nv++; nrows += len; ntakes += take;
                 if (nbuf == WALK_BUF) flush();
             }
             bool down = false;
             while (lsp > 0) {
                 lsp--;
+                WP(p_pops++;)
                 const uint32_t e = (uint32_t)rl(lstk, lsp);
                 const int32_t nn = (int32_t)(e >> 8);
                 if (ret < nn) { cur = e & 0xFFu; n = nn - ret; down = true; break; }  // lsh.rs:341-343
@@ -919,10 +949,12 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
             if (!down) break;
         }
         // the block returned `ret` to the upper walk
+        WP(p_dfs += clock64() - p_d0 - (p_flush - p_fl0); const uint64_t p_p0 = clock64();)
         bool down = false;
         __builtin_amdgcn_wave_barrier();
         while (usp > 0) {
             usp--;
+            WP(p_upops++;)
             if (usp < WALK_STACK) {
                 const int4 e = ust[usp];
                 const int32_t nn = __builtin_amdgcn_readfirstlane(e.y);
@@ -933,6 +965,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
                 }
             }
         }
+        WP(p_upper += clock64() - p_p0;)
         if (!down) break;
     }
     if (nbuf) flush();
@@ -941,6 +974,12 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
         counts[pair] = c;
     }
+    WP(if (lane == 0 && pair < 8192) {
+        uint64_t *o = zh_walk_prof_buf + pair * 16;
+        o[0] = clock64() - p_t0; o[1] = wall_clock64() - p_w0; o[2] = p_load; o[3] = p_upper; o[4] = p_flush; o[5] = p_dfs;
+        o[6] = p_blocks; o[7] = p_uppers; o[8] = p_inner; o[9] = p_pops; o[10] = p_upops; o[11] = nv; o[12] = p_w0;
+        uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); o[13] = hw;
+    })
 }
 
 hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
