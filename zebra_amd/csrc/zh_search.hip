@@ -814,41 +814,64 @@ extern "C" __attribute__((visibility("default"))) int zh_debug_walk_prof(uint64_
 #define WP(...)
 #endif
 
+// a wave-uniform value the compiler must keep in a VGPR (it would otherwise compute it on the scalar unit: the DFS below is bound
+// by the SIMD's one scalar issue slot per four cycles -- tests/probes/walk_prof.py -- while its vector slot idles)
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x) {
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t in_vgpr_shl8(uint32_t x) {
+    uint32_t r;
+    asm volatile("v_lshlrev_b32 %0, 8, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+#define WALK_RING 128u       // visit records waiting to leave the wave: ring of 128 slots (+ one slot every lane without a visit writes to)
+#define WALK_FLUSH 32u       // ... leave 32 at a time (< ZH_LOG_CHUNK - 1: at most one new log chunk per flush)
+#define WALK_EXIT (0x80000000u | 63u)
+
 __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
                                                            const uint32_t *__restrict__ bits, uint32_t wpq,
                                                            ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
                                                            uint32_t *__restrict__ leafCount, ZhWalkLog wlog) {
     __shared__ int4 ust[WALK_STACK];  // upper-level stack {child ref, n, the child's plane when it is an upper node}
-    __shared__ uint4 vb_a[WALK_BUF];
-    __shared__ uint64_t vb_r[WALK_BUF], vb_c[WALK_BUF];
+    __shared__ uint4 vb_a[WALK_RING + 1];
+    __shared__ uint32_t vb_r[WALK_RING + 1], vb_c[WALK_RING + 1];
     const uint32_t T = f.n_trees, lane = threadIdx.x;
     const uint64_t pair = blockIdx.x;
     const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
     const uint32_t *__restrict__ qbits = bits + (size_t)b * wpq;
-    uint32_t nv = 0, nbuf = 0;
-    uint64_t nrows = 0, ntakes = 0;
+    if (n0 <= 0) {  // lsh.rs:306: the first leaf takes nothing and nothing is ever < 0: no visit
+        if (lane == 0) { ZhPairCounts c; c.visits = 0; c.rows = 0; c.takes = 0; c.pad = 0; counts[pair] = c; }
+        return;
+    }
+    // the pair's running totals: wave-uniform, kept in VGPRs (see in_vgpr)
+    uint32_t v_nv = in_vgpr(0), v_nrows = in_vgpr(0), v_ntakes = in_vgpr(0);
+    uint32_t flushed = 0;
     uint32_t log_chunk = 0xFFFFFFFFu;
     int32_t log_cn = -1;
     bool log_ok = true;
     WP(uint64_t p_t0 = clock64(); uint64_t p_w0 = wall_clock64(); uint64_t p_load = 0, p_upper = 0, p_flush = 0, p_dfs = 0;
        uint32_t p_blocks = 0, p_uppers = 0, p_inner = 0, p_pops = 0, p_upops = 0;)
-    auto flush = [&]() {  // as walk_kernel's count-pass flush: visits leave the wave WALK_BUF at a time, one lane each
+    auto flush = [&](uint32_t cnt) {  // as walk_kernel's count-pass flush: the ring's oldest `cnt` (<= WALK_FLUSH) visits leave, one lane each
         WP(const uint64_t p_f0 = clock64();)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t first = nv - nbuf, vi = first + lane;
-        const bool mine = lane < nbuf;
-        const uint4 va = vb_a[mine ? lane : 0];
+        const uint32_t first = flushed, vi = first + lane, upto = first + cnt;
+        const bool mine = lane < cnt;
+        const uint32_t slot = mine ? (vi & (WALK_RING - 1)) : WALK_RING;
+        const uint4 va = vb_a[slot];
         ZhVisit v;
         v.b = b; v.leaf_off = va.y; v.len = va.z; v.take = va.w; v.node = va.x; v.pad = 0;
-        v.row_off = vb_r[mine ? lane : 0]; v.cand_off = vb_c[mine ? lane : 0];
+        v.row_off = vb_r[slot]; v.cand_off = vb_c[slot];
         if (mine) {
             atomicAdd(&leafCount[v.node], 1u);
             if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
         }
-        if (nv > ZH_INLINE_VISITS && log_ok) {
+        if (upto > ZH_INLINE_VISITS && log_ok) {
             constexpr uint32_t PER = ZH_LOG_CHUNK - 1;
-            const int32_t c1 = (int32_t)((nv - 1 - ZH_INLINE_VISITS) / PER);
+            static_assert(WALK_FLUSH < PER, "a flush may open at most one log chunk");
+            const int32_t c1 = (int32_t)((upto - 1 - ZH_INLINE_VISITS) / PER);
             uint32_t newc = 0xFFFFFFFFu;
             if (c1 > log_cn) {
                 uint32_t c = 0;
@@ -874,7 +897,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
                 if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
             }
         }
-        nbuf = 0;
+        flushed = upto;
         __builtin_amdgcn_wave_barrier();
         WP(p_flush += clock64() - p_f0;)
     };
@@ -901,52 +924,69 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         const uint32_t s0 = (uint32_t)(-ref - 1);
         int4 r = blk.recs[s0 + lane];  // the array is padded: 64 records can always be read
         const int r0x = rl(r.x, 0);
-        const uint32_t cnt = r0x >= 0 ? (uint32_t)rl(r.z, 0) : 1u;
+        const uint32_t cnt = r0x >= 0 ? (uint32_t)rl(r.z, 0) : 1u;  // odd (a full binary subtree), so <= 63: lane 63 is never a node
         if (lane >= cnt) r = make_int4(-1, 0, 0, 0);
         int sgn = 0;
         if (r.x >= 0) sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
-        // everything an INNER step needs in one word per lane -- main child | backup child << 8 (lsh.rs:335-338: above -> right is
-        // main), bit 31 = leaf -- so that a step is ONE v_readlane (round 2: record .x, .y and the sign, three), and a leaf's lane
-        // records its own visit from its own registers (round 2: three more read-lanes for lane 0 to do it)
-        uint32_t pk = 0x80000000u;
+        // One word per lane holds everything a step needs.  Inner node: main child | backup child << 8 (lsh.rs:335-338: above ->
+        // right is main) -- the next step's v_readlane takes the word itself as its lane select (the hardware uses bits 5:0).  Leaf:
+        // bit 31 | own lane -- unique in the block, so `pk == w` is true in the visited leaf's lane alone and that lane records the
+        // visit from its own registers (`pkm`: the same word, or no word at all for an empty leaf, which is stepped on but not a
+        // visit).  Lanes past the block read as empty leaves; lane 63 (WALK_EXIT) is where the stack's sentinel leads once the
+        // block is exhausted.
+        uint32_t pk = 0x80000000u | lane;
+        const uint32_t pkm = r.x < 0 && r.z > 0 ? pk : 0xFFFFFFFFu;
         if (r.x >= 0) {
             const uint32_t l = (uint32_t)r.y & 0xFFFFu, rr = (uint32_t)r.y >> 16;
             pk = sgn ? (rr | (l << 8)) : (l | (rr << 8));
         }
         WP(if (__builtin_amdgcn_readfirstlane((int)pk) == 12345) p_blocks++; const uint64_t p_d0 = clock64(); p_load += p_d0 - p_l0;
            const uint64_t p_fl0 = p_flush;)
-        int lstk = 0;          // the block's DFS stack: lane j holds entry j = local node | n << 8
-        uint32_t lsp = 0, cur = 0;
+        // the block's DFS stack: lane j holds entry j = backup node | n << 8; entry 0 is a sentinel no return value ever exhausts
+        uint32_t lstk = lane == 0 ? ((0x7FFFFFu << 8) | 63u) : 0u;
+        uint32_t lsp = 1;
+        uint32_t vidx = 0xFFFFFFFFu, vtk = 0, vrow = 0, vcand = 0;  // the visit of this lane's leaf, if any (a DFS meets a leaf once)
+        uint32_t n8 = in_vgpr_shl8((uint32_t)n);
         int32_t ret = 0;
-        for (;;) {
-            // down the main children to a leaf: a loop of its own, so that the compiler keeps the walk's many other live scalars
-            // (visit counters, log state, n of the upper levels) out of its back edge -- as one loop with `continue` every inner step
-            // carried ~20 s_mov copies of them (37 instructions per inner node, 10 of them work)
-            uint32_t w = (uint32_t)rl((int)pk, cur);
-            while (!(w >> 31)) {
-                lstk = lane == lsp ? (int)(((w >> 8) & 0xFFu) | ((uint32_t)n << 8)) : lstk;  // "v_writelane": one compare + select
-                lsp++;
-                cur = w & 0xFFu;
-                w = (uint32_t)rl((int)pk, cur);
-                WP(p_inner++;)
-            }
-            const uint32_t len = (uint32_t)rl(r.z, cur);
-            const uint32_t take = n <= 0 ? 0u : (len < (uint32_t)n ? len : (uint32_t)n);
-            ret = (int32_t)take;  // lsh.rs:306 / 329
-            if (take > 0) {
-                if (lane == cur) { vb_a[nbuf] = make_uint4((uint32_t)r.w, (uint32_t)r.y, len, take); vb_r[nbuf] = nrows; vb_c[nbuf] = ntakes; }
-                nbuf++; nv++; nrows += len; ntakes += take;
-                if (nbuf == WALK_BUF) flush();
-            }
-            bool down = false;
-            while (lsp > 0) {
+        uint32_t w = (uint32_t)rl((int)pk, 0);
+        // down the main children to a leaf: 1 scalar + 5 vector instructions and the branch per inner node.  (Round 2's loop spent
+        // 37 instructions here, most of them scalar copies of the walk's other live state.)
+#define WALK_DESCEND()                                                                                                       \
+        while (!(w >> 31)) {                                                                                                 \
+            const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
+            lstk = lane == lsp ? e_ : lstk;                                                                                  \
+            lsp++;                                                                                                           \
+            w = (uint32_t)rl((int)pk, w);                                                                                    \
+            WP(p_inner++;)                                                                                                   \
+        }
+        WALK_DESCEND();
+        do {  // one leaf per turn; the loop is left through the sentinel: the block is done and `ret` is its return value
+            // the leaf: no branch -- an empty one (lsh.rs:306 / 329: it returns 0) matches no lane and adds nothing
+            const uint32_t len = (uint32_t)rl(r.z, w);
+            const uint32_t take = len < (uint32_t)n ? len : (uint32_t)n;  // n >= 1 here (n0 >= 1; a backup is entered with nn - ret > 0)
+            ret = (int32_t)take;
+            const bool me = pkm == w;
+            vidx = me ? v_nv : vidx; vtk = me ? take : vtk; vrow = me ? v_nrows : vrow; vcand = me ? v_ntakes : vcand;
+            v_nv += in_vgpr(len) != 0u ? 1u : 0u; v_nrows += len; v_ntakes += take;
+            uint32_t e;
+            do {  // lsh.rs:341-343: the nearest pending backup whose n the return value has not used up
                 lsp--;
                 WP(p_pops++;)
-                const uint32_t e = (uint32_t)rl(lstk, lsp);
-                const int32_t nn = (int32_t)(e >> 8);
-                if (ret < nn) { cur = e & 0xFFu; n = nn - ret; down = true; break; }  // lsh.rs:341-343
-            }
-            if (!down) break;
+                e = (uint32_t)rl((int)lstk, lsp);
+            } while ((uint32_t)ret >= (e >> 8));
+            n = (int32_t)((e >> 8) - (uint32_t)ret);
+            n8 = in_vgpr_shl8((uint32_t)n);
+            w = (uint32_t)rl((int)pk, e);
+            WALK_DESCEND();
+        } while (w != WALK_EXIT);
+#undef WALK_DESCEND
+        // the visited leaves' records join the ring (every other lane writes the spare slot: no branch), full groups leave the wave
+        {
+            const uint32_t slot = vidx != 0xFFFFFFFFu ? (vidx & (WALK_RING - 1)) : WALK_RING;
+            vb_a[slot] = make_uint4((uint32_t)r.w, (uint32_t)r.y, (uint32_t)r.z, vtk);
+            vb_r[slot] = vrow; vb_c[slot] = vcand;
+            const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_nv);
+            while (nv - flushed >= WALK_FLUSH) flush(WALK_FLUSH);
         }
         // the block returned `ret` to the upper walk
         WP(p_dfs += clock64() - p_d0 - (p_flush - p_fl0); const uint64_t p_p0 = clock64();)
@@ -968,10 +1008,11 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         WP(p_upper += clock64() - p_p0;)
         if (!down) break;
     }
-    if (nbuf) flush();
+    const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_nv);
+    if (nv > flushed) flush(nv - flushed);
     if (lane == 0) {
         ZhPairCounts c;
-        c.visits = nv; c.rows = (uint32_t)nrows; c.takes = (uint32_t)ntakes; c.pad = 0;
+        c.visits = nv; c.rows = v_nrows; c.takes = v_ntakes; c.pad = 0;
         counts[pair] = c;
     }
     WP(if (lane == 0 && pair < 8192) {
