@@ -147,6 +147,13 @@ typedef struct zh_stats_t {
     uint64_t scan_batches_accum; /* timed internal batches swept by the table scan */
     uint64_t hash_from_scores;  /* 1: the most recent batch took every sign of the forest from row scores (zh_set_hash_mode) */
     uint64_t hash_exact_fixups; /* ... and this many of its signs lay inside the rounding bound and were recomputed exactly */
+    uint64_t prefiltered;       /* 1: the most recent batch picked its candidates from the row scores (zh_set_sweep_mode): rows_scored
+                                 * rows were judged on their scores, rows_swept of them scored with the reference's arithmetic */
+    uint64_t prefilter_exact_visits; /* ... leaf visits whose `take` nearest rows the scores could not decide (scored exactly) */
+    uint64_t prefilter_exact_rows;   /* ... rows scored exactly in total (= rows_swept) */
+    uint64_t prefilter_fallbacks_accum; /* batches redone with the sweep because a candidate list ran over (since zh_stats_reset) */
+    uint64_t prefilter_last_overflow;   /* ... what ran over in the most recent of them: 1 | 2 a (query, tree) list, 4 the table of
+                                         * visits to score exactly, 8 a leaf longer than 64 rows */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -383,7 +390,13 @@ ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
 /* How the distance sweep of a batch is organised: 1 = leaf by leaf (the rows of every visited leaf are gathered from HBM once
  * per group of <= 4 queries that visit it), 2 = table scan (every stored row is streamed from HBM once per batch window, in
  * address order, and scored against every query that visits one of its num_trees leaves; the queries come from L2), 0 = the
- * library chooses per batch from the counted work (default).  Results are bit-identical in both. */
+ * library chooses per batch from the counted work (default).  Results are bit-identical in both.
+ * A batch whose hash came from row scores (zh_set_hash_mode) holds row . query for every stored row, i.e. every L2 / L2^2 / cosine
+ * distance of the batch up to rounding.  In mode 0 (and 3 = the same, stated) such a batch is PREFILTERED instead of swept: per
+ * (query, tree) the visited leaves' rows are judged on their scores with a rigorous rounding bound -- which `take` rows a leaf
+ * hands over (lsh.rs:300-330), and which of those can still be among the k nearest -- and only the survivors, plus every visit the
+ * bound cannot decide, are scored with the reference's arithmetic; ids, keys and counts stay bit-identical.  Modes 1 and 2 always
+ * sweep.  (max_node_size <= 8 and no leaf longer than 64 rows, top_k <= 64, forests built by this library.) */
 ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
 /* How a batch that needs EVERY sign of the forest (small leaves: the reference's default max_node_size 5) gets them:
  * 1 = one dot product per (query, plane), 2 * b * planes * dim flop on the matrix cores; 2 = from row scores: a plane is built from

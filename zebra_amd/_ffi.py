@@ -50,7 +50,9 @@ class Stats(C.Structure):
                 ("ms_select", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
                 ("timed_batches", C.c_uint64), ("sweep_rows_accum", C.c_uint64), ("swept_rows_accum", C.c_uint64), ("sweep_launches_accum", C.c_uint64),
                 ("window_batches", C.c_uint64), ("table_scan", C.c_uint64), ("scan_batches_accum", C.c_uint64),
-                ("hash_from_scores", C.c_uint64), ("hash_exact_fixups", C.c_uint64)]
+                ("hash_from_scores", C.c_uint64), ("hash_exact_fixups", C.c_uint64),
+                ("prefiltered", C.c_uint64), ("prefilter_exact_visits", C.c_uint64), ("prefilter_exact_rows", C.c_uint64),
+                ("prefilter_fallbacks_accum", C.c_uint64), ("prefilter_last_overflow", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

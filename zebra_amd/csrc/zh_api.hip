@@ -101,7 +101,8 @@ struct DevBuf {
 struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
-        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl;
+        wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl,
+        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -120,15 +121,26 @@ struct zh_search_ctx {
     ZhTotals tot{};
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
+    uint32_t score_Bp = 0;    // ... for this many (padded) queries per stored row
+    // prefilter (zh_search.hip): the batch's candidates are picked from those row scores and only they are scored exactly.  Its
+    // control words come back pinned; a list that ran over makes zh_search_wait redo the batch the classic way, from these:
+    bool prefilter = false, prefilter_off_once = false;
+    uint32_t pf_cap = 0;
+    uint32_t *h_pf = nullptr;
+    std::vector<const float *> sv_q;
+    std::vector<uint64_t *> sv_ids, sv_keys;
+    std::vector<uint32_t *> sv_counts;
+    hipStream_t sv_heavy = nullptr;
     std::vector<DevBuf *> all_bufs() {
         return {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                 &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
-                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin};
+                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl};
     }
     void release_all() {
         for (DevBuf *b : all_bufs()) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
         if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
+        if (h_pf) { hipHostFree(h_pf); h_pf = nullptr; }
     }
 };
 
@@ -182,7 +194,7 @@ struct zh_index {
 
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
-    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model, 1 leaf-major, 2 table scan
+    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan, 3 = 0
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
@@ -193,6 +205,14 @@ struct zh_index {
     DevBuf plane_hab;          // the same per PLANE (its two sample rows), for the first hab_planes planes at (hab_rows, hab_gen)
     uint32_t hab_planes = 0;
     uint64_t hab_rows = 0, hab_gen = 0;
+    // {|r|^2/2, |r|} of the row in every slot of leaf_ids, for the prefilter: built on first use from the norms of (meta_rows,
+    // meta_gen), dropped with the trees
+    DevBuf leaf_meta;
+    bool leaf_meta_valid = false;
+    uint64_t meta_rows = 0, meta_gen = 0;
+    // batches in a row that the prefilter handed back to the sweep (a list ran over: rows the bound cannot tell apart, many long
+    // leaves): after two the forest is swept until it changes -- such data would pay for both every batch
+    std::atomic<uint32_t> prefilter_strikes{0};
     bool scan_unsafe = false;  // an injected forest lists a row twice in one tree: rowLeaf holds one slot per (row, tree) -> leaf-major only
     double visits_per_pair = 0;  // leaf visits per (query, tree) pair, running mean over the batches so far (stats_mu)
     int profiling = 0;
@@ -228,6 +248,9 @@ static int ctx_init(zh_search_ctx *c, zh_index *ix) {
     for (DevBuf *b : c->all_bufs()) b->defer = true;  // never hipFree (a device-wide drain) between batches
     hipError_t e = hipHostMalloc((void **)&c->h_totals, sizeof(ZhTotals), hipHostMallocDefault);
     if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    e = hipHostMalloc((void **)&c->h_pf, 4 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    memset(c->h_pf, 0, 4 * sizeof(uint32_t));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_emit, hipEventDisableTiming));
@@ -299,6 +322,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
+    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     ix->plane_samples.release(); ix->samples_valid = false;
     ix->plane_hab.release(); ix->hab_planes = 0; ix->hab_rows = 0; ix->hab_gen = 0;
@@ -451,6 +475,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
+    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0;
     ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->batches_since_change = 0;
     ix->max_leaf_len = 0;
@@ -1091,7 +1116,8 @@ extern "C" int zh_set_hash_mode(zh_index *ix, int mode) {
 }
 extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    if (mode < 0 || mode > 2) return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan)", mode);
+    if (mode < 0 || mode > 3)
+        return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan, 3 = as 0: prefilter where row scores exist)", mode);
     ix->sweep_mode = mode;
     return ZH_OK;
 }
@@ -1237,7 +1263,7 @@ static int build_row_leaf(zh_index *ix) {
 static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
-    const int mode = ix->sweep_mode ? ix->sweep_mode : forced;
+    const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
     if (mode == 2) return true;
     if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
@@ -1330,6 +1356,7 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
         dQ = c->wQpad.as<float>();
         B = Bp;
     }
+    c->score_Bp = (uint32_t)B;
     const uint32_t wq = (uint32_t)((B + 63) / 64 * 2);  // sign words per ROW of the score GEMM's (unused) bit output
     const uint64_t cap64 = (uint64_t)B * ix->n_planes / 64 + (1u << 16);  // ~1.6 % of the signs: 4x the share seen on ~N(0,1) rows
     const uint32_t fix_cap = (uint32_t)std::min<uint64_t>(cap64, 0x7FFFFFFFull);
@@ -1357,6 +1384,29 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
 }
 
 int ctx_wait(zh_search_ctx *c);
+
+// A batch hashed from row scores can pick its candidates from them (zh_search.hip, "Prefilter"): for the metrics the scores
+// determine, leaves short enough for the per-lane selection, and forests this library built (a row is in one leaf per tree).
+static bool use_prefilter(const zh_index *ix, const zh_search_ctx *c, size_t k, int metric) {
+    static const bool off = getenv("ZH_NO_PREFILTER") != nullptr;  // A/B: sweep + select for every batch
+    if (off || !c->score_hash || c->prefilter_off_once || (ix->prefilter_strikes.load() >= 2 && ix->sweep_mode != 3)) return false;
+    static const bool env_sweep = getenv("ZH_SWEEP_MODE") != nullptr;
+    if ((ix->sweep_mode != 0 && ix->sweep_mode != 3) || (env_sweep && ix->sweep_mode != 3)) return false;  // a sweep was asked for
+    if (metric != ZH_L2SQ && metric != ZH_L2 && metric != ZH_COSINE) return false;
+    // leaves of <= 8 rows are judged per lane; the odd longer one (rows a split could not separate) is a visit for the exact path
+    if (ix->opt.max_node_size > 8 || ix->max_leaf_len == 0 || ix->max_leaf_len > 64 || k > 64 || ix->scan_unsafe || !ix->n_leaf_ids) return false;
+    return true;
+}
+
+static int build_leaf_meta(zh_index *ix) {  // under blk_mu; the norms are those launch_score_hash just validated
+    int rc;
+    if ((rc = ix->leaf_meta.ensure(ix->n_leaf_ids * sizeof(float2)))) return rc;
+    HIPCHK(zh_launch_leaf_meta(ix->leaf_ids.as<uint32_t>(), ix->n_leaf_ids, ix->row_hn2.as<float>(), ix->row_norm.as<float>(),
+                               ix->leaf_meta.as<float2>(), ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->leaf_meta_valid = true; ix->meta_rows = ix->norm_rows; ix->meta_gen = ix->norm_gen;
+    return ZH_OK;
+}
 
 static ZhWalkLog walk_log(const zh_search_ctx *c) {
     ZhWalkLog l;
@@ -1425,6 +1475,8 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     HIPCHK(hipEventRecord(c->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));
     c->score_hash = use_score_hash(ix, B, c->P_dense);
+    c->prefilter = use_prefilter(ix, c, k, metric);
+    c->sv_q.assign(dQs, dQs + nwin);
     if (c->score_hash) {
         if ((rc = launch_score_hash(c, dQ, B, s))) return rc;
     } else if (c->P_dense)
@@ -1448,6 +1500,56 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     HIPCHK(hipMemcpyAsync(c->h_totals, c->wTotals.p, sizeof(ZhTotals), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev_totals, s));
     c->state = 1;
+    return ZH_OK;
+}
+
+// second half of a prefiltered batch: candidates from the row scores -> the exact path for what they cannot decide -> exact keys
+// of the few survivors -> final top-k over num_trees short lists per query
+static int finish_prefilter(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint64_t *const *outIds,
+                            uint64_t *const *outKeys, uint32_t *const *outCounts) {
+    zh_index *ix = c->ix;
+    const uint32_t d = ix->opt.dim, T = ix->n_trees;
+    const size_t B = c->B, k = c->k, nwin = c->nwin, bwin = c->bwin;
+    hipStream_t s = c->s;
+    int rc;
+    if (!ix->leaf_meta_valid || ix->meta_rows != ix->norm_rows || ix->meta_gen != ix->norm_gen) {
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if ((!ix->leaf_meta_valid || ix->meta_rows != ix->norm_rows || ix->meta_gen != ix->norm_gen) && (rc = build_leaf_meta(ix))) return rc;
+    }
+    const char *cap_e = getenv("ZH_PREFILTER_CAP");  // tests: lists that run over (read per batch)
+    const uint32_t cap_env = cap_e ? (uint32_t)atoi(cap_e) : 0u;
+    const uint32_t cap = cap_env ? std::max<uint32_t>(cap_env, 1) : (k <= 16 ? 64u : (k <= 32 ? 128u : 256u));
+    const uint64_t lists = (uint64_t)B * T;
+    const uint32_t amb_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, c->tot.visits / 32 + 1024), 1u << 26);
+    c->pf_cap = cap;
+    if ((rc = c->wPfRows.ensure(lists * cap * 4)) || (rc = c->wPfCounts.ensure(lists * 4)) || (rc = c->wPfKeys.ensure(lists * cap * 8)) ||
+        (rc = c->wPfIds.ensure(lists * cap * 8)) || (rc = c->wPfAmb.ensure((size_t)amb_cap * sizeof(uint4))) || (rc = c->wPfCtl.ensure(16)))
+        return rc;
+    HIPCHK(hipMemsetAsync(c->wPfCtl.p, 0, 16, s));
+    ZhPrefilter pf;
+    pf.S = c->wScore.as<float>(); pf.Bp = c->score_Bp; pf.leaf_meta = ix->leaf_meta.as<float2>(); pf.qnorm = c->wQnorm.as<float>();
+    pf.rows = c->wPfRows.as<uint32_t>(); pf.counts = c->wPfCounts.as<uint32_t>(); pf.cap = cap;
+    pf.amb = c->wPfAmb.as<uint4>(); pf.amb_cap = amb_cap; pf.ctl = c->wPfCtl.as<uint32_t>();
+    ZhForestDev f = forest_dev(ix);
+    HIPCHK(hipEventRecord(c->ev[2], s));
+    HIPCHK(hipEventRecord(c->ev_sw0, s));
+    HIPCHK(zh_launch_prefilter(f, d, (uint32_t)B, (uint32_t)k, c->metric, c->mode, c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(),
+                               walk_log(c), pf, s));
+    HIPCHK(hipEventRecord(c->ev_sw1, s));
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    HIPCHK(zh_launch_prefilter_exact(f, d, ix->X.as<float>(), c->dQ, c->wQQ.as<float>(), (uint32_t)B, c->metric, c->mode, ix->opt.id_base, pf,
+                                     c->wPfKeys.as<uint64_t>(), c->wPfIds.as<uint64_t>(), s));
+    HIPCHK(hipEventRecord(c->ev[4], s));
+    HIPCHK(zh_launch_final_lists(T, (uint32_t)B, (uint32_t)k, cap, c->wPfKeys.as<uint64_t>(), c->wPfIds.as<uint64_t>(), c->wPfCounts.as<uint32_t>(),
+                                 dOutIds, dOutKeys, dOutCounts, s));
+    for (size_t j = 0; j < nwin && nwin > 1; j++) {
+        HIPCHK(hipMemcpyAsync(outIds[j], dOutIds + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(outKeys[j], dOutKeys + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(outCounts[j], dOutCounts + j * bwin, bwin * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(c->h_pf, c->wPfCtl.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    c->state = 2;
     return ZH_OK;
 }
 
@@ -1492,6 +1594,10 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     }
     if (tot.visits > 0xFFFFFFFull || tot.rows >= (1ull << 36))
         return fail(ZH_ELIMIT, "more than 2^28 leaf visits or 2^36 scored rows in one batch; use a smaller batch");
+    c->sv_ids.assign(outIds, outIds + nwin); c->sv_keys.assign(outKeys, outKeys + nwin); c->sv_counts.assign(outCounts, outCounts + nwin);
+    c->sv_heavy = heavy;
+    if (c->prefilter && (tot.flags & 1u)) c->prefilter = false;  // the visit log ran out: the emit walk and the sweep serve this batch
+    if (c->prefilter) return finish_prefilter(c, dOutIds, dOutKeys, dOutCounts, outIds, outKeys, outCounts);
     if ((rc = c->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
     if ((rc = c->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;
     if ((rc = c->wGroupRowOff.ensure(std::max<uint64_t>(tot.groups, 1) * 8))) return rc;
@@ -1579,9 +1685,29 @@ int ctx_wait(zh_search_ctx *c) {
     c->state = 0;
     HIPCHK(hipEventSynchronize(c->ev[5]));
     if (c->trivial) return ZH_OK;
+    const bool pf = c->prefilter;
+    const uint32_t pf_amb = pf ? c->h_pf[0] : 0, pf_flags = pf ? c->h_pf[1] : 0, pf_exact = pf ? c->h_pf[2] : 0;
+    if (pf_flags) {  // a candidate list (or the ambiguous-visit table) ran over: this batch again, swept the classic way
+        {
+            std::lock_guard<std::mutex> lk(ix->stats_mu);
+            ix->stats.prefilter_fallbacks_accum++;
+            ix->stats.prefilter_last_overflow = pf_flags;
+        }
+        ix->prefilter_strikes.fetch_add(1);
+        const std::vector<const float *> q = c->sv_q;
+        const std::vector<uint64_t *> ids = c->sv_ids, keys = c->sv_keys;
+        const std::vector<uint32_t *> counts = c->sv_counts;
+        c->prefilter_off_once = true;
+        int rc = ctx_begin(c, q.data(), c->nwin, c->bwin, c->k, c->metric, c->mode, c->s);
+        if (!rc) rc = ctx_finish(c, ids.data(), keys.data(), counts.data(), c->sv_heavy);
+        c->prefilter_off_once = false;
+        if (rc) return rc;
+        return ctx_wait(c);
+    }
+    if (pf) ix->prefilter_strikes = 0;
     const ZhTotals tot = c->tot;
     uint64_t uniq = 0;
-    if (ix->profiling >= 2 && tot.visits) {  // R_unique: rows of the distinct leaves touched by the batch
+    if (ix->profiling >= 2 && tot.visits && !pf) {  // R_unique: rows of the distinct leaves touched by the batch
         std::vector<ZhVisit> hv(tot.visits);
         HIPCHK(hipMemcpy(hv.data(), c->wVisits.p, tot.visits * sizeof(ZhVisit), hipMemcpyDeviceToHost));
         std::vector<std::pair<uint32_t, uint32_t>> leaves(hv.size());
@@ -1599,11 +1725,15 @@ int ctx_wait(zh_search_ctx *c) {
     zh_stats_t &st = ix->stats;
     st.batch = c->B; st.window_batches = c->nwin; st.visits = tot.visits; st.rows_scored = tot.rows; st.candidates = tot.takes;
     st.planes_dense = c->P_dense; st.planes_total = ix->n_planes;
-    const uint64_t swept = c->scan ? ix->n_rows : tot.group_rows;
+    const uint64_t swept = pf ? pf_exact : (c->scan ? ix->n_rows : tot.group_rows);
     st.rows_swept = swept;
-    st.sweep_bytes = c->scan ? ix->n_rows * ((uint64_t)4 * ix->opt.dim + 8 * ix->n_trees) + tot.rows * 8
-                             : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8;
-    st.table_scan = c->scan ? 1 : 0;
+    st.sweep_bytes = pf ? tot.rows * 64 + (uint64_t)pf_exact * 4 * ix->opt.dim  // one 64-byte sector of the score table per scored row
+                        : (c->scan ? ix->n_rows * ((uint64_t)4 * ix->opt.dim + 8 * ix->n_trees) + tot.rows * 8
+                                   : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8);
+    st.table_scan = c->scan && !pf ? 1 : 0;
+    st.prefiltered = pf ? 1 : 0;
+    st.prefilter_exact_visits = pf_amb;
+    st.prefilter_exact_rows = pf_exact;
     st.hash_from_scores = c->score_hash ? 1 : 0;
     st.hash_exact_fixups = c->score_hash ? tot.hash_fixups : 0;
     if (ix->profiling >= 2) st.rows_unique = uniq;
@@ -1615,7 +1745,7 @@ int ctx_wait(zh_search_ctx *c) {
         st.swept_rows_accum += swept;
         const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim);
         st.sweep_launches_accum += (swept + rpl - 1) / rpl;
-        st.scan_batches_accum += c->scan ? 1 : 0;
+        st.scan_batches_accum += c->scan && !pf ? 1 : 0;
     }
     return ZH_OK;
 }

@@ -205,6 +205,29 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
                                    uint64_t *dKeys, void *dScratch, hipStream_t s);
 
 // ---- launchers (zh_score.hip): every sign of a forest built from stored rows, from N row scores per query --------
+// Prefilter (zh_search.hip, "Prefilter"): a batch hashed from row scores picks the rows that can be among a pair's k best from
+// those scores; only they are scored with the reference's arithmetic.  Lists: one per (tree, query), `cap` slots, list (t, b) at
+// (t * B + b) * cap.  ctl[0] = ambiguous visits appended, ctl[1] = overflow bits (1 a list, 2 a list in the exact pass, 4 the
+// ambiguous-visit table, 8 a leaf longer than a wave), ctl[2] = rows scored exactly.
+struct ZhPrefilter {
+    const float *S;            // row scores S[row * Bp + b]
+    uint32_t Bp;
+    const float2 *leaf_meta;   // per slot of leaf_ids: {|r|^2 / 2, |r|} of the row stored there
+    const float *qnorm;        // |q| per query
+    uint32_t *rows, *counts;
+    uint32_t cap;
+    uint4 *amb;                // {pair, leaf_off, len, take}
+    uint32_t amb_cap;
+    uint32_t *ctl;
+};
+float zh_prefilter_bound(int metric, uint32_t d);
+hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float2 *dOut, hipStream_t s);
+hipError_t zh_launch_prefilter(ZhForestDev f, uint32_t d, uint32_t B, uint32_t k, int metric, int mode, const ZhPairCounts *dCounts,
+                               const ZhVisit *dInline, ZhWalkLog log, ZhPrefilter pf, hipStream_t s);
+hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX, const float *dQ, const float *dQQ, uint32_t B, int metric,
+                                     int mode, uint64_t id_base, ZhPrefilter pf, uint64_t *dKeys, uint64_t *dIds, hipStream_t s);
+hipError_t zh_launch_final_lists(uint32_t T, uint32_t B, uint32_t k, uint32_t cap, const uint64_t *dKeys, const uint64_t *dIds,
+                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s);
 hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *dHalfN2 /* may be null */, float *dNorm, hipStream_t s);
 // the score table of exactly four queries (dQ4: 4 x d): dS[row][0..3]
 hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const float *dQ4, float *dS, hipStream_t s);

@@ -2594,7 +2594,8 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
                                                      const uint32_t *__restrict__ shard_counts, uint64_t id_base,
                                                      uint64_t *__restrict__ out_ids, uint64_t *__restrict__ out_keys,
                                                      uint32_t *__restrict__ out_counts, uint64_t stride64,
-                                                     uint64_t stride32) {
+                                                     uint64_t stride32, uint32_t L) {
+    // MERGE: every source list has L slots per query (L = k for shard results; the prefilter's per-tree lists are longer)
     __shared__ uint64_t sk[FIN_SORT_N];
     __shared__ uint64_t si[FIN_SORT_N];
     __shared__ uint64_t rk[ZH_MAX_TOPK];
@@ -2603,7 +2604,7 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     uint64_t n_src;  // entries in the source stream (MERGE: S*k slots, some invalid)
     uint64_t c0 = 0;
-    if (MERGE) n_src = (uint64_t)T * k;  // T carries the shard count here
+    if (MERGE) n_src = (uint64_t)T * L;  // T carries the shard count here
     else { c0 = candBase[(uint64_t)b * T]; n_src = candBase[(uint64_t)(b + 1) * T] - c0; }
     __shared__ uint32_t s_fill;
     uint32_t have = 0;
@@ -2631,9 +2632,9 @@ __global__ __launch_bounds__(256) void final_kernel(const uint64_t *__restrict__
                 if (e < n_src) {
                     uint64_t key, id;
                     if (MERGE) {
-                        uint32_t s = (uint32_t)(e / k), j = (uint32_t)(e % k);
+                        uint32_t s = (uint32_t)(e / L), j = (uint32_t)(e % L);
                         bool valid = j < shard_counts[(size_t)s * stride32 + b];  // shard s starts stride32 counts further
-                        size_t src = (size_t)s * stride64 + (size_t)b * k + j;        // ... and stride64 ids / keys further
+                        size_t src = (size_t)s * stride64 + (size_t)b * L + j;        // ... and stride64 ids / keys further
                         key = valid ? cand_keys[src] : ~0ull;
                         id = valid ? cand_ids64[src] : ~0ull;
                     } else {
@@ -2679,7 +2680,7 @@ hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, ui
     if (!B) return hipSuccess;
     hipLaunchKernelGGL(final_kernel<false>, dim3(B), dim3(256), 0, s, dCandBase, B, T, k, dCandKeys, dCandIds,
                        (const uint64_t *)nullptr, (const uint32_t *)nullptr, id_base, dOutIds, dOutKeys, dOutCounts,
-                       (uint64_t)0, (uint64_t)0);
+                       (uint64_t)0, (uint64_t)0, k);
     return hipGetLastError();
 }
 
@@ -2742,6 +2743,326 @@ hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *d
     }
     hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, S, k, dKeys,
                        (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts,
-                       stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B);
+                       stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B, k);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefilter: which rows can be among a pair's k best is decided from the ROW SCORES the hash already computed.
+//
+// A batch hashed from row scores (zh_score.hip) holds S[row][q] = row . q for every stored row.  With the stored |r|^2/2 and
+// |r| that is every L2^2 / cosine distance of the batch up to rounding -- and the wandering walk of a small-leaf forest asks for
+// ~10^5 of them per query only to keep k.  So instead of sweeping the visited leaves (4*d bytes per scored row), a wave per
+// (query, tree) pair replays the pair's visits on the scores (one 64-byte sector per scored row):
+//   * value v and half-width e per row such that the key the reference computes lies in [v - e, v + e] in the value's scale
+//     (derivation at zh_prefilter_bound, rigorous in the same sense as the row-score hash);
+//   * a visit takes its `take` nearest rows (lsh.rs:300-330): decided by the values when the take-th and (take+1)-th intervals are
+//     disjoint, otherwise the visit is AMBIGUOUS and goes to the exact path (prefilter_amb_kernel: the leaf scored with the
+//     reference's arithmetic, as the sweep + select would);
+//   * of the rows taken, only those whose lower bound does not exceed the k-th smallest upper bound seen so far can be among
+//     the pair's k best -- a few more than k survive.
+// The survivors (and the ambiguous visits' rows) are then scored exactly (prefilter_keys_kernel, the canonical sums) and the
+// usual final top-k runs over num_trees short lists per query.  Results are bit-identical to the sweep's by construction; a list
+// or the ambiguous-visit table running over is reported to the host, which redoes the batch the classic way.
+// ------------------------------------------------------------------------------------------------
+#define PF_MAXLEN 8      // rows per leaf the per-lane selection handles (longer leaves: not prefiltered, zh_api.hip)
+#define PF_BUF 512       // survivors buffered per pair between compactions
+
+__device__ __forceinline__ uint32_t f32_sortable(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// KINDA 0: L2 family, v = |r|^2/2 - r.q (= (distance^2 - |q|^2) / 2: same order per query); 1: cosine distance; 2: 1 - cosine
+// distance (ZH_COSINE_PARITY keys) in the order of the key's bits.  false: nothing certain about this row (zero / tiny / infinite norms, NaN scores)
+template <int KINDA>
+__device__ __forceinline__ bool pf_value(float h, float nx, float s, float nq, float Kb, float &v, float &e) {
+    if (KINDA == 0) {
+        const float nn = nx + nq;
+        if (!(nn > 1e-12f)) return false;
+        v = h - s;
+        e = Kb * nn * nn;
+    } else {
+        if (!(nx > 1e-12f && nq > 1e-12f)) return false;  // simsimd's zero-norm cases, and norms whose squares left the normal range
+        float r = 1.0f - s / (nx * nq);
+        r = r > 0.f ? r : 0.f;
+        e = Kb;
+        if (KINDA == 2) {
+            // keys compare as the BITS of the f64 (distance.rs:23-25 as the oracle restates it): 1 - distance < 0 -- an obtuse angle --
+            // sorts after every non-negative key, larger magnitudes later.  v follows that order (2 + |key| for a negative key);
+            // a key within the bound of zero could be on either side: not certain
+            const float key = 1.0f - r;
+            if (!(fabsf(key) > e)) return false;
+            v = key > 0.f ? key : 2.0f - key;
+        } else
+            v = r;
+    }
+    return (v - v == 0.f) && (e - e == 0.f);
+}
+
+template <int KINDA>
+__global__ __launch_bounds__(64) void prefilter_kernel(ZhForestDev f, uint32_t T, uint32_t B, uint32_t k,
+                                                        const ZhPairCounts *__restrict__ counts, const ZhVisit *__restrict__ inl,
+                                                        ZhWalkLog wlog, ZhPrefilter pf, float Kb) {
+    __shared__ uint64_t bk[PF_BUF];  // sortable upper bound << 32 | sortable lower bound
+    __shared__ uint32_t br[PF_BUF];  // the row
+    const uint32_t lane = threadIdx.x;
+    const uint64_t pair = blockIdx.x;
+    const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
+    const size_t lp = (size_t)t * B + b;
+    const uint32_t nv = counts[pair].visits;
+    if (!nv) {
+        if (lane == 0) pf.counts[lp] = 0;
+        return;
+    }
+    const float nq = pf.qnorm[b];
+    uint32_t fill = 0, tau = 0xFFFFFFFFu;  // wave-uniform: buffered survivors, the k-th smallest upper bound so far (sortable)
+    bool over = false;
+    auto compact = [&]() {  // sort by upper bound, take the k-th as the new threshold, drop what it excludes
+        const uint32_t np2 = next_pow2(fill);
+        for (uint32_t i = fill + lane; i < np2; i += 64) { bk[i] = ~0ull; br[i] = ~0u; }
+        block_bitonic_sort<uint32_t>(bk, br, np2);
+        if (fill >= k) {
+            tau = (uint32_t)(bk[k - 1] >> 32);
+            uint32_t nf = 0;
+            for (uint32_t base = 0; base < fill; base += 64) {
+                const uint32_t i = base + lane;
+                const bool in = i < fill;
+                const uint64_t key = in ? bk[i] : 0ull;
+                const uint32_t row = in ? br[i] : 0u;
+                const bool keep = in && (uint32_t)key <= tau;
+                const uint64_t m = __ballot(keep);
+                __syncthreads();  // every lane holds its entry before any slot of this chunk is overwritten
+                if (keep) {
+                    const uint32_t slot = nf + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                    bk[slot] = key; br[slot] = row;
+                }
+                nf += (uint32_t)__popcll(m);
+            }
+            fill = nf;
+        }
+        __syncthreads();
+    };
+    auto process = [&](bool on, uint32_t leaf_off, uint32_t len, uint32_t take) {
+        float v[PF_MAXLEN], e[PF_MAXLEN];
+        uint32_t id[PF_MAXLEN];
+        bool amb = on && len > PF_MAXLEN;
+#pragma unroll
+        for (int j = 0; j < PF_MAXLEN; j++) {
+            id[j] = 0;
+            if (on && (uint32_t)j < len) id[j] = f.leaf_ids[(size_t)leaf_off + j];
+        }
+#pragma unroll
+        for (int j = 0; j < PF_MAXLEN; j++) {
+            v[j] = INFINITY; e[j] = 0.f;
+            if (on && (uint32_t)j < len) {
+                const float2 m = pf.leaf_meta[(size_t)leaf_off + j];
+                const float s = pf.S[(size_t)id[j] * pf.Bp + b];
+                if (!pf_value<KINDA>(m.x, m.y, s, nq, Kb, v[j], e[j])) { amb = true; v[j] = INFINITY; e[j] = 0.f; }
+            }
+        }
+        uint32_t rank[PF_MAXLEN];
+#pragma unroll
+        for (int j = 0; j < PF_MAXLEN; j++) {
+            rank[j] = 0;
+#pragma unroll
+            for (int i = 0; i < PF_MAXLEN; i++)
+                if (i != j) rank[j] += (v[i] < v[j] || (v[i] == v[j] && i < j)) ? 1u : 0u;
+        }
+        if (on && !amb && take < len) {  // the take nearest rows are certain when the intervals on both sides of the cut are disjoint
+            float maxin = -INFINITY, minout = INFINITY;
+#pragma unroll
+            for (int j = 0; j < PF_MAXLEN; j++)
+                if ((uint32_t)j < len) {
+                    if (rank[j] < take) maxin = fmaxf(maxin, v[j] + e[j]);
+                    else minout = fminf(minout, v[j] - e[j]);
+                }
+            if (!(minout > maxin)) amb = true;
+        }
+        if (on && amb) {
+            const uint32_t slot = atomicAdd(&pf.ctl[0], 1u);
+            if (slot < pf.amb_cap) pf.amb[slot] = make_uint4((uint32_t)pair, leaf_off, len, take);
+            else atomicOr(&pf.ctl[1], 4u);
+        }
+        const bool live = on && !amb;
+#pragma unroll
+        for (int j = 0; j < PF_MAXLEN; j++) {
+            const uint32_t lo = f32_sortable(v[j] - e[j]), hi = f32_sortable(v[j] + e[j]);
+            const bool pass = live && !over && (uint32_t)j < len && rank[j] < take && lo <= tau;
+            const uint64_t m = __ballot(pass);
+            if (m) {  // wave-uniform
+                if (pass) {
+                    const uint32_t slot = fill + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                    bk[slot] = ((uint64_t)hi << 32) | lo; br[slot] = id[j];
+                }
+                fill += (uint32_t)__popcll(m);
+                if (fill > PF_BUF - 64) {
+                    __syncthreads();
+                    compact();
+                    if (fill > PF_BUF - 64) over = true;  // more rows within the bound of the k-th best than the buffer holds
+                }
+            }
+        }
+    };
+    const uint32_t n_inl = nv < ZH_INLINE_VISITS ? nv : ZH_INLINE_VISITS;
+    {
+        const bool on = lane < n_inl;
+        uint32_t lo = 0, ln = 0, tk = 0;
+        if (on) { const ZhVisit vv = inl[pair * ZH_INLINE_VISITS + lane]; lo = vv.leaf_off; ln = vv.len; tk = vv.take; }
+        process(on, lo, ln, tk);
+    }
+    if (nv > ZH_INLINE_VISITS) {
+        uint32_t chunk = wlog.head[pair], remaining = nv - ZH_INLINE_VISITS;
+        while (remaining) {  // wave-uniform
+            const uint32_t cnt = remaining < ZH_LOG_CHUNK - 1 ? remaining : ZH_LOG_CHUNK - 1;
+            const uint2 *C = wlog.pool + (size_t)chunk * ZH_LOG_CHUNK;
+            const uint32_t next = C[0].x;
+            const bool on = lane >= 1 && lane <= cnt;
+            uint2 en = make_uint2(0, 0);
+            int4 r = make_int4(-1, 0, 0, 0);
+            if (on) { en = C[lane]; r = f.node_pack[en.x]; }
+            process(on, (uint32_t)r.y, (uint32_t)r.z, en.y);
+            remaining -= cnt; chunk = next;
+        }
+    }
+    __syncthreads();
+    if (fill) compact();
+    uint32_t n = fill;
+    if (n > pf.cap) { over = true; n = pf.cap; }
+    for (uint32_t i = lane; i < n; i += 64) pf.rows[lp * pf.cap + i] = br[i];
+    if (lane == 0) {
+        pf.counts[lp] = n;
+        if (over) atomicOr(&pf.ctl[1], 1u);
+    }
+}
+
+// an ambiguous visit, the reference's way: every row of the leaf scored with the canonical sums, the `take` smallest
+// (key, id) join the pair's list -- what sweep + select do for every visit of a batch that is not prefiltered
+template <int KIND>
+__global__ __launch_bounds__(256) void prefilter_amb_kernel(const float *__restrict__ X, uint32_t d, const float *__restrict__ Q,
+                                                             const float *__restrict__ QQ, uint32_t T, uint32_t B,
+                                                             const uint32_t *__restrict__ leaf_ids, int metric, int param,
+                                                             ZhPrefilter pf) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), nw = gridDim.x * 4;
+    const uint32_t total = pf.ctl[0] < pf.amb_cap ? pf.ctl[0] : pf.amb_cap;
+    for (uint32_t i = wave; i < total; i += nw) {
+        const uint4 a = pf.amb[i];
+        const uint32_t b = a.x / T, t = a.x % T, len = a.z, take = a.w;
+        const size_t lp = (size_t)t * B + b;
+        if (len > 64) {
+            if (lane == 0) atomicOr(&pf.ctl[1], 8u);
+            continue;
+        }
+        uint64_t mykey = ~0ull;
+        uint32_t myid = ~0u;
+        for (uint32_t j = 0; j < len; j++) {
+            const uint32_t id = leaf_ids[(size_t)a.y + j];
+            float s0, s1;
+            lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)b * d, d, lane, param, s0, s1);
+            const uint64_t key = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
+            if (lane == j) { mykey = key; myid = id; }
+        }
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < len; j++) {
+            const uint64_t kj = __shfl(mykey, (int)j);
+            const uint32_t ij = __shfl(myid, (int)j);
+            rank += (kj < mykey || (kj == mykey && ij < myid)) ? 1u : 0u;
+        }
+        if (lane < len && rank < take) {
+            const uint32_t slot = atomicAdd(&pf.counts[lp], 1u);
+            if (slot < pf.cap) pf.rows[lp * pf.cap + slot] = myid;
+            else atomicOr(&pf.ctl[1], 2u);
+        }
+    }
+}
+
+// the lists' rows scored exactly: one wave per slot
+template <int KIND>
+__global__ __launch_bounds__(256) void prefilter_keys_kernel(const float *__restrict__ X, uint32_t d, const float *__restrict__ Q,
+                                                              const float *__restrict__ QQ, uint32_t B, uint64_t lists, int metric,
+                                                              int param, uint64_t id_base, ZhPrefilter pf,
+                                                              uint64_t *__restrict__ keys, uint64_t *__restrict__ ids) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t lp = w / pf.cap;
+    const uint32_t slot = (uint32_t)(w % pf.cap);
+    if (lp >= lists) return;
+    const uint32_t c = pf.counts[lp];
+    if (slot >= (c < pf.cap ? c : pf.cap)) return;
+    const uint32_t b = (uint32_t)(lp % B);
+    const uint32_t row = pf.rows[w];
+    float s0, s1;
+    lane_sums_generic<KIND>(X + (size_t)row * d, Q + (size_t)b * d, d, lane, param, s0, s1);
+    if (lane == 0) {
+        keys[w] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
+        ids[w] = id_base + row;
+        atomicAdd(&pf.ctl[2], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void leaf_meta_kernel(const uint32_t *__restrict__ leaf_ids, uint64_t n, const float *__restrict__ hn2,
+                                                         const float *__restrict__ norm, float2 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = leaf_ids[i];
+    out[i] = make_float2(hn2[r], norm[r]);
+}
+hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float2 *dOut, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(leaf_meta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dLeafIds, n, dHalfN2, dNorm, dOut);
+    return hipGetLastError();
+}
+
+// Half-width of the interval the reference's key lies in around the value computed from a row score (u = 2^-24, c0 = ceil(d/256)
+// + 8 = longest chain of the canonical sums).
+// L2 family, in the scale of v = |r|^2/2 - r.q:  the canonical d* = sum (x_i - q_i)^2 is within (c0 + 3) u D of the real D =
+// |x|^2 + |q|^2 - 2 x.q; the score is within (d + 8) u |x||q| of x.q (the bound the row-score hash rests on), the stored |r|^2/2
+// within (d + 8) u |x|^2/2, their difference rounds once more: |d*/2 - (v + |q|^2/2)| <= (d + c0 + 13) u / 2 * (|x| + |q|)^2;
+// + 2 u (|x| + |q|)^2 for v +- e themselves, * 1.002 for the rounded norms the kernel squares.
+// Cosine: ab, a2, b2 within c0 u (relative to |x||q|, |x|^2, |q|^2) give ab / sqrt(a2 b2) within 2 c0 u of the real cosine; the
+// score and the two rounded norms give s / (|x||q|) within (2 (d + 8) + 4) u; + 4 u for the kernel's own roundings.
+float zh_prefilter_bound(int metric, uint32_t d) {
+    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0;
+    if (metric == ZH_COSINE) return (float)((2.0 * (c0 + 4.0) + 2.0 * (d + 9.0) + 8.0) * u * 1.002);
+    return (float)((0.5 * (d + c0 + 13.0) + 2.0) * u * 1.002);
+}
+
+hipError_t zh_launch_prefilter(ZhForestDev f, uint32_t d, uint32_t B, uint32_t k, int metric, int mode, const ZhPairCounts *dCounts,
+                               const ZhVisit *dInline, ZhWalkLog log, ZhPrefilter pf, hipStream_t s) {
+    const uint64_t pairs = (uint64_t)B * f.n_trees;
+    if (!pairs) return hipSuccess;
+    const float Kb = zh_prefilter_bound(metric, d);
+    const dim3 grid((uint32_t)pairs), blk(64);
+    if (metric == ZH_COSINE && mode == ZH_COSINE_PARITY)
+        hipLaunchKernelGGL(prefilter_kernel<2>, grid, blk, 0, s, f, f.n_trees, B, k, dCounts, dInline, log, pf, Kb);
+    else if (metric == ZH_COSINE)
+        hipLaunchKernelGGL(prefilter_kernel<1>, grid, blk, 0, s, f, f.n_trees, B, k, dCounts, dInline, log, pf, Kb);
+    else
+        hipLaunchKernelGGL(prefilter_kernel<0>, grid, blk, 0, s, f, f.n_trees, B, k, dCounts, dInline, log, pf, Kb);
+    return hipGetLastError();
+}
+
+hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX, const float *dQ, const float *dQQ, uint32_t B, int metric, int mode,
+                                     uint64_t id_base, ZhPrefilter pf, uint64_t *dKeys, uint64_t *dIds, hipStream_t s) {
+    const uint64_t lists = (uint64_t)B * f.n_trees;
+    if (!lists) return hipSuccess;
+    const uint64_t waves = lists * pf.cap;
+    const dim3 gk((uint32_t)((waves + 3) / 4)), blk(256);
+    if (metric == ZH_COSINE) {
+        hipLaunchKernelGGL(prefilter_amb_kernel<K_COS>, dim3(2048), blk, 0, s, dX, d, dQ, dQQ, f.n_trees, B, f.leaf_ids, metric, mode, pf);
+        hipLaunchKernelGGL(prefilter_keys_kernel<K_COS>, gk, blk, 0, s, dX, d, dQ, dQQ, B, lists, metric, mode, id_base, pf, dKeys, dIds);
+    } else {
+        hipLaunchKernelGGL(prefilter_amb_kernel<K_L2>, dim3(2048), blk, 0, s, dX, d, dQ, dQQ, f.n_trees, B, f.leaf_ids, metric, mode, pf);
+        hipLaunchKernelGGL(prefilter_keys_kernel<K_L2>, gk, blk, 0, s, dX, d, dQ, dQQ, B, lists, metric, mode, id_base, pf, dKeys, dIds);
+    }
+    return hipGetLastError();
+}
+
+hipError_t zh_launch_final_lists(uint32_t T, uint32_t B, uint32_t k, uint32_t cap, const uint64_t *dKeys, const uint64_t *dIds,
+                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    if (!B) return hipSuccess;
+    hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, T, k, dKeys,
+                       (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts, (uint64_t)B * cap, (uint64_t)B, cap);
     return hipGetLastError();
 }

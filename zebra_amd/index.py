@@ -277,8 +277,9 @@ class LSHIndex:
         check(lib().zh_set_dense_levels(self._h, levels))
 
     def set_sweep_mode(self, mode):
-        """0 = chosen per batch (default), 1 = leaf by leaf, 2 = table scan (zh_set_sweep_mode)"""
-        check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2}.get(mode, mode)))
+        """0 = chosen per batch (default: a batch hashed from row scores is prefiltered, not swept), 1 = leaf by leaf, 2 = table
+        scan, 3 = as 0 (zh_set_sweep_mode)"""
+        check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2, "prefilter": 3}.get(mode, mode)))
 
     def set_hash_mode(self, mode):
         """0 = chosen per batch (default), 1 = one dot product per plane, 2 = from row scores (zh_set_hash_mode)"""
