@@ -455,7 +455,26 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
               "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
               "window_batches": WIN}
-    if not scan:
+    if st.get("prefiltered"):
+        # The batch was hashed from row scores and PREFILTERED (zh_set_sweep_mode): no sweep ran.  `ms_sweep` is prefilter_kernel -- one
+        # wave per (query, tree) replays the pair's visits on the score table -- and one launch serves the whole internal batch.
+        # Algorithmic bytes per scored row: 4 (leaf id) + 8 (|r|^2/2, |r|) + 4 (its score); per visit: 8 (log entry) + 16 (node record).
+        # The score is a 4-byte read from a random 1-KiB row of the table: the kernel moves a 64-byte sector for it (sector_GBps).
+        n_b = max(st["timed_batches"], 1)
+        pf_ms = st["ms_sweep"] / n_b
+        rows_b, visits_b = st["sweep_rows_accum"] / n_b, st["visits"]
+        bytes_alg = 16.0 * rows_b + 24.0 * visits_b
+        bytes_sector = (64.0 + 12.0) * rows_b + 24.0 * visits_b
+        g = bytes_alg / (pf_ms * 1e-3) / 1e9 if pf_ms else 0.0
+        roof = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": bytes_alg, "kernel": "prefilter_kernel<%d>" % (2 if wl["metric"] == "cosine" else 0), "launch_ms": pf_ms,
+                "rows_per_launch": rows_b, "visits_per_launch": visits_b, "launches_per_batch": 1.0 / (WIN if steps >= WIN else 1), "window_batches": WIN,
+                "sector_GBps": bytes_sector / (pf_ms * 1e-3) / 1e9 if pf_ms else 0.0,
+                "exact_rows_per_launch": st["prefilter_exact_rows"], "exact_visits_per_launch": st["prefilter_exact_visits"],
+                "prefilter_fallbacks": st["prefilter_fallbacks_accum"],
+                "note": "no sweep in this regime: candidates are judged on the hash's row scores (64-byte sector gathers: latency-bound, not "
+                        "byte-bound); the batch's time is the hash (row-score GEMM + sign gather) and the walk -- stage_ms_per_batch"}
+    elif not scan:
         # Leaf-major sweep: SURVEY s8(d)'s bytes ARE what the kernel moves through HBM (PMC traffic 0.99-1.01x): HBM roofline.
         roof = {"bound": "hbm", "achieved": s8d_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s8d_GBps / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": bytes_alg,
