@@ -66,7 +66,9 @@ WORKLOADS = {
     "scale64m": dict(rows=64_000_000, dim=768, metric="cosine", k=10, batch=1024, M=32768, T=15, kind=0,
                      desc="64M x 768-d cosine top-10, batch=1024 (the metric's shape at the largest N that fits one GPU), "
                           "rows sharded across GPUs + RCCL top-k merge"),
-    "refdefault": dict(rows=1_000_000, dim=384, metric="l2sq", k=10, batch=256, M=5, T=15, kind=0,
+    # (its own host loop: every batch its own internal batch, two begun ahead -- the batch's time is hash + walk, a chain of dependent
+    # latencies that only other batches' chains can overlap; measured r03: window 2 / one ahead 11.9 ms, window 1 / two ahead 10.5 ms)
+    "refdefault": dict(rows=1_000_000, dim=384, metric="l2sq", k=10, batch=256, M=5, T=15, kind=0, window=1, lookahead_depth=2,
                        desc="1M x 384-d L2^2 top-10, batch=256, the reference's DEFAULT options (max_node_size 5, lsh.rs:131-138): "
                             "the wandering walk of DefaultTextDatabase"),
     "tiny": dict(rows=200_000, dim=768, metric="l2", k=100, batch=256, M=1024, T=15, kind=0,
@@ -76,7 +78,7 @@ WORKLOADS = {
 # cfg3_window_of_one: the bench line's workload with every batch its own internal batch -- the latency / throughput trade of --window
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
 OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg2", "cfg2", 1, 40), ("cfg4_one_of_8_shards", "cfg4", 8, 12),
-                 ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 8), ("scale64m_n1", "scale64m", 1, 6)]
+                 ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6)]
 
 
 def parse():
@@ -100,10 +102,10 @@ def parse():
     ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
                     help="host loop: begin window w+1 before finishing window w (its hash runs beside w's walk).  Pays when hash + walk "
                          "outweigh the sweep (reference-default options: -8 %% per batch), costs elsewhere; auto decides from the warm-up's stage times")
-    ap.add_argument("--lookahead-depth", type=int, default=1,
+    ap.add_argument("--lookahead-depth", type=int, default=None,
                     help="windows BEGUN ahead of the one being finished when the look-ahead loop runs (their hash and walk are enqueued on their "
                          "own streams and run beside the current window's walk / sweep)")
-    ap.add_argument("--window", type=int, default=2,
+    ap.add_argument("--window", type=int, default=None,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan"], default="auto",
                     help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
@@ -221,7 +223,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     pipelined = not args.no_pipeline
     NS = max(2, args.in_flight)
-    WIN = max(1, window_override or args.window) if pipelined else 1
+    WIN = max(1, window_override or args.window or wl.get("window", 2)) if pipelined else 1  # (default 2)
     if args.profile_run and pipelined:
         warmup = (warmup + WIN - 1) // WIN * WIN  # whole windows only: every sweep launch of the process is a full-window launch
     n_batches = steps + warmup
@@ -248,7 +250,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     r0 = make_results()
     cur = torch.cuda.current_stream()
-    LA = max(1, args.lookahead_depth)  # extra slots of the look-ahead loop
+    LA = max(1, args.lookahead_depth or wl.get("lookahead_depth", 1))  # extra slots of the look-ahead loop (default 1)
     if group is None:
         heavy = ix.sweep_stream()
         if args.debug_normal_priority_sweeps:
@@ -762,7 +764,8 @@ def main():
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",
                                                                "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
-                                                               "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling")
+                                                               "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling",
+                                                               "visits_per_launch", "sector_GBps", "exact_rows_per_launch", "exact_visits_per_launch", "prefilter_fallbacks", "note")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms")}

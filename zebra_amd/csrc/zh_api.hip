@@ -1469,14 +1469,16 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
         if ((rc = c->wLogPool.ensure(std::max<size_t>(first, 1) * ZH_LOG_CHUNK * sizeof(uint2)))) return rc;
         c->log_chunks = std::max<size_t>(first, 1);
     }
-    HIPCHK(zh_launch_batch_init(c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), (uint32_t)nn, c->wLogCtl.as<ZhLogCtl>(),
+    c->score_hash = use_score_hash(ix, B, c->P_dense);
+    c->prefilter = use_prefilter(ix, c, k, metric);
+    c->sv_q.assign(dQs, dQs + nwin);
+    // a prefiltered batch forms no leaf groups: no per-leaf visit counts to zero, to bump from the walk, or to scan afterwards
+    uint32_t *leaf_count = c->prefilter ? nullptr : c->wLeafCount.as<uint32_t>();
+    HIPCHK(zh_launch_batch_init(c->wLeafCount.as<uint32_t>(), c->wLeafFill.as<uint32_t>(), c->prefilter ? 0u : (uint32_t)nn, c->wLogCtl.as<ZhLogCtl>(),
                                 c->wTotals.as<ZhTotals>(), s));
     ZhForestDev f = forest_dev(ix);
     HIPCHK(hipEventRecord(c->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));
-    c->score_hash = use_score_hash(ix, B, c->P_dense);
-    c->prefilter = use_prefilter(ix, c, k, metric);
-    c->sv_q.assign(dQs, dQs + nwin);
     if (c->score_hash) {
         if ((rc = launch_score_hash(c, dQ, B, s))) return rc;
     } else if (c->P_dense)
@@ -1488,12 +1490,13 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
         bd.recs = ix->blk_recs.as<int4>(); bd.upper = ix->blk_upper.as<int4>(); bd.root = ix->blk_roots.as<int2>();
         bd.n_blocks = ix->n_blocks; bd.n_upper = ix->n_upper;
         HIPCHK(zh_launch_walk_blocked(f, bd, (uint32_t)B, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->wCounts.as<ZhPairCounts>(),
-                                      c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
+                                      c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), s));
     } else
         HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
-                                    c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wLeafCount.as<uint32_t>(), walk_log(c), s));
-    HIPCHK(zh_launch_leaf_scan(f, c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
-                               c->wGroupRowBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
+                                    c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), s));
+    if (!c->prefilter)
+        HIPCHK(zh_launch_leaf_scan(f, c->wLeafCount.as<uint32_t>(), c->wGroupBase.as<uint32_t>(),
+                                   c->wGroupRowBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(), s));
     HIPCHK(zh_launch_pair_scan(c->wCounts.as<ZhPairCounts>(), (uint32_t)pairs, c->wRowBase.as<uint64_t>(),
                                c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wTotals.as<ZhTotals>(),
                                c->wLogCtl.as<ZhLogCtl>(), s));
@@ -1596,7 +1599,16 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         return fail(ZH_ELIMIT, "more than 2^28 leaf visits or 2^36 scored rows in one batch; use a smaller batch");
     c->sv_ids.assign(outIds, outIds + nwin); c->sv_keys.assign(outKeys, outKeys + nwin); c->sv_counts.assign(outCounts, outCounts + nwin);
     c->sv_heavy = heavy;
-    if (c->prefilter && (tot.flags & 1u)) c->prefilter = false;  // the visit log ran out: the emit walk and the sweep serve this batch
+    if (c->prefilter && (tot.flags & 1u)) {
+        // the visit log ran out (an index's first wandering batches): this batch again the classic way -- its emit walk needs the
+        // per-leaf counts a prefiltered first half does not take -- and with a log that fits the next one
+        const std::vector<const float *> q = c->sv_q;
+        c->prefilter_off_once = true;
+        rc = ctx_begin(c, q.data(), nwin, bwin, k, c->metric, c->mode, s);
+        c->prefilter_off_once = false;
+        if (rc) return rc;
+        return ctx_finish(c, outIds, outKeys, outCounts, heavy);
+    }
     if (c->prefilter) return finish_prefilter(c, dOutIds, dOutKeys, dOutCounts, outIds, outKeys, outCounts);
     if ((rc = c->wVisits.ensure(std::max<uint64_t>(tot.visits, 1) * sizeof(ZhVisit)))) return rc;
     if ((rc = c->wGroups.ensure(std::max<uint64_t>(tot.groups, 1) * sizeof(ZhGroup)))) return rc;

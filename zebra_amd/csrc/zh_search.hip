@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
             }
         } else {
             if (mine) {
-                atomicAdd(&leafCount[v.node], 1u);
+                if (leafCount) atomicAdd(&leafCount[v.node], 1u);  // (a prefiltered batch forms no leaf groups)
                 if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
             }
             if (nv > ZH_INLINE_VISITS && log_ok) {  // row-uniform: entries [max(first, 32), nv) go to the log
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         v.b = b; v.leaf_off = va.y; v.len = va.z; v.take = va.w; v.node = va.x; v.pad = 0;
         v.row_off = vb_r[slot]; v.cand_off = vb_c[slot];
         if (mine) {
-            atomicAdd(&leafCount[v.node], 1u);
+            if (leafCount) atomicAdd(&leafCount[v.node], 1u);  // (a prefiltered batch forms no leaf groups)
             if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
         }
         if (upto > ZH_INLINE_VISITS && log_ok) {
