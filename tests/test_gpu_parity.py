@@ -662,6 +662,45 @@ def test_visit_log_overflow_falls_back_to_the_emit_walk(za, env):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+_LAZY_LOG_SCRIPT = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import zebra_amd as za
+from oracle import zebra_oracle as zo
+n, d, M, T, k, B = 20000, 128, 5, 5, 10, 16
+X = zo.synth_rows(n, d)
+Q = zo.synth_queries(B, d, n)
+ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+ix.add(X)
+ix.set_dense_levels(100)
+ix.set_hash_mode("scores")
+f = zo.Forest.from_arrays(X, M, ix.get_forest())
+oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+for mode in ("auto", "auto", "auto", "auto", "leaf", "leaf"):  # the blocked view (and with it the lazily fixed signs) arrives with the third batch
+    ix.set_sweep_mode(mode)
+    ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+    assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all(), mode
+st = ix.stats()
+assert st["hash_from_scores"] == 1 and st["hash_exact_fixups"] > 0, st
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"ZH_WALK_LOG_CHUNKS": "3", "ZH_WALK_LOG_FIXED": "1"}, {"ZH_WALK_LOG_CHUNKS": "3"}])
+def test_visit_log_overflow_with_lazily_fixed_signs(za, env):
+    """the row-score hash leaves its uncertain signs flagged for the blocked walk (zh_score.hip); a batch whose visit log runs out is
+    walked again by the pointer walk, which reads plain bits: the flagged signs are recomputed first -- both walks must see the
+    same forest, or the second one writes past what the first one counted"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _LAZY_LOG_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_reference_format_round_trip_through_the_gpu_index(za):
     """a forest built on the GPU, written out as the reference's tree values (bincode-legacy Node<N>,
     lsh.rs:99-105), read back against the vectors in ANOTHER row order (fjall iterates by key), serves the same answers."""

@@ -102,7 +102,7 @@ struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
         wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl,
-        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl;
+        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl, wUnc;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -122,6 +122,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     uint32_t score_Bp = 0;    // ... for this many (padded) queries per stored row
+    bool lazy_fix = false;    // ... with the uncertain signs flagged (wUnc) for the blocked walk to recompute when it meets one
     // prefilter (zh_search.hip): the batch's candidates are picked from those row scores and only they are scored exactly.  Its
     // control words come back pinned; a list that ran over makes zh_search_wait redo the batch the classic way, from these:
     bool prefilter = false, prefilter_off_once = false;
@@ -134,7 +135,7 @@ struct zh_search_ctx {
     std::vector<DevBuf *> all_bufs() {
         return {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                 &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
-                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl};
+                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl, &wUnc};
     }
     void release_all() {
         for (DevBuf *b : all_bufs()) b->release();
@@ -1325,7 +1326,7 @@ static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense) {
     return t_score < 0.7 * t_dense;
 }
 
-static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStream_t s) {
+static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, bool lazy, hipStream_t s) {
     zh_index *ix = c->ix;
     const uint32_t d = ix->opt.dim;
     int rc;
@@ -1351,6 +1352,7 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
     if (B % 4) {  // pad the batch with zero queries to a multiple of four (their signs are computed and never read)
         const size_t Bp = (B + 3) & ~(size_t)3;
         if ((rc = c->wQpad.ensure(Bp * d * 4)) || (rc = c->wBits.ensure(Bp * c->wpq * 4))) return rc;
+        if (lazy && (rc = c->wUnc.ensure(Bp * c->wpq * 4))) return rc;
         HIPCHK(hipMemcpyAsync(c->wQpad.p, dQ, B * d * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemsetAsync(c->wQpad.as<float>() + B * d, 0, (Bp - B) * d * 4, s));
         dQ = c->wQpad.as<float>();
@@ -1379,7 +1381,8 @@ static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, hipStr
     ZhTotals *tot = c->wTotals.as<ZhTotals>();
     HIPCHK(zh_launch_score_signs(c->wScore.as<float>(), (uint32_t)B, ix->plane_samples.as<uint2>(), ix->n_planes, ix->row_hn2.as<float>(),
                                  ix->row_norm.as<float>(), ix->plane_hab.as<float4>(), c->wQnorm.as<float>(), dQ, d, ix->planes.as<float>(), ix->consts.as<float>(),
-                                 c->wBits.as<uint32_t>(), c->wpq, c->wFixList.as<uint2>(), fix_cap, &tot->hash_fixups, s));
+                                 c->wBits.as<uint32_t>(), c->wpq, c->wFixList.as<uint2>(), fix_cap, &tot->hash_fixups,
+                                 lazy ? c->wUnc.as<uint32_t>() : nullptr, s));
     return ZH_OK;
 }
 
@@ -1479,18 +1482,22 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     ZhForestDev f = forest_dev(ix);
     HIPCHK(hipEventRecord(c->ev[0], s));
     if (metric == ZH_COSINE) HIPCHK(zh_launch_qnorm(dQ, (uint32_t)B, d, c->wQQ.as<float>(), s));
+    static const bool no_blocks = getenv("ZH_WALK_NO_BLOCKS") != nullptr;  // A/B: the pointer walk for all-dense signs too
+    const bool blocked = c->P_dense >= ix->n_planes && ix->n_planes && ix->blocks_valid && !no_blocks;
+    static const bool eager_fix = getenv("ZH_EAGER_FIXUPS") != nullptr;  // A/B: every uncertain sign recomputed before the walk
+    c->lazy_fix = c->score_hash && blocked && !eager_fix && ((B + 3) & ~(size_t)3) != 4 && d % 4 == 0;  // (plane_above_wave's shape)
+    if (c->lazy_fix && (rc = c->wUnc.ensure(std::max<size_t>((size_t)B * c->wpq * 4, 4)))) return rc;
     if (c->score_hash) {
-        if ((rc = launch_score_hash(c, dQ, B, s))) return rc;
+        if ((rc = launch_score_hash(c, dQ, B, c->lazy_fix, s))) return rc;
     } else if (c->P_dense)
         HIPCHK(zh_launch_hash_dense(dQ, (uint32_t)B, f.planes, f.consts, c->P_dense, d, c->wBits.as<uint32_t>(), c->wpq, nullptr, s));
     HIPCHK(hipEventRecord(c->ev[1], s));
-    static const bool no_blocks = getenv("ZH_WALK_NO_BLOCKS") != nullptr;  // A/B: the pointer walk for all-dense signs too
-    if (c->P_dense >= ix->n_planes && ix->n_planes && ix->blocks_valid && !no_blocks) {
+    if (blocked) {
         ZhBlocksDev bd;
         bd.recs = ix->blk_recs.as<int4>(); bd.upper = ix->blk_upper.as<int4>(); bd.root = ix->blk_roots.as<int2>();
         bd.n_blocks = ix->n_blocks; bd.n_upper = ix->n_upper;
         HIPCHK(zh_launch_walk_blocked(f, bd, (uint32_t)B, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->wCounts.as<ZhPairCounts>(),
-                                      c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), s));
+                                      c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), c->lazy_fix ? c->wUnc.as<uint32_t>() : nullptr, dQ, d, s));
     } else
         HIPCHK(zh_launch_walk_count(f, dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
                                     c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), s));
@@ -1628,6 +1635,8 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
                                 c->wGroupRowOff.as<uint64_t>(), walk_log(c), s));
     } else {
         // the visit log ran out of chunks: walk again, emitting this time, and give the next batch a log that fits
+        if (c->lazy_fix)  // the pointer walk reads plain sign bits: the flagged ones are recomputed first
+            HIPCHK(zh_launch_score_unc_fix(c->dQ, (uint32_t)B, d, f.planes, f.consts, ix->n_planes, c->wBits.as<uint32_t>(), c->wUnc.as<uint32_t>(), c->wpq, s));
         HIPCHK(zh_launch_walk_emit(f, c->dQ, (uint32_t)B, d, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->P_dense,
                                    c->wCounts.as<ZhPairCounts>(), c->wInline.as<ZhVisit>(), c->wRowBase.as<uint64_t>(),
                                    c->wCandBase.as<uint64_t>(), c->wVisitBase.as<uint64_t>(), c->wVisits.as<ZhVisit>(),
@@ -1943,7 +1952,7 @@ extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *o
             c->wpq = wpq;
             if ((rc = c->wTotals.ensure(sizeof(ZhTotals))) || (rc = c->wBits.ensure(nb * wpq * 4))) return rc;
             HIPCHK(hipMemsetAsync(c->wTotals.p, 0, sizeof(ZhTotals), s));
-            if ((rc = launch_score_hash(c, dq.as<float>(), nb, s))) return rc;
+            if ((rc = launch_score_hash(c, dq.as<float>(), nb, false, s))) return rc;
             HIPCHK(hipMemcpyAsync(hb.data(), c->wBits.p, nb * wpq * 4, hipMemcpyDeviceToHost, s));
             ZhTotals ht;
             HIPCHK(hipMemcpyAsync(&ht, c->wTotals.p, sizeof ht, hipMemcpyDeviceToHost, s));

@@ -139,7 +139,8 @@ hipError_t zh_launch_walk_count(ZhForestDev f, const float *dQ, uint32_t B, uint
 // the counting pass for all-dense signs over the blocked forest: one memory round trip per BLOCK instead of per node
 hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
                                   uint32_t words_per_q, ZhPairCounts *dCounts, ZhVisit *dInline, uint32_t *dLeafCount,
-                                  ZhWalkLog log, hipStream_t s);
+                                  ZhWalkLog log, const uint32_t *dUnc /* null, or the row-score hash's flagged signs */, const float *dQ,
+                                  uint32_t d, hipStream_t s);
 // places every visit recorded by the counting pass (inline + log) and joins the leaf groups: the cheap, flat
 // replacement of the emit walk whenever the log did not overflow
 hipError_t zh_launch_expand(ZhForestDev f, uint32_t B, const ZhPairCounts *dCounts, const ZhVisit *dInline,
@@ -236,9 +237,11 @@ hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const 
 // inside the rounding bound recomputed exactly (list of fix_cap entries; *dFixCount must be 0 on entry and receives their number)
 // dPlaneHab: per plane {|a|^2/2, |b|^2/2, |a| + |b|, 0} of its sample rows (zh_launch_plane_hab), read in plane order by the signs kernel
 hipError_t zh_launch_plane_hab(const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm, float4 *dOut, hipStream_t s);
+hipError_t zh_launch_score_unc_fix(const float *dQ, uint32_t B, uint32_t d, const float *dPlanes, const float *dConsts, uint32_t P,
+                                   uint32_t *dBits, const uint32_t *dUnc, uint32_t wpq, hipStream_t s);
 hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
                                  const float4 *dPlaneHab, const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
-                                 uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
+                                 uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount, uint32_t *dUnc /* null: list + fix-up kernel */,
                                  hipStream_t s);
 
 // ---- launchers (zh_build.hip) ----------------------------------------------------------------

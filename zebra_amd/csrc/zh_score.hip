@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void score_signs_kernel(const float *__restric
                                                            const float *__restrict__ qnorm,
                                                            float K, uint32_t *__restrict__ bits, uint32_t wpq,
                                                            uint2 *__restrict__ fix_list, uint32_t fix_cap,
-                                                           unsigned long long *__restrict__ fix_count) {
+                                                           unsigned long long *__restrict__ fix_count, uint32_t *__restrict__ unc) {
+    // unc != null ("lazy" fix-ups): the uncertain signs are not listed for the fix-up kernel but flagged in a second bit matrix of
+    // the same shape; the blocked walk recomputes the ones it actually steps on (zh_search.hip) -- a wandering walk meets ~5 % of
+    // the forest's planes per query, so ~95 % of the listed fix-ups were signs nobody read
     __shared__ uint32_t sbits[256][9];  // [query of the chunk][word of the block] (+1: the eight words of a query start on different banks)
+    __shared__ uint32_t subits[256][9];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t Wb = blockIdx.x * 8;
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(256) void score_signs_kernel(const float *__restric
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     sbits[4 * lane + c][wv * 2 + i] = sw[c];
-                    uint32_t u = uw[c];
+                    if (unc) subits[4 * lane + c][wv * 2 + i] = uw[c];
+                    uint32_t u = unc ? 0u : uw[c];
                     while (u) {
                         const uint32_t j = (uint32_t)__builtin_ctz(u);
                         u &= u - 1;
@@ -169,6 +174,11 @@ __global__ __launch_bounds__(256) void score_signs_kernel(const float *__restric
             uint4 *dst = reinterpret_cast<uint4 *>(bits + (size_t)qt * wpq + Wb);
             dst[0] = make_uint4(sbits[threadIdx.x][0], sbits[threadIdx.x][1], sbits[threadIdx.x][2], sbits[threadIdx.x][3]);
             dst[1] = make_uint4(sbits[threadIdx.x][4], sbits[threadIdx.x][5], sbits[threadIdx.x][6], sbits[threadIdx.x][7]);
+            if (unc) {
+                uint4 *du = reinterpret_cast<uint4 *>(unc + (size_t)qt * wpq + Wb);
+                du[0] = make_uint4(subits[threadIdx.x][0], subits[threadIdx.x][1], subits[threadIdx.x][2], subits[threadIdx.x][3]);
+                du[1] = make_uint4(subits[threadIdx.x][4], subits[threadIdx.x][5], subits[threadIdx.x][6], subits[threadIdx.x][7]);
+            }
         }
         __syncthreads();
     }
@@ -272,6 +282,36 @@ __global__ __launch_bounds__(256) void score_overflow_kernel(const float *__rest
     bits[(size_t)q * wpq + W] = word;
 }
 
+// lazy fix-ups after all: a consumer other than the blocked walk needs the batch's signs (the emit walk of a batch whose visit log
+// ran out): every flagged sign recomputed in place, a thread per sign word
+__global__ __launch_bounds__(256) void score_unc_fix_kernel(const float *__restrict__ Q, uint32_t B, uint32_t d, const float *__restrict__ planes,
+                                                             const float *__restrict__ consts, uint32_t P, uint32_t *__restrict__ bits,
+                                                             const uint32_t *__restrict__ unc, uint32_t wpq) {
+    const uint32_t words = (P + 31) / 32;
+    const unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned long long)B * words) return;
+    const uint32_t q = (uint32_t)(idx / words), W = (uint32_t)(idx % words);
+    uint32_t u = unc[(size_t)q * wpq + W];
+    if (!u) return;
+    uint32_t word = bits[(size_t)q * wpq + W];
+    while (u) {
+        const uint32_t j = (uint32_t)__builtin_ctz(u);
+        u &= u - 1;
+        const uint32_t p = W * 32 + j;
+        if (p >= P) break;
+        const bool above = zh_plane_above(planes + (size_t)p * d, consts[p], Q + (size_t)q * d, d);
+        word = above ? word | (1u << j) : word & ~(1u << j);
+    }
+    bits[(size_t)q * wpq + W] = word;
+}
+hipError_t zh_launch_score_unc_fix(const float *dQ, uint32_t B, uint32_t d, const float *dPlanes, const float *dConsts, uint32_t P,
+                                   uint32_t *dBits, const uint32_t *dUnc, uint32_t wpq, hipStream_t s) {
+    const unsigned long long n = (unsigned long long)B * ((P + 31) / 32);
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(score_unc_fix_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dQ, B, d, dPlanes, dConsts, P, dBits, dUnc, wpq);
+    return hipGetLastError();
+}
+
 // per plane: {|a|^2 / 2, |b|^2 / 2, |a| + |b|, 0} of its two sample rows (the same float values score_signs4 / the overflow path
 // read from the per-row arrays)
 __global__ __launch_bounds__(256) void plane_hab_kernel(const uint2 *__restrict__ samples, uint32_t P, const float *__restrict__ hn2,
@@ -294,7 +334,7 @@ float zh_score_bound_factor(uint32_t d) { return (float)(d + 8) * 5.9604645e-8f 
 hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamples, uint32_t P, const float *dHalfN2, const float *dRowNorm,
                                  const float4 *dPlaneHab, const float *dQNorm, const float *dQ, uint32_t d, const float *dPlanes, const float *dConsts,
                                  uint32_t *dBits, uint32_t wpq, uint2 *dFixList, uint32_t fix_cap, unsigned long long *dFixCount,
-                                 hipStream_t s) {
+                                 uint32_t *dUnc, hipStream_t s) {
     if (!B || !P) return hipSuccess;
     const uint32_t words = (P + 31) / 32;
     const float K = zh_score_bound_factor(d);
@@ -303,7 +343,8 @@ hipError_t zh_launch_score_signs(const float *dS, uint32_t B, const uint2 *dSamp
                            dFixList, fix_cap, dFixCount);
     else
         hipLaunchKernelGGL(score_signs_kernel, dim3((words + 7) / 8), dim3(256), 0, s, dS, B, dSamples, P, dPlaneHab, dQNorm, K,
-                           dBits, wpq, dFixList, fix_cap, dFixCount);
+                           dBits, wpq, dFixList, fix_cap, dFixCount, B == 4 ? nullptr : dUnc);
+    if (dUnc && B != 4) return hipGetLastError();  // lazy: the walk recomputes the flagged signs it meets
     hipLaunchKernelGGL(score_fixup_kernel, dim3(4096), dim3(256), 0, s, dQ, d, dPlanes, dConsts, dBits, wpq, dFixList, fix_cap, dFixCount);
     const unsigned long long n = (unsigned long long)B * words;
     hipLaunchKernelGGL(score_overflow_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dS, B, dSamples, P, dHalfN2, dRowNorm,

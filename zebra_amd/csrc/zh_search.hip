@@ -826,6 +826,30 @@ __device__ __forceinline__ uint32_t in_vgpr_shl8(uint32_t x) {
     asm volatile("v_lshlrev_b32 %0, 8, %1" : "=v"(r) : "s"(x));
     return r;
 }
+// point_is_above for ONE plane by a whole wave (d % 4 == 0): the plane's and the query's rows are loaded 256 elements at a time,
+// lane i holding float4 i of the pass -- one round trip per 256 elements instead of zh_plane_above's one per 32 -- and the
+// k-ascending fma chain (the order contract of the hash) runs on v_readlane broadcasts.  Wave-uniform arguments and result.
+__device__ __forceinline__ bool plane_above_wave(const float *__restrict__ w, float c, const float *__restrict__ x, uint32_t d,
+                                                 uint32_t lane) {
+    const float4 *w4 = reinterpret_cast<const float4 *>(w), *x4 = reinterpret_cast<const float4 *>(x);
+    const uint32_t n4 = d / 4;
+    float acc = 0.0f;
+    for (uint32_t base = 0; base < n4; base += 64) {  // 256 elements per pass, eight registers: the walk's waves stay small enough
+        float4 wr = make_float4(0.f, 0.f, 0.f, 0.f), xr = wr;  // for the hash of the next batch to find room beside them
+        if (base + lane < n4) { wr = w4[base + lane]; xr = x4[base + lane]; }
+        const uint32_t cnt = n4 - base < 64u ? n4 - base : 64u;
+        for (uint32_t t = 0; t < cnt; t++) {
+#define RLF(v_) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_), (int)t))
+            acc = __builtin_fmaf(RLF(wr.x), RLF(xr.x), acc);
+            acc = __builtin_fmaf(RLF(wr.y), RLF(xr.y), acc);
+            acc = __builtin_fmaf(RLF(wr.z), RLF(xr.z), acc);
+            acc = __builtin_fmaf(RLF(wr.w), RLF(xr.w), acc);
+#undef RLF
+        }
+    }
+    return ((double)acc + (double)c) >= 0.0;  // lsh.rs:40-42, as zh_plane_above
+}
+
 #define WALK_RING 128u       // visit records waiting to leave the wave: ring of 128 slots (+ one slot every lane without a visit writes to)
 #define WALK_FLUSH 32u       // ... leave 32 at a time (< ZH_LOG_CHUNK - 1: at most one new log chunk per flush)
 #define WALK_EXIT (0x80000000u | 63u)
@@ -833,7 +857,10 @@ __device__ __forceinline__ uint32_t in_vgpr_shl8(uint32_t x) {
 __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
                                                            const uint32_t *__restrict__ bits, uint32_t wpq,
                                                            ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
-                                                           uint32_t *__restrict__ leafCount, ZhWalkLog wlog) {
+                                                           uint32_t *__restrict__ leafCount, ZhWalkLog wlog,
+                                                           const uint32_t *__restrict__ unc, const float *__restrict__ Q, uint32_t d) {
+    // unc != null: the row-score hash left its uncertain signs flagged instead of fixing them (zh_score.hip, "lazy"): a flagged sign
+    // is recomputed here with point_is_above's own arithmetic (plane_above_wave) when -- and only when -- the walk steps on its node
     __shared__ int4 ust[WALK_STACK];  // upper-level stack {child ref, n, the child's plane when it is an upper node}
     __shared__ uint4 vb_a[WALK_RING + 1];
     __shared__ uint32_t vb_r[WALK_RING + 1], vb_c[WALK_RING + 1];
@@ -841,6 +868,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
     const uint64_t pair = blockIdx.x;
     const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
     const uint32_t *__restrict__ qbits = bits + (size_t)b * wpq;
+    const uint32_t *__restrict__ qunc = unc ? unc + (size_t)b * wpq : nullptr;
     if (n0 <= 0) {  // lsh.rs:306: the first leaf takes nothing and nothing is ever < 0: no visit
         if (lane == 0) { ZhPairCounts c; c.visits = 0; c.rows = 0; c.takes = 0; c.pad = 0; counts[pair] = c; }
         return;
@@ -910,8 +938,11 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
             WP(const uint64_t p_u0 = clock64(); p_uppers++;)
             const int4 ra = blk.upper[2 * (size_t)ref], rb = blk.upper[2 * (size_t)ref + 1];
             const uint32_t word = qbits[(uint32_t)pl >> 5];
+            const uint32_t uword = qunc ? qunc[(uint32_t)pl >> 5] : 0u;
             const int4 a = uni4(ra), c2 = uni4(rb);
-            const bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)word) >> (pl & 31)) & 1;
+            bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)word) >> (pl & 31)) & 1;
+            if (((uint32_t)__builtin_amdgcn_readfirstlane((int)uword) >> (pl & 31)) & 1)
+                above = plane_above_wave(f.planes + (size_t)pl * d, f.consts[pl], Q + (size_t)b * d, d, lane);
             if (usp < WALK_STACK && lane == 0) ust[usp] = make_int4(above ? a.y : a.z, n, above ? c2.x : c2.y, 0);
             usp++;
             ref = above ? a.z : a.y;  // lsh.rs:335-338: above -> right is main
@@ -927,18 +958,24 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         const uint32_t cnt = r0x >= 0 ? (uint32_t)rl(r.z, 0) : 1u;  // odd (a full binary subtree), so <= 63: lane 63 is never a node
         if (lane >= cnt) r = make_int4(-1, 0, 0, 0);
         int sgn = 0;
-        if (r.x >= 0) sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
+        uint32_t ub = 0;
+        if (r.x >= 0) {
+            sgn = (int)((qbits[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u);
+            if (qunc) ub = (qunc[(uint32_t)r.x >> 5] >> (r.x & 31)) & 1u;
+        }
         // One word per lane holds everything a step needs.  Inner node: main child | backup child << 8 (lsh.rs:335-338: above ->
         // right is main) -- the next step's v_readlane takes the word itself as its lane select (the hardware uses bits 5:0).  Leaf:
         // bit 31 | own lane -- unique in the block, so `pk == w` is true in the visited leaf's lane alone and that lane records the
         // visit from its own registers (`pkm`: the same word, or no word at all for an empty leaf, which is stepped on but not a
         // visit).  Lanes past the block read as empty leaves; lane 63 (WALK_EXIT) is where the stack's sentinel leads once the
-        // block is exhausted.
+        // block is exhausted.  A node whose sign is flagged looks like a leaf with bit 30 set: the descent stops on it, the sign is
+        // recomputed and the descent goes on (WALK_DESCEND).
         uint32_t pk = 0x80000000u | lane;
         const uint32_t pkm = r.x < 0 && r.z > 0 ? pk : 0xFFFFFFFFu;
         if (r.x >= 0) {
             const uint32_t l = (uint32_t)r.y & 0xFFFFu, rr = (uint32_t)r.y >> 16;
             pk = sgn ? (rr | (l << 8)) : (l | (rr << 8));
+            if (ub) pk = 0xC0000000u | lane;
         }
         WP(if (__builtin_amdgcn_readfirstlane((int)pk) == 12345) p_blocks++; const uint64_t p_d0 = clock64(); p_load += p_d0 - p_l0;
            const uint64_t p_fl0 = p_flush;)
@@ -952,12 +989,19 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         // down the main children to a leaf: 1 scalar + 5 vector instructions and the branch per inner node.  (Round 2's loop spent
         // 37 instructions here, most of them scalar copies of the walk's other live state.)
 #define WALK_DESCEND()                                                                                                       \
-        while (!(w >> 31)) {                                                                                                 \
-            const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
-            lstk = lane == lsp ? e_ : lstk;                                                                                  \
-            lsp++;                                                                                                           \
-            w = (uint32_t)rl((int)pk, w);                                                                                    \
-            WP(p_inner++;)                                                                                                   \
+        for (;;) {                                                                                                           \
+            while (!(w >> 31)) {                                                                                             \
+                const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
+                lstk = lane == lsp ? e_ : lstk;                                                                              \
+                lsp++;                                                                                                       \
+                w = (uint32_t)rl((int)pk, w);                                                                                \
+                WP(p_inner++;)                                                                                               \
+            }                                                                                                                \
+            if (!(w & 0x40000000u)) break;                                                                                   \
+            /* a flagged sign (one node in ~400): point_is_above itself, then on down */                                     \
+            const int p_ = rl(r.x, w);                                                                                       \
+            const uint32_t ry_ = (uint32_t)rl(r.y, w), l_ = ry_ & 0xFFFFu, rr_ = ry_ >> 16;                                  \
+            w = plane_above_wave(f.planes + (size_t)p_ * d, f.consts[p_], Q + (size_t)b * d, d, lane) ? (rr_ | (l_ << 8)) : (l_ | (rr_ << 8)); \
         }
         WALK_DESCEND();
         do {  // one leaf per turn; the loop is left through the sentinel: the block is done and `ret` is its return value
@@ -1025,11 +1069,11 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
 
 hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
                                   uint32_t words_per_q, ZhPairCounts *dCounts, ZhVisit *dInline, uint32_t *dLeafCount,
-                                  ZhWalkLog log, hipStream_t s) {
+                                  ZhWalkLog log, const uint32_t *dUnc, const float *dQ, uint32_t d, hipStream_t s) {
     const uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
     hipLaunchKernelGGL(walk_blocked_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, blk, B, n, dBits, words_per_q, dCounts,
-                       dInline, dLeafCount, log);
+                       dInline, dLeafCount, log, dUnc, dQ, d);
     return hipGetLastError();
 }
 
