@@ -153,7 +153,7 @@ typedef struct zh_stats_t {
     uint64_t prefilter_exact_rows;   /* ... rows scored exactly in total (= rows_swept) */
     uint64_t prefilter_fallbacks_accum; /* batches redone with the sweep because a candidate list ran over (since zh_stats_reset) */
     uint64_t prefilter_last_overflow;   /* ... what ran over in the most recent of them: 1 | 2 a (query, tree) list, 4 the table of
-                                         * visits to score exactly, 8 a leaf longer than 64 rows */
+                                         * visits to score exactly, 8 a leaf longer than 64 rows, 16 a query's lists together hold more than the final sort */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

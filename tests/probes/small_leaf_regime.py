@@ -23,6 +23,8 @@ if os.environ.get("DENSE_LEVELS"):
     ix.set_dense_levels(int(os.environ["DENSE_LEVELS"]))
 for _ in range(5):  # the first batch learns the visits per pair (on-demand hash + emit walk); once the forest has served a few
     ix.search_batch(Q, k, m)  # batches unchanged the library builds its derived views (blocked forest, row -> leaf table: host time, once)
+st0 = ix.stats()
+print("warm-up:", {a: st0[a] for a in ("prefiltered", "prefilter_fallbacks_accum", "prefilter_last_overflow", "prefilter_exact_visits", "prefilter_exact_rows")})
 ix.set_profiling(1)
 ix.stats(reset=True)
 t0 = time.perf_counter()
@@ -31,7 +33,8 @@ for _ in range(3):
 dt = (time.perf_counter() - t0) / 3
 st = ix.stats()
 print("ms/batch", round(dt * 1e3, 2), "qps", round(B / dt), {s: round(st["ms_" + s] / st["timed_batches"], 3) for s in ("hash", "walk", "sweep", "select", "final")},
-      "visits", st["visits"], "rows", st["rows_scored"], "cands", st["candidates"])
+      "visits", st["visits"], "rows", st["rows_scored"], "cands", st["candidates"],
+      {a: st[a] for a in ("hash_from_scores", "hash_exact_fixups", "prefiltered", "prefilter_exact_visits", "prefilter_exact_rows", "prefilter_fallbacks_accum", "prefilter_last_overflow")})
 f = zo.Forest.from_arrays(X, 5, ix.get_forest())
 for b in sorted({0, min(1, B - 1), B // 2, max(B - 2, 0), B - 1}):
     oi, ok = f.search(Q[b], k, zo.COSINE, zo.PARITY) if COS else f.search(Q[b], k, zo.L2SQ)

@@ -72,25 +72,24 @@ def test_prefilter_equals_oracle_and_sweep(za, n, d, M, T, k, B, kind, metric):
     ix.close()
 
 
-def test_a_forest_of_long_leaves_goes_back_to_the_sweep_and_stays_there(za):
+def test_a_forest_with_long_leaves(za):
     """clustered rows at d = 64 with max_node_size 3: splits between near-identical rows leave leaves of up to ~40 rows; every visit to
-    one takes the exact path and hands over `take` rows, the lists run over -> the batch is redone with the sweep, and after two such
-    batches the index stops trying until its trees change"""
+    one takes the exact path (the per-lane selection handles 8 rows), thresholded like the rest"""
     n, d, M, T, k, B = 20000, 64, 3, 4, 10, 16
     X = zo.synth_rows(n, d, kind=2)
     Q = zo.synth_queries(B, d, n, kind=2)
     ix = _index(za, X, M, T)
-    f = zo.Forest.from_arrays(X, M, ix.get_forest())
-    oi, ok, oc = f.search_batch(Q, k, zo.L2, 0)
-    ix.search_batch(Q, k, za.L2Distance())
-    ix.stats(reset=True)
-    seen = []
-    for _ in range(4):
-        ids, keys, counts = ix.search_batch(Q, k, za.L2Distance())
-        _same(ids, keys, counts, oi, ok, oc, "long leaves")
+    fo = ix.get_forest()
+    assert fo["right"][fo["plane"] < 0].max() > 8
+    f = zo.Forest.from_arrays(X, M, fo)
+    for metric in ("l2", "cos"):
+        m, om, omode = _metric(za, metric)
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        for _ in range(3):
+            ids, keys, counts = ix.search_batch(Q, k, m)
+            _same(ids, keys, counts, oi, ok, oc, metric)
         st = ix.stats()
-        seen.append((st["prefiltered"], st["prefilter_fallbacks_accum"]))
-    assert seen[-1][0] == 0 and seen[-1][1] == seen[-2][1] <= 2, seen  # no third attempt
+        assert st["prefiltered"] == 1 and st["prefilter_exact_visits"] > 0, st
     ix.close()
 
 
@@ -125,19 +124,29 @@ def test_a_list_that_runs_over_sends_the_batch_to_the_sweep(za):
     ix = _index(za, X, M, T)
     f = zo.Forest.from_arrays(X, M, ix.get_forest())
     oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+    m = za.L2SquaredDistance()
+    ix.search_batch(Q, k, m)
     ix.stats(reset=True)
     os.environ["ZH_PREFILTER_CAP"] = "3"  # fewer slots than k: every list runs over
     try:
-        ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+        seen = []
+        for _ in range(4):
+            ids, keys, counts = ix.search_batch(Q, k, m)
+            _same(ids, keys, counts, oi, ok, oc, "fallback")
+            st = ix.stats()
+            seen.append((st["prefiltered"], st["prefilter_fallbacks_accum"], st["prefilter_last_overflow"]))
     finally:
         del os.environ["ZH_PREFILTER_CAP"]
-    st = ix.stats()
-    assert st["prefilter_fallbacks_accum"] == 1 and st["prefiltered"] == 0, st
-    _same(ids, keys, counts, oi, ok, oc, "fallback")
-    ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())  # the next batch is prefiltered again
-    st = ix.stats()
-    assert st["prefilter_fallbacks_accum"] == 1 and st["prefiltered"] == 1, st
-    _same(ids, keys, counts, oi, ok, oc, "after")
+    # two batches in a row handed back to the sweep: the index stops trying until its trees change (no third attempt)
+    assert [s_[:2] for s_ in seen] == [(0, 1), (0, 2), (0, 2), (0, 2)] and seen[0][2] & 1, seen
+    ix.add(zo.synth_rows(64, d, row0=n))  # the trees change: the prefilter is tried again, with lists that fit
+    X2 = np.concatenate([X, zo.synth_rows(64, d, row0=n)])
+    f.insert(X2, n)
+    ix.set_dense_levels(-1)
+    for _ in range(3):
+        ids, keys, counts = ix.search_batch(Q, k, m)
+    assert ix.stats()["prefiltered"] == 1, ix.stats()
+    _same(ids, keys, counts, *f.search_batch(Q, k, zo.L2SQ, 0), "after the trees changed")
     ix.close()
 
 

@@ -1528,17 +1528,19 @@ static int finish_prefilter(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutK
     }
     const char *cap_e = getenv("ZH_PREFILTER_CAP");  // tests: lists that run over (read per batch)
     const uint32_t cap_env = cap_e ? (uint32_t)atoi(cap_e) : 0u;
-    const uint32_t cap = cap_env ? std::max<uint32_t>(cap_env, 1) : (k <= 16 ? 64u : (k <= 32 ? 128u : 256u));
+    const uint32_t cap = cap_env ? std::max<uint32_t>(cap_env, 1) : (k <= 16 && c->metric != ZH_COSINE ? 64u : (k <= 32 ? 128u : 256u));
+    // (cosine with parity keys: "nearest" is the smallest non-negative cosine, where candidates are densest, and every row within the
+    // bound of ZERO is a legitimate top candidate from the exact pass: ~49 rows per list at d = 768, batch 196 -- 64 slots ran over)
     const uint64_t lists = (uint64_t)B * T;
     const uint32_t amb_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, c->tot.visits / 32 + 1024), 1u << 26);
     c->pf_cap = cap;
-    if ((rc = c->wPfRows.ensure(lists * cap * 4)) || (rc = c->wPfCounts.ensure(lists * 4)) || (rc = c->wPfKeys.ensure(lists * cap * 8)) ||
+    if ((rc = c->wPfRows.ensure(lists * cap * 4)) || (rc = c->wPfCounts.ensure(lists * 8)) || (rc = c->wPfKeys.ensure(lists * cap * 8)) ||
         (rc = c->wPfIds.ensure(lists * cap * 8)) || (rc = c->wPfAmb.ensure((size_t)amb_cap * sizeof(uint4))) || (rc = c->wPfCtl.ensure(16)))
         return rc;
     HIPCHK(hipMemsetAsync(c->wPfCtl.p, 0, 16, s));
     ZhPrefilter pf;
     pf.S = c->wScore.as<float>(); pf.Bp = c->score_Bp; pf.leaf_meta = ix->leaf_meta.as<float2>(); pf.qnorm = c->wQnorm.as<float>();
-    pf.rows = c->wPfRows.as<uint32_t>(); pf.counts = c->wPfCounts.as<uint32_t>(); pf.cap = cap;
+    pf.rows = c->wPfRows.as<uint32_t>(); pf.counts = c->wPfCounts.as<uint32_t>(); pf.tau = reinterpret_cast<float *>(pf.counts + lists); pf.cap = cap;
     pf.amb = c->wPfAmb.as<uint4>(); pf.amb_cap = amb_cap; pf.ctl = c->wPfCtl.as<uint32_t>();
     ZhForestDev f = forest_dev(ix);
     HIPCHK(hipEventRecord(c->ev[2], s));
@@ -1551,7 +1553,7 @@ static int finish_prefilter(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutK
                                      c->wPfKeys.as<uint64_t>(), c->wPfIds.as<uint64_t>(), s));
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(zh_launch_final_lists(T, (uint32_t)B, (uint32_t)k, cap, c->wPfKeys.as<uint64_t>(), c->wPfIds.as<uint64_t>(), c->wPfCounts.as<uint32_t>(),
-                                 dOutIds, dOutKeys, dOutCounts, s));
+                                 dOutIds, dOutKeys, dOutCounts, pf.ctl + 1, s));
     for (size_t j = 0; j < nwin && nwin > 1; j++) {
         HIPCHK(hipMemcpyAsync(outIds[j], dOutIds + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(outKeys[j], dOutKeys + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));

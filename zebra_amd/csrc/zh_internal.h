@@ -216,6 +216,7 @@ struct ZhPrefilter {
     const float2 *leaf_meta;   // per slot of leaf_ids: {|r|^2 / 2, |r|} of the row stored there
     const float *qnorm;        // |q| per query
     uint32_t *rows, *counts;
+    float *tau;                // per list: k of the pair's rows have keys at or below this value (the scale of the prefilter's v); +inf: fewer than k
     uint32_t cap;
     uint4 *amb;                // {pair, leaf_off, len, take}
     uint32_t amb_cap;
@@ -228,7 +229,8 @@ hipError_t zh_launch_prefilter(ZhForestDev f, uint32_t d, uint32_t B, uint32_t k
 hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX, const float *dQ, const float *dQQ, uint32_t B, int metric,
                                      int mode, uint64_t id_base, ZhPrefilter pf, uint64_t *dKeys, uint64_t *dIds, hipStream_t s);
 hipError_t zh_launch_final_lists(uint32_t T, uint32_t B, uint32_t k, uint32_t cap, const uint64_t *dKeys, const uint64_t *dIds,
-                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s);
+                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts,
+                                 uint32_t *dOver /* the prefilter's overflow word: bit 16 = a query's lists hold more than the final sort */, hipStream_t s);
 hipError_t zh_launch_row_norms(const float *dX, uint64_t n, uint32_t d, float *dHalfN2 /* may be null */, float *dNorm, hipStream_t s);
 // the score table of exactly four queries (dQ4: 4 x d): dS[row][0..3]
 hipError_t zh_launch_row_scores4(const float *dX, uint64_t n, uint32_t d, const float *dQ4, float *dS, hipStream_t s);

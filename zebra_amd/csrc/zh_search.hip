@@ -2735,20 +2735,27 @@ hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, ui
 __global__ __launch_bounds__(64) void merge_wave_kernel(uint32_t B, uint32_t S, uint32_t k, const uint64_t *__restrict__ keys,
                                                          const uint64_t *__restrict__ ids, const uint32_t *__restrict__ counts,
                                                          uint64_t *__restrict__ out_ids, uint64_t *__restrict__ out_keys,
-                                                         uint32_t *__restrict__ out_counts, uint64_t stride64, uint64_t stride32) {
+                                                         uint32_t *__restrict__ out_counts, uint64_t stride64, uint64_t stride32,
+                                                         uint32_t L, uint32_t *__restrict__ over) {
+    // every source list has L slots per query (L = k for shard results; the prefilter's per-tree lists are longer and mostly
+    // empty): the valid entries are packed, so the sort is as long as what is there
     __shared__ uint64_t sk[MERGE_WAVE_N], si[MERGE_WAVE_N];
-    const uint32_t b = blockIdx.x, lane = threadIdx.x, n = S * k, np2 = next_pow2(n);
-    for (uint32_t e = lane; e < np2; e += 64) {
-        uint64_t key = ~0ull, id = ~0ull;
-        if (e < n) {
-            const uint32_t sh = e / k, j = e % k;
-            if (j < counts[(size_t)sh * stride32 + b]) {
-                const size_t src = (size_t)sh * stride64 + (size_t)b * k + j;
-                key = keys[src]; id = ids[src];
-            }
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    uint32_t n = 0;
+    for (uint32_t sh = 0; sh < S; sh++) {  // wave-uniform
+        const uint32_t c0 = counts[(size_t)sh * stride32 + b], c = c0 < L ? c0 : L;
+        if (n + c > MERGE_WAVE_N) {  // only with S * L > MERGE_WAVE_N slots (the prefilter's lists, launched with `over`): reported, the batch is redone
+            if (lane == 0 && over) atomicOr(over, 16u);
+            break;
         }
-        sk[e] = key; si[e] = id;
+        for (uint32_t j = lane; j < c; j += 64) {
+            const size_t src = (size_t)sh * stride64 + (size_t)b * L + j;
+            sk[n + j] = keys[src]; si[n + j] = ids[src];
+        }
+        n += c;
     }
+    const uint32_t np2 = next_pow2(n);
+    for (uint32_t e = n + lane; e < np2; e += 64) { sk[e] = ~0ull; si[e] = ~0ull; }
     __syncthreads();
     for (uint32_t size = 2; size <= np2; size <<= 1)
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -2782,7 +2789,7 @@ hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *d
     if (!B) return hipSuccess;
     if ((uint64_t)S * k <= MERGE_WAVE_N) {
         hipLaunchKernelGGL(merge_wave_kernel, dim3(B), dim3(64), 0, s, B, S, k, dKeys, dIds, dCounts, dOutIds, dOutKeys, dOutCounts,
-                           stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B);
+                           stride64 ? stride64 : (uint64_t)B * k, stride32 ? stride32 : (uint64_t)B, k, (uint32_t *)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, S, k, dKeys,
@@ -2856,7 +2863,7 @@ __global__ __launch_bounds__(64) void prefilter_kernel(ZhForestDev f, uint32_t T
     const size_t lp = (size_t)t * B + b;
     const uint32_t nv = counts[pair].visits;
     if (!nv) {
-        if (lane == 0) pf.counts[lp] = 0;
+        if (lane == 0) { pf.counts[lp] = 0; pf.tau[lp] = INFINITY; }
         return;
     }
     const float nq = pf.qnorm[b];
@@ -2976,12 +2983,19 @@ __global__ __launch_bounds__(64) void prefilter_kernel(ZhForestDev f, uint32_t T
     for (uint32_t i = lane; i < n; i += 64) pf.rows[lp * pf.cap + i] = br[i];
     if (lane == 0) {
         pf.counts[lp] = n;
+        // the pair's threshold for the exact pass: k of its rows have keys at or below this value (in the scale of v)
+        float tf = INFINITY;
+        if (tau != 0xFFFFFFFFu) tf = __uint_as_float((tau & 0x80000000u) ? tau ^ 0x80000000u : ~tau);
+        pf.tau[lp] = tf;
         if (over) atomicOr(&pf.ctl[1], 1u);
     }
 }
 
 // an ambiguous visit, the reference's way: every row of the leaf scored with the canonical sums, the `take` smallest
-// (key, id) join the pair's list -- what sweep + select do for every visit of a batch that is not prefiltered
+// (key, id) are what the visit hands over -- what sweep + select do for every visit of a batch that is not prefiltered -- and
+// those of them that can still be among the pair's k best join its list: k rows of the pair have keys at or below pf.tau (in
+// the scale of the prefilter's v), so a row whose exact key lies above it is out.  The exact key in that scale: cosine: the
+// key itself (parity: in the order of its bits, as pf_value); L2: (d* - |q|^2) / 2 with the computed |q|^2 and its rounding.
 template <int KIND>
 __global__ __launch_bounds__(256) void prefilter_amb_kernel(const float *__restrict__ X, uint32_t d, const float *__restrict__ Q,
                                                              const float *__restrict__ QQ, uint32_t T, uint32_t B,
@@ -3000,12 +3014,21 @@ __global__ __launch_bounds__(256) void prefilter_amb_kernel(const float *__restr
         }
         uint64_t mykey = ~0ull;
         uint32_t myid = ~0u;
+        double myv = 0.0;  // the exact key in the scale of v, less its own uncertainty (L2: the rounded |q|^2)
+        const double nq = (double)pf.qnorm[b];
         for (uint32_t j = 0; j < len; j++) {
             const uint32_t id = leaf_ids[(size_t)a.y + j];
             float s0, s1;
             lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)b * d, d, lane, param, s0, s1);
             const uint64_t key = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
-            if (lane == j) { mykey = key; myid = id; }
+            if (lane == j) {
+                mykey = key; myid = id;
+                if (KIND == K_COS) {
+                    const double kv = __longlong_as_double((long long)key);
+                    myv = (param == ZH_COSINE_PARITY && kv < 0.0) ? 2.0 - kv : kv;
+                } else
+                    myv = 0.5 * (double)s0 - 0.5 * nq * nq - ((double)d + 10.0) * 5.9604644775390625e-8 * 1.01 * nq * nq;
+            }
         }
         uint32_t rank = 0;
         for (uint32_t j = 0; j < len; j++) {
@@ -3013,7 +3036,7 @@ __global__ __launch_bounds__(256) void prefilter_amb_kernel(const float *__restr
             const uint32_t ij = __shfl(myid, (int)j);
             rank += (kj < mykey || (kj == mykey && ij < myid)) ? 1u : 0u;
         }
-        if (lane < len && rank < take) {
+        if (lane < len && rank < take && !(myv > (double)pf.tau[lp])) {  // (NaN: kept)
             const uint32_t slot = atomicAdd(&pf.counts[lp], 1u);
             if (slot < pf.cap) pf.rows[lp * pf.cap + slot] = myid;
             else atomicOr(&pf.ctl[1], 2u);
@@ -3021,28 +3044,37 @@ __global__ __launch_bounds__(256) void prefilter_amb_kernel(const float *__restr
     }
 }
 
-// the lists' rows scored exactly: one wave per slot
+// the lists' rows scored exactly: one wave per (query, tree) list, its rows one after the other with the next row's loads in flight
+// (a wave per SLOT was 250k waves of which 4 in 5 found an empty slot: 0.75 ms for 60k rows)
 template <int KIND>
 __global__ __launch_bounds__(256) void prefilter_keys_kernel(const float *__restrict__ X, uint32_t d, const float *__restrict__ Q,
                                                               const float *__restrict__ QQ, uint32_t B, uint64_t lists, int metric,
                                                               int param, uint64_t id_base, ZhPrefilter pf,
                                                               uint64_t *__restrict__ keys, uint64_t *__restrict__ ids) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t lp = w / pf.cap;
-    const uint32_t slot = (uint32_t)(w % pf.cap);
+    const uint64_t lp = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (lp >= lists) return;
-    const uint32_t c = pf.counts[lp];
-    if (slot >= (c < pf.cap ? c : pf.cap)) return;
+    const uint32_t c0 = pf.counts[lp], c = c0 < pf.cap ? c0 : pf.cap;
+    if (!c) return;
     const uint32_t b = (uint32_t)(lp % B);
-    const uint32_t row = pf.rows[w];
-    float s0, s1;
-    lane_sums_generic<KIND>(X + (size_t)row * d, Q + (size_t)b * d, d, lane, param, s0, s1);
-    if (lane == 0) {
-        keys[w] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
-        ids[w] = id_base + row;
-        atomicAdd(&pf.ctl[2], 1u);
+    const uint32_t myrow = lane < c ? pf.rows[lp * pf.cap + lane] : 0u;  // cap <= 256: four passes at most
+    for (uint32_t base = 0; base < c; base += 64) {
+        const uint32_t rows64 = base == 0 ? myrow : (base + lane < c ? pf.rows[lp * pf.cap + base + lane] : 0u);
+        const uint32_t cnt = c - base < 64u ? c - base : 64u;
+        uint64_t mykey = 0;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)rows64, (int)j);
+            float s0, s1;
+            lane_sums_generic<KIND>(X + (size_t)row * d, Q + (size_t)b * d, d, lane, param, s0, s1);
+            const uint64_t key = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
+            if (lane == j) mykey = key;
+        }
+        if (lane < cnt) {
+            keys[lp * pf.cap + base + lane] = mykey;
+            ids[lp * pf.cap + base + lane] = id_base + rows64;
+        }
     }
+    if (lane == 0) atomicAdd(&pf.ctl[2], c);
 }
 
 __global__ __launch_bounds__(256) void leaf_meta_kernel(const uint32_t *__restrict__ leaf_ids, uint64_t n, const float *__restrict__ hn2,
@@ -3091,8 +3123,7 @@ hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX,
                                      uint64_t id_base, ZhPrefilter pf, uint64_t *dKeys, uint64_t *dIds, hipStream_t s) {
     const uint64_t lists = (uint64_t)B * f.n_trees;
     if (!lists) return hipSuccess;
-    const uint64_t waves = lists * pf.cap;
-    const dim3 gk((uint32_t)((waves + 3) / 4)), blk(256);
+    const dim3 gk((uint32_t)((lists + 3) / 4)), blk(256);
     if (metric == ZH_COSINE) {
         hipLaunchKernelGGL(prefilter_amb_kernel<K_COS>, dim3(2048), blk, 0, s, dX, d, dQ, dQQ, f.n_trees, B, f.leaf_ids, metric, mode, pf);
         hipLaunchKernelGGL(prefilter_keys_kernel<K_COS>, gk, blk, 0, s, dX, d, dQ, dQQ, B, lists, metric, mode, id_base, pf, dKeys, dIds);
@@ -3104,8 +3135,17 @@ hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX,
 }
 
 hipError_t zh_launch_final_lists(uint32_t T, uint32_t B, uint32_t k, uint32_t cap, const uint64_t *dKeys, const uint64_t *dIds,
-                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+                                 const uint32_t *dCounts, uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint32_t *dOver,
+                                 hipStream_t s) {
     if (!B) return hipSuccess;
+    // one wave per query over the PACKED lists, 16 KB of LDS (the 256-thread kernel's 50 KB wait for room beside the walks).  The
+    // lists are mostly empty (~15-50 of 64-128 slots): up to 4x as many slots as the sort holds are tried this way; a query whose
+    // lists do hold more than the sort reports it and the batch is redone with the sweep
+    if ((uint64_t)T * cap <= 4 * MERGE_WAVE_N) {
+        hipLaunchKernelGGL(merge_wave_kernel, dim3(B), dim3(64), 0, s, B, T, k, dKeys, dIds, dCounts, dOutIds, dOutKeys, dOutCounts,
+                           (uint64_t)B * cap, (uint64_t)B, cap, dOver);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(final_kernel<true>, dim3(B), dim3(256), 0, s, (const uint64_t *)nullptr, B, T, k, dKeys,
                        (const uint32_t *)nullptr, dIds, dCounts, (uint64_t)0, dOutIds, dOutKeys, dOutCounts, (uint64_t)B * cap, (uint64_t)B, cap);
     return hipGetLastError();
