@@ -1468,7 +1468,13 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     if ((rc = c->wLogHead.ensure(pairs * 4))) return rc;
     if ((rc = c->wLogCtl.ensure(sizeof(ZhLogCtl)))) return rc;
     if (!c->wLogPool.p) {
-        static const size_t first = [] { const char *e = getenv("ZH_WALK_LOG_CHUNKS"); return e ? (size_t)atoll(e) : (size_t)8192; }();
+        static const size_t first_env = [] { const char *e = getenv("ZH_WALK_LOG_CHUNKS"); return e ? (size_t)atoll(e) : (size_t)0; }();
+        size_t first = first_env ? first_env : 8192;
+        if (!first_env) {  // a context created after the index has served batches starts with a log that fits what those batches logged
+            std::lock_guard<std::mutex> lk(ix->stats_mu);
+            const double v = ix->visits_per_pair * (double)pairs;
+            if (v > 0) first = std::max<size_t>(first, (size_t)(1.5 * (v / (ZH_LOG_CHUNK - 1) + (double)pairs)) + 16);
+        }
         if ((rc = c->wLogPool.ensure(std::max<size_t>(first, 1) * ZH_LOG_CHUNK * sizeof(uint2)))) return rc;
         c->log_chunks = std::max<size_t>(first, 1);
     }
