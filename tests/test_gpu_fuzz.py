@@ -105,3 +105,69 @@ def test_fuzz_medium_wandering_walks(seed):
         for b in range(B):
             c = int(oc[b])
             assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), (d, n, M, T, k, B, dense, b)
+
+
+_pfirst, _pcount = (int(x) for x in os.environ.get("ZH_FUZZ_PREFILTER_SEEDS", "0:12").split(":"))
+_pf_seen = []  # per seed: batches that were prefiltered (checked by the last test of the file)
+
+
+@pytest.mark.parametrize("seed", range(_pfirst, _pfirst + _pcount))
+def test_fuzz_prefilter(seed):
+    """small-leaf forests with every sign from row scores: the prefilter (candidates judged on the scores, zh_search.hip) and -- from
+    the third batch of a forest on, when the blocked view exists -- the lazily fixed signs, against the oracle and against the sweep;
+    ties (integer rows, duplicates), clustered rows, zero rows, a query that is a stored row, inserts and removals in between"""
+    import zebra_amd as za
+    rng = np.random.default_rng(5000 + seed)
+    d = int(rng.choice([4, 17, 32, 64, 100, 128, 384, 768]))
+    n = int(rng.integers(200, 6000))
+    M = int(rng.choice([1, 2, 3, 5, 5, 8]))
+    T = int(rng.integers(1, 7))
+    k = int(rng.choice([1, 3, 10, 10, 37, 64]))
+    B = int(rng.integers(1, 24))
+    kind = int(rng.choice([0, 0, 1, 2]))
+    X = zo.synth_rows(n, d, seed=seed, kind=kind)
+    if rng.random() < 0.4:
+        X[rng.integers(0, n, 6)] = X[0]          # exact duplicates: equal keys inside a leaf
+    if rng.random() < 0.2:
+        X[rng.integers(0, n, 3)] = 0             # zero rows: simsimd's special cases
+    Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
+    if rng.random() < 0.3:
+        Q[0] = X[int(rng.integers(0, n))]        # distance 0 / cosine 1 exactly
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
+    ix.add(X)
+    ix.set_hash_mode("scores")
+    ix.set_dense_levels(100)
+    f = zo.Forest.build(X, M, T, seed=seed)
+    mets = [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
+            (za.CosineDistance(False), zo.COSINE, zo.CORRECTED)]
+    seen_pf = 0
+    for it in range(5):  # the blocked view (and with it the lazily fixed signs) arrives with the third batch
+        m, om, omode = mets[int(rng.integers(0, 4))]
+        ix.set_sweep_mode("leaf" if it == 3 else "auto")
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        st = ix.stats()
+        seen_pf += st["prefiltered"]
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), (d, n, M, T, k, om, it)
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), (d, n, M, T, k, om, omode, it, b, st["prefiltered"])
+        if it == 1:  # grow and shrink between batches: the per-slot norms and the blocked view are rebuilt
+            more = int(rng.integers(1, 200))
+            X = np.concatenate([X, zo.synth_rows(more, d, seed=seed, row0=10**6, kind=kind)])
+            ix.add(X[n:])
+            f.insert(X, n)
+            n += more
+            gone = rng.choice(n, size=min(5, n), replace=False).astype(np.uint64)
+            ix.remove(gone)
+            f.remove(gone)
+            ix.set_dense_levels(100)
+    _pf_seen.append(seen_pf)
+    ix.close()
+
+
+def test_fuzz_prefilter_was_exercised():
+    """the seeds above must actually reach the prefilter (a sweep would pass them too)"""
+    if not _pf_seen:
+        pytest.skip("no prefilter seeds ran in this process")
+    assert sum(1 for s_ in _pf_seen if s_ >= 2) >= 0.6 * len(_pf_seen), _pf_seen
