@@ -59,6 +59,7 @@ struct ZhWalkLog {
     uint32_t capacity;    // chunks
     uint32_t *head;       // first chunk of every pair (valid when the pair has more than ZH_INLINE_VISITS visits)
     ZhLogCtl *ctl;
+    uint32_t leaf_entries;  // 1: entries are {offset into leaf_ids, take | length << 16} (a prefiltered batch: its reader needs no node record)
 };
 
 // Blocked view of the forest for walks that find every sign precomputed (ZH_BLOCK_NODES, zh_api.hip build_blocks): every

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void walk_kernel(ZhForestDev f, const float *__
                     if (mine && vi >= ZH_INLINE_VISITS) {
                         const uint32_t li = vi - ZH_INLINE_VISITS;
                         const uint32_t id = (int32_t)(li / PER) == log_cn ? log_chunk : newc;
-                        wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = make_uint2(v.node, v.take);
+                        wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = wlog.leaf_entries ? make_uint2(v.leaf_off, v.take | (v.len << 16)) : make_uint2(v.node, v.take);
                     }
                     if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
                 }
@@ -785,7 +785,7 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
                                const uint32_t *dLeafCount, uint32_t *dLeafFill, const uint32_t *dGroupBase,
                                const uint64_t *dGroupRowBase, ZhGroup *dGroups, uint64_t *dGroupRowOff, hipStream_t s) {
     if (!((uint64_t)B * f.n_trees)) return hipSuccess;
-    ZhWalkLog nolog{nullptr, 0, nullptr, nullptr};
+    ZhWalkLog nolog{nullptr, 0, nullptr, nullptr, 0};
     launch_walk<true>(f, dQ, B, d, n, dBits, words_per_q, P_dense, const_cast<ZhPairCounts *>(dCounts),
                       const_cast<ZhVisit *>(dInline), dRowBase, dCandBase, dVisitBase, dVisits,
                       const_cast<uint32_t *>(dLeafCount), dLeafFill, dGroupBase, dGroupRowBase, dGroups, dGroupRowOff, nolog, s);
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
                 if (mine && vi >= ZH_INLINE_VISITS) {
                     const uint32_t li = vi - ZH_INLINE_VISITS;
                     const uint32_t id = (int32_t)(li / PER) == log_cn ? log_chunk : newc;
-                    wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = make_uint2(v.node, v.take);
+                    wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = wlog.leaf_entries ? make_uint2(v.leaf_off, v.take | (v.len << 16)) : make_uint2(v.node, v.take);
                 }
                 if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
             }
@@ -2970,9 +2970,13 @@ __global__ __launch_bounds__(64) void prefilter_kernel(ZhForestDev f, uint32_t T
             const uint32_t next = C[0].x;
             const bool on = lane >= 1 && lane <= cnt;
             uint2 en = make_uint2(0, 0);
-            int4 r = make_int4(-1, 0, 0, 0);
-            if (on) { en = C[lane]; r = f.node_pack[en.x]; }
-            process(on, (uint32_t)r.y, (uint32_t)r.z, en.y);
+            uint32_t lo = 0, ln = 0, tk = 0;
+            if (on) {
+                en = C[lane];
+                if (wlog.leaf_entries) { lo = en.x; ln = en.y >> 16; tk = en.y & 0xFFFFu; }  // (wave-uniform choice)
+                else { const int4 r = f.node_pack[en.x]; lo = (uint32_t)r.y; ln = (uint32_t)r.z; tk = en.y; }
+            }
+            process(on, lo, ln, tk);
             remaining -= cnt; chunk = next;
         }
     }
