@@ -225,7 +225,9 @@ ZH_API int zh_search_batch_device(zh_index *idx, const float *d_q, size_t b, siz
  * `stream` and returns; finish waits (host side) only for three totals, then enqueues the distance sweep,
  * the selection and the final top-k and returns; wait blocks until the results are complete.  With two
  * contexts on two streams one host thread keeps the sweep of batch i and the small latency-bound kernels of
- * batches i and i+1 on the GPU together.  Queries and outputs must stay valid until wait (or a stream sync). */
+ * batches i and i+1 on the GPU together.  Queries and outputs must stay valid until wait, and the outputs are complete only
+ * when wait has returned -- a stream sync is not enough: a prefiltered batch (zh_set_sweep_mode) whose candidate lists ran over is
+ * redone with the sweep inside wait. */
 typedef struct zh_search_ctx zh_search_ctx;
 ZH_API int zh_search_ctx_create(zh_index *idx, zh_search_ctx **out);
 ZH_API void zh_search_ctx_destroy(zh_search_ctx *ctx);

@@ -125,7 +125,7 @@ struct zh_search_ctx {
     bool lazy_fix = false;    // ... with the uncertain signs flagged (wUnc) for the blocked walk to recompute when it meets one
     // prefilter (zh_search.hip): the batch's candidates are picked from those row scores and only they are scored exactly.  Its
     // control words come back pinned; a list that ran over makes zh_search_wait redo the batch the classic way, from these:
-    bool prefilter = false, prefilter_off_once = false;
+    bool prefilter = false, prefilter_off_once = false, stream_ordered = false;
     uint32_t pf_cap = 0;
     uint32_t *h_pf = nullptr;
     std::vector<const float *> sv_q;
@@ -1304,7 +1304,12 @@ static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     // the dense kernel: MFMA-bound for real batches, a plane-streaming GEMV (HBM-bound) for a handful of queries
     const double t_dense = std::max((double)ix->n_planes * per_plane / 9e13, (double)ix->n_planes * d * 4.0 / 5e12);
     const double bits_bytes = (double)ix->n_planes * (double)B / 8.0;
-    if (t_dense < t_chain && bits_bytes < 2e9) return ix->n_planes;  // (every context in flight holds its own sign bits)
+    // ... or every sign from the row scores (zh_score.hip) where the forest allows: B * rows dot products + a gather per plane
+    double t_all = t_dense;
+    if (ix->samples_valid && ix->hash_mode != 1 && (double)ix->n_rows * (double)((B + 3) & ~(size_t)3) * 4.0 <= (double)(12ull << 30))
+        t_all = std::min(t_all, std::max(2.0 * (double)B * (double)ix->n_rows * d / 9e13, (double)ix->n_rows * d * 4.0 / 5e12) +
+                                    (double)ix->n_planes * 2.0 * std::max(64.0, (double)B * 4.0) / 4e12);
+    if (t_all < t_chain && bits_bytes < 2e9) return ix->n_planes;  // (every context in flight holds its own sign bits)
     return top;
 }
 
@@ -1315,7 +1320,7 @@ static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense) {
     const int mode = ix->hash_mode ? ix->hash_mode : forced;
     if (mode == 1 || !ix->samples_valid || ix->n_planes == 0 || P_dense < ix->n_planes) return false;
     const size_t Bp = (B + 3) & ~(size_t)3;  // (the kernels take queries four at a time: the batch is padded with zero queries)
-    if ((uint64_t)ix->n_rows * Bp * 4 > (4ull << 30) || ix->n_rows > 0xFFFFFFF0ull) return false;
+    if ((uint64_t)ix->n_rows * Bp * 4 > (12ull << 30) || ix->n_rows > 0xFFFFFFF0ull) return false;  // the score table of ONE context (288 GB of HBM)
     if (mode == 2) return true;
     // per-plane hash: MFMA-bound for real batches, a plane-streaming GEMV for a handful of queries; row scores: the same two
     // bounds over the ROWS, + the gather of two score rows per plane (>= one 64-byte sector each) + the exact fix-ups
@@ -1392,7 +1397,7 @@ int ctx_wait(zh_search_ctx *c);
 // determine, leaves short enough for the per-lane selection, and forests this library built (a row is in one leaf per tree).
 static bool use_prefilter(const zh_index *ix, const zh_search_ctx *c, size_t k, int metric) {
     static const bool off = getenv("ZH_NO_PREFILTER") != nullptr;  // A/B: sweep + select for every batch
-    if (off || !c->score_hash || c->prefilter_off_once || (ix->prefilter_strikes.load() >= 2 && ix->sweep_mode != 3)) return false;
+    if (off || !c->score_hash || c->prefilter_off_once || c->stream_ordered || (ix->prefilter_strikes.load() >= 2 && ix->sweep_mode != 3)) return false;
     static const bool env_sweep = getenv("ZH_SWEEP_MODE") != nullptr;
     if ((ix->sweep_mode != 0 && ix->sweep_mode != 3) || (env_sweep && ix->sweep_mode != 3)) return false;  // a sweep was asked for
     if (metric != ZH_L2SQ && metric != ZH_L2 && metric != ZH_COSINE) return false;
@@ -1896,6 +1901,9 @@ extern "C" int zh_search_finish_window(zh_search_ctx *c, uint64_t *const *d_out_
 double zh_index_visits_per_pair(zh_index *ix) {
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     return ix->visits_per_pair;
+}
+void zh_search_ctx_stream_ordered(zh_search_ctx *c) {
+    if (c) c->stream_ordered = true;
 }
 void zh_search_ctx_abandon(zh_search_ctx *c) {
     if (c && c->state == 1) c->state = 0;  // what was enqueued by begin completes on its stream; its results are never used

@@ -12,6 +12,9 @@ int zh_set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2
 double zh_index_visits_per_pair(zh_index *ix);
 // (zh_shard.hip) a context whose batch was begun and will never be finished goes back to idle
 void zh_search_ctx_abandon(zh_search_ctx *c);
+// the caller consumes a batch's outputs in STREAM order, before zh_search_wait has returned (the sharded search enqueues its
+// all-gather behind finish): the context then never takes a path that may redo the batch from the host (the prefilter)
+void zh_search_ctx_stream_ordered(zh_search_ctx *c);
 
 // ---- one leaf visit of the walk (tree_result, lsh.rs:290-348): score `len` rows of a leaf for
 // query `b`, keep the `take` smallest.  row_off / cand_off are the visit's slices of the key

@@ -189,6 +189,7 @@ extern "C" int zh_shard_ctx_create(zh_shard_group *g, zh_shard_ctx **out) {
     c->g = g;
     auto bail = [&](int code) { zh_shard_ctx_destroy(c); return code; };
     if ((rc = zh_search_ctx_create(g->ix, &c->sc))) return bail(rc);
+    zh_search_ctx_stream_ordered(c->sc);  // the exchange is enqueued behind the local search, before any wait
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     hipError_t e = hipStreamCreateWithPriority(&c->light, hipStreamNonBlocking, greatest);
