@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "$COMMIT" > $OUT/commit.txt
+echo "$CFGS" > $OUT/configs.txt   # summarize.py writes summaries for these only
 python3 profiles/summarize.py --sha > $OUT/kernel_sources.sha
 # --profile-run: nothing but full windows of the workload (every sweep launch of the process is comparable with bench.py's
 # launch_ms); the PMC passes add --serial-windows: the SAME window as the timed run, one window on the GPU at a time (per-kernel

@@ -73,8 +73,14 @@ def box(cfg_dir, out_json):
 def container(tag, commit):
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
+    # only the configurations of THIS collection (collect.sh lists them): gpurun_out/ keeps the directories of earlier collections,
+    # and re-labelling their summaries with this commit would claim counters for kernels that were not measured at it
+    lst = os.path.join(root, "configs.txt")
+    only = set(open(lst).read().split()) if os.path.exists(lst) else None
     for cmdf in sorted(glob.glob(os.path.join(root, "*.cmd"))):
         cfg = os.path.basename(cmdf)[:-4]
+        if only is not None and cfg not in only:
+            continue
         st = glob.glob(os.path.join(root, cfg, "stats", "**", "*kernel_stats.csv"), recursive=True)
         if st:
             shutil.copy(st[0], os.path.join(here, f"{tag}_{cfg}_kernel_stats.csv"))
