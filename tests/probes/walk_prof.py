@@ -22,7 +22,7 @@ OUT = os.path.join(ROOT, "tests", "probes", "_build", "libzebra_hip_prof.so")
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     src = sorted(glob.glob(os.path.join(ROOT, "zebra_amd", "csrc", "*.hip"))) + [os.path.join(ROOT, "zebra_amd", "csrc", "zh_refformat.cpp")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-DZH_WALK_PROF", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-DZH_WALK_PROF"] + os.environ.get("PROBE_DEFINES", "").split() + [ "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                            "-ffp-contract=off", "-fvisibility=hidden", "-Wno-unused-parameter", "-Wno-unused-value", "-shared",
                            "-Wl,--no-undefined", "-o", OUT] + src + ["-L/opt/rocm/lib", "-lrccl"])
 
