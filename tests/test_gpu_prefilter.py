@@ -72,6 +72,28 @@ def test_prefilter_equals_oracle_and_sweep(za, n, d, M, T, k, B, kind, metric):
     ix.close()
 
 
+def test_prefilter_with_an_id_base(za):
+    """a shard's ids are id_base + row: the exact-key kernel adds it, as the final kernel of the sweep path does"""
+    n, d, M, T, k, B, base = 12000, 96, 5, 4, 10, 9, 5_000_000_000
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=base)
+    ix.add(X)
+    ix.set_dense_levels(100)
+    ix.set_hash_mode("scores")
+    f = zo.Forest.from_arrays(X, M, ix.get_forest())
+    oi, ok, oc = f.search_batch(Q, k, zo.L2SQ, 0)
+    for mode in ("auto", "auto", "leaf"):
+        ix.set_sweep_mode(mode)
+        ids, keys, counts = ix.search_batch(Q, k, za.L2SquaredDistance())
+        assert ix.stats()["prefiltered"] == (0 if mode == "leaf" else 1)
+        assert (counts == oc).all()
+        for b in range(B):
+            c = int(oc[b])
+            assert (ids[b, :c] == oi[b, :c] + np.uint64(base)).all() and (keys[b, :c] == ok[b, :c]).all(), (mode, b)
+    ix.close()
+
+
 def test_a_forest_with_long_leaves(za):
     """clustered rows at d = 64 with max_node_size 3: splits between near-identical rows leave leaves of up to ~40 rows; every visit to
     one takes the exact path (the per-lane selection handles 8 rows), thresholded like the rest"""
@@ -181,7 +203,8 @@ def test_prefilter_follows_inserts_and_removals(za):
 
 
 def test_prefilter_in_pipelined_windows(za):
-    """two contexts in flight, windows of two batches: the prefiltered second half runs on the contexts' own streams"""
+    """two contexts in flight, windows of two batches: the prefiltered second half runs on the contexts' own streams; then the same
+    windows with lists that run over: zh_search_wait redoes the WINDOW with the sweep and hands out the same per-batch results"""
     import torch
     n, d, M, T, k, B = 30000, 128, 5, 6, 10, 32
     X = zo.synth_rows(n, d)
@@ -189,24 +212,37 @@ def test_prefilter_in_pipelined_windows(za):
     f = zo.Forest.from_arrays(X, M, ix.get_forest())
     dev = torch.device("cuda", 0)
     Qs = [zo.synth_queries(B, d, n, b0=j * B) for j in range(4)]
+    want = [f.search_batch(q, k, zo.L2SQ, 0) for q in Qs]
     dq = [torch.from_numpy(q).to(dev) for q in Qs]
-    outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.int64, device=dev),
-             torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(4)]
-    torch.cuda.synchronize()
     m = za.L2SquaredDistance()
     ctxs = [ix.search_context(), ix.search_context()]
-    for w in range(2):
-        ctxs[w].begin_window([dq[2 * w].data_ptr(), dq[2 * w + 1].data_ptr()], B, k, m)
-    for w in range(2):
-        o = outs[2 * w:2 * w + 2]
-        ctxs[w].finish_window([x[0].data_ptr() for x in o], [x[1].data_ptr() for x in o], [x[2].data_ptr() for x in o])
-    for c in ctxs:
-        c.wait()
+
+    def run():
+        outs = [(torch.zeros((B, k), dtype=torch.int64, device=dev), torch.zeros((B, k), dtype=torch.int64, device=dev),
+                 torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(4)]
+        torch.cuda.synchronize()
+        for w in range(2):
+            ctxs[w].begin_window([dq[2 * w].data_ptr(), dq[2 * w + 1].data_ptr()], B, k, m)
+        for w in range(2):
+            o = outs[2 * w:2 * w + 2]
+            ctxs[w].finish_window([x[0].data_ptr() for x in o], [x[1].data_ptr() for x in o], [x[2].data_ptr() for x in o])
+        for c in ctxs:
+            c.wait()
+        for j in range(4):
+            _same(outs[j][0].cpu().numpy().view(np.uint64), outs[j][1].cpu().numpy().view(np.uint64), outs[j][2].cpu().numpy().view(np.uint32),
+                  *want[j], j)
+
+    run()
+    run()  # (a context's first wandering window may outgrow its visit log and be swept)
     assert ix.stats()["prefiltered"] == 1
-    for j in range(4):
-        oi, ok, oc = f.search_batch(Qs[j], k, zo.L2SQ, 0)
-        _same(outs[j][0].cpu().numpy().view(np.uint64), outs[j][1].cpu().numpy().view(np.uint64), outs[j][2].cpu().numpy().view(np.uint32),
-              oi, ok, oc, j)
+    ix.stats(reset=True)
+    os.environ["ZH_PREFILTER_CAP"] = "2"
+    try:
+        run()
+    finally:
+        del os.environ["ZH_PREFILTER_CAP"]
+    st = ix.stats()
+    assert st["prefilter_fallbacks_accum"] == 2 and st["prefiltered"] == 0, st
     for c in ctxs:
         c.close()
     ix.close()
