@@ -852,7 +852,7 @@ __device__ __forceinline__ bool plane_above_wave(const float *__restrict__ w, fl
 
 #define WALK_RING 128u       // visit records waiting to leave the wave: ring of 128 slots (+ one slot every lane without a visit writes to)
 #define WALK_FLUSH 32u       // ... leave 32 at a time (< ZH_LOG_CHUNK - 1: at most one new log chunk per flush)
-#define WALK_EXIT (0x80000000u | 63u)
+#define WALK_EXIT (0xC0000000u | 63u)
 
 __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
                                                            const uint32_t *__restrict__ bits, uint32_t wpq,
@@ -936,12 +936,15 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
     for (;;) {
         if (ref >= 0) {  // an upper (inner) node: its records and its sign word are requested together
             WP(const uint64_t p_u0 = clock64(); p_uppers++;)
-            const int4 ra = blk.upper[2 * (size_t)ref], rb = blk.upper[2 * (size_t)ref + 1];
-            const uint32_t word = qbits[(uint32_t)pl >> 5];
-            const uint32_t uword = qunc ? qunc[(uint32_t)pl >> 5] : 0u;
-            const int4 a = uni4(ra), c2 = uni4(rb);
-            bool above = ((uint32_t)__builtin_amdgcn_readfirstlane((int)word) >> (pl & 31)) & 1;
-            if (((uint32_t)__builtin_amdgcn_readfirstlane((int)uword) >> (pl & 31)) & 1)
+            // wave-uniform addresses: scalar loads (through the constant address space) -- the records arrive in SGPRs, no vector
+            // memory instruction, no v_readfirstlane per word
+            typedef const int32_t __attribute__((address_space(4))) *cptr_t;
+            const cptr_t up = (cptr_t)(uintptr_t)(blk.upper + 2 * (size_t)ref);
+            const int4 a = make_int4(up[0], up[1], up[2], up[3]), c2 = make_int4(up[4], up[5], up[6], up[7]);
+            const uint32_t word = (uint32_t)((cptr_t)(uintptr_t)qbits)[(uint32_t)pl >> 5];
+            const uint32_t uword = qunc ? (uint32_t)((cptr_t)(uintptr_t)qunc)[(uint32_t)pl >> 5] : 0u;
+            bool above = (word >> (pl & 31)) & 1;
+            if ((uword >> (pl & 31)) & 1)
                 above = plane_above_wave(f.planes + (size_t)pl * d, f.consts[pl], Q + (size_t)b * d, d, lane);
             if (usp < WALK_STACK && lane == 0) ust[usp] = make_int4(above ? a.y : a.z, n, above ? c2.x : c2.y, 0);
             usp++;
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         // visit).  Lanes past the block read as empty leaves; lane 63 (WALK_EXIT) is where the stack's sentinel leads once the
         // block is exhausted.  A node whose sign is flagged looks like a leaf with bit 30 set: the descent stops on it, the sign is
         // recomputed and the descent goes on (WALK_DESCEND).
-        uint32_t pk = 0x80000000u | lane;
+        uint32_t pk = lane == 63 ? WALK_EXIT : (0x80000000u | lane);
         const uint32_t pkm = r.x < 0 && r.z > 0 ? pk : 0xFFFFFFFFu;
         if (r.x >= 0) {
             const uint32_t l = (uint32_t)r.y & 0xFFFFu, rr = (uint32_t)r.y >> 16;
@@ -989,40 +992,43 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
         // down the main children to a leaf: 1 scalar + 5 vector instructions and the branch per inner node.  (Round 2's loop spent
         // 37 instructions here, most of them scalar copies of the walk's other live state.)
 #define WALK_DESCEND()                                                                                                       \
-        for (;;) {                                                                                                           \
-            while (!(w >> 31)) {                                                                                             \
-                const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
-                lstk = lane == lsp ? e_ : lstk;                                                                              \
-                lsp++;                                                                                                       \
-                w = (uint32_t)rl((int)pk, w);                                                                                \
-                WP(p_inner++;)                                                                                               \
-            }                                                                                                                \
-            if (!(w & 0x40000000u)) break;                                                                                   \
-            /* a flagged sign (one node in ~400): point_is_above itself, then on down */                                     \
-            const int p_ = rl(r.x, w);                                                                                       \
-            const uint32_t ry_ = (uint32_t)rl(r.y, w), l_ = ry_ & 0xFFFFu, rr_ = ry_ >> 16;                                  \
-            w = plane_above_wave(f.planes + (size_t)p_ * d, f.consts[p_], Q + (size_t)b * d, d, lane) ? (rr_ | (l_ << 8)) : (l_ | (rr_ << 8)); \
+        while (!(w >> 31)) {                                                                                                 \
+            const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
+            lstk = lane == lsp ? e_ : lstk;                                                                                  \
+            lsp++;                                                                                                           \
+            w = (uint32_t)rl((int)pk, w);                                                                                    \
+            WP(p_inner++;)                                                                                                   \
         }
         WALK_DESCEND();
-        do {  // one leaf per turn; the loop is left through the sentinel: the block is done and `ret` is its return value
-            // the leaf: no branch -- an empty one (lsh.rs:306 / 329: it returns 0) matches no lane and adds nothing
-            const uint32_t len = (uint32_t)rl(r.z, w);
-            const uint32_t take = len < (uint32_t)n ? len : (uint32_t)n;  // n >= 1 here (n0 >= 1; a backup is entered with nn - ret > 0)
-            ret = (int32_t)take;
-            const bool me = pkm == w;
-            vidx = me ? v_nv : vidx; vtk = me ? take : vtk; vrow = me ? v_nrows : vrow; vcand = me ? v_ntakes : vcand;
-            v_nv += in_vgpr(len) != 0u ? 1u : 0u; v_nrows += len; v_ntakes += take;
-            uint32_t e;
-            do {  // lsh.rs:341-343: the nearest pending backup whose n the return value has not used up
-                lsp--;
-                WP(p_pops++;)
-                e = (uint32_t)rl((int)lstk, lsp);
-            } while ((uint32_t)ret >= (e >> 8));
-            n = (int32_t)((e >> 8) - (uint32_t)ret);
-            n8 = in_vgpr_shl8((uint32_t)n);
-            w = (uint32_t)rl((int)pk, e);
+        for (;;) {  // (the outer loop turns only for a flagged sign: one node in ~400)
+            if (w < 0xC0000000u) {
+                do {  // one leaf per turn; WALK_EXIT and the flagged words are the only ones with bit 30: one compare per leaf
+                    // the leaf: no branch -- an empty one (lsh.rs:306 / 329: it returns 0) matches no lane and adds nothing
+                    const uint32_t len = (uint32_t)rl(r.z, w);
+                    const uint32_t take = len < (uint32_t)n ? len : (uint32_t)n;  // n >= 1 here (n0 >= 1; a backup is entered with nn - ret > 0)
+                    ret = (int32_t)take;
+                    const bool me = pkm == w;
+                    vidx = me ? v_nv : vidx; vtk = me ? take : vtk; vrow = me ? v_nrows : vrow; vcand = me ? v_ntakes : vcand;
+                    v_nv += in_vgpr(len) != 0u ? 1u : 0u; v_nrows += len; v_ntakes += take;
+                    uint32_t e;
+                    do {  // lsh.rs:341-343: the nearest pending backup whose n the return value has not used up
+                        lsp--;
+                        WP(p_pops++;)
+                        e = (uint32_t)rl((int)lstk, lsp);
+                    } while ((uint32_t)ret >= (e >> 8));
+                    n = (int32_t)((e >> 8) - (uint32_t)ret);
+                    n8 = in_vgpr_shl8((uint32_t)n);
+                    w = (uint32_t)rl((int)pk, e);
+                    WALK_DESCEND();
+                } while (w < 0xC0000000u);
+            }
+            if (w == WALK_EXIT) break;  // through the sentinel: the block is done and `ret` is its return value
+            // a flagged sign: point_is_above itself, then on down
+            const int p_ = rl(r.x, w);
+            const uint32_t ry_ = (uint32_t)rl(r.y, w), l_ = ry_ & 0xFFFFu, rr_ = ry_ >> 16;
+            w = plane_above_wave(f.planes + (size_t)p_ * d, f.consts[p_], Q + (size_t)b * d, d, lane) ? (rr_ | (l_ << 8)) : (l_ | (rr_ << 8));
             WALK_DESCEND();
-        } while (w != WALK_EXIT);
+        }
 #undef WALK_DESCEND
         // the visited leaves' records join the ring (every other lane writes the spare slot: no branch), full groups leave the wave
         {
