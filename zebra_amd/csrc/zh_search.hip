@@ -847,7 +847,9 @@ __device__ __forceinline__ bool plane_above_wave(const float *__restrict__ w, fl
 #undef RLF
         }
     }
-    return ((double)acc + (double)c) >= 0.0;  // lsh.rs:40-42, as zh_plane_above
+    // lsh.rs:40-42, as zh_plane_above; every lane ran the same chain: said so, or the compiler treats everything the walk derives from
+    // the result (the cursor, the stack pointer) as divergent and moves it to VGPRs
+    return __builtin_amdgcn_readfirstlane((int)(((double)acc + (double)c) >= 0.0)) != 0;
 }
 
 #define WALK_RING 128u       // visit records waiting to leave the wave: ring of 128 slots (+ one slot every lane without a visit writes to)
