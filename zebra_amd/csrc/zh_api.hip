@@ -1408,9 +1408,9 @@ static bool use_prefilter(const zh_index *ix, const zh_search_ctx *c, size_t k, 
 
 static int build_leaf_meta(zh_index *ix) {  // under blk_mu; the norms are those launch_score_hash just validated
     int rc;
-    if ((rc = ix->leaf_meta.ensure(ix->n_leaf_ids * sizeof(float2)))) return rc;
+    if ((rc = ix->leaf_meta.ensure(ix->n_leaf_ids * sizeof(float4)))) return rc;
     HIPCHK(zh_launch_leaf_meta(ix->leaf_ids.as<uint32_t>(), ix->n_leaf_ids, ix->row_hn2.as<float>(), ix->row_norm.as<float>(),
-                               ix->leaf_meta.as<float2>(), ix->stream));
+                               ix->leaf_meta.as<float4>(), ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->leaf_meta_valid = true; ix->meta_rows = ix->norm_rows; ix->meta_gen = ix->norm_gen;
     return ZH_OK;
@@ -1553,7 +1553,7 @@ static int finish_prefilter(zh_search_ctx *c, uint64_t *dOutIds, uint64_t *dOutK
         return rc;
     HIPCHK(hipMemsetAsync(c->wPfCtl.p, 0, 16, s));
     ZhPrefilter pf;
-    pf.S = c->wScore.as<float>(); pf.Bp = c->score_Bp; pf.leaf_meta = ix->leaf_meta.as<float2>(); pf.qnorm = c->wQnorm.as<float>();
+    pf.S = c->wScore.as<float>(); pf.Bp = c->score_Bp; pf.leaf_meta = ix->leaf_meta.as<float4>(); pf.qnorm = c->wQnorm.as<float>();
     pf.rows = c->wPfRows.as<uint32_t>(); pf.counts = c->wPfCounts.as<uint32_t>(); pf.tau = reinterpret_cast<float *>(pf.counts + lists); pf.cap = cap;
     pf.amb = c->wPfAmb.as<uint4>(); pf.amb_cap = amb_cap; pf.ctl = c->wPfCtl.as<uint32_t>();
     ZhForestDev f = forest_dev(ix);

@@ -213,11 +213,11 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
 // Prefilter (zh_search.hip, "Prefilter"): a batch hashed from row scores picks the rows that can be among a pair's k best from
 // those scores; only they are scored with the reference's arithmetic.  Lists: one per (tree, query), `cap` slots, list (t, b) at
 // (t * B + b) * cap.  ctl[0] = ambiguous visits appended, ctl[1] = overflow bits (1 a list, 2 a list in the exact pass, 4 the
-// ambiguous-visit table, 8 a leaf longer than a wave), ctl[2] = rows scored exactly.
+// ambiguous-visit table, 8 a leaf longer than a wave, 16 a query's lists together longer than the final sort), ctl[2] = rows scored exactly.
 struct ZhPrefilter {
     const float *S;            // row scores S[row * Bp + b]
     uint32_t Bp;
-    const float2 *leaf_meta;   // per slot of leaf_ids: {|r|^2 / 2, |r|} of the row stored there
+    const float4 *leaf_meta;   // per slot of leaf_ids: {the row id (its bits), |r|^2 / 2, |r|, 0} of the row stored there
     const float *qnorm;        // |q| per query
     uint32_t *rows, *counts;
     float *tau;                // per list: k of the pair's rows have keys at or below this value (the scale of the prefilter's v); +inf: fewer than k
@@ -227,7 +227,7 @@ struct ZhPrefilter {
     uint32_t *ctl;
 };
 float zh_prefilter_bound(int metric, uint32_t d);
-hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float2 *dOut, hipStream_t s);
+hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float4 *dOut, hipStream_t s);
 hipError_t zh_launch_prefilter(ZhForestDev f, uint32_t d, uint32_t B, uint32_t k, int metric, int mode, const ZhPairCounts *dCounts,
                                const ZhVisit *dInline, ZhWalkLog log, ZhPrefilter pf, hipStream_t s);
 hipError_t zh_launch_prefilter_exact(ZhForestDev f, uint32_t d, const float *dX, const float *dQ, const float *dQQ, uint32_t B, int metric,

@@ -2906,18 +2906,19 @@ __global__ __launch_bounds__(64) void prefilter_kernel(ZhForestDev f, uint32_t T
         float v[PF_MAXLEN], e[PF_MAXLEN];
         uint32_t id[PF_MAXLEN];
         bool amb = on && len > PF_MAXLEN;
+        float4 m[PF_MAXLEN];  // {row id (bits), |r|^2/2, |r|, -}: one 16-byte record per leaf slot, a leaf's records side by side
 #pragma unroll
         for (int j = 0; j < PF_MAXLEN; j++) {
             id[j] = 0;
-            if (on && (uint32_t)j < len) id[j] = f.leaf_ids[(size_t)leaf_off + j];
+            m[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on && (uint32_t)j < len) { m[j] = pf.leaf_meta[(size_t)leaf_off + j]; id[j] = __float_as_uint(m[j].x); }
         }
 #pragma unroll
         for (int j = 0; j < PF_MAXLEN; j++) {
             v[j] = INFINITY; e[j] = 0.f;
             if (on && (uint32_t)j < len) {
-                const float2 m = pf.leaf_meta[(size_t)leaf_off + j];
                 const float s = pf.S[(size_t)id[j] * pf.Bp + b];
-                if (!pf_value<KINDA>(m.x, m.y, s, nq, Kb, v[j], e[j])) { amb = true; v[j] = INFINITY; e[j] = 0.f; }
+                if (!pf_value<KINDA>(m[j].y, m[j].z, s, nq, Kb, v[j], e[j])) { amb = true; v[j] = INFINITY; e[j] = 0.f; }
             }
         }
         uint32_t rank[PF_MAXLEN];
@@ -3090,13 +3091,13 @@ __global__ __launch_bounds__(256) void prefilter_keys_kernel(const float *__rest
 }
 
 __global__ __launch_bounds__(256) void leaf_meta_kernel(const uint32_t *__restrict__ leaf_ids, uint64_t n, const float *__restrict__ hn2,
-                                                         const float *__restrict__ norm, float2 *__restrict__ out) {
+                                                         const float *__restrict__ norm, float4 *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = leaf_ids[i];
-    out[i] = make_float2(hn2[r], norm[r]);
+    out[i] = make_float4(__uint_as_float(r), hn2[r], norm[r], 0.f);
 }
-hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float2 *dOut, hipStream_t s) {
+hipError_t zh_launch_leaf_meta(const uint32_t *dLeafIds, uint64_t n, const float *dHalfN2, const float *dNorm, float4 *dOut, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(leaf_meta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dLeafIds, n, dHalfN2, dNorm, dOut);
     return hipGetLastError();
