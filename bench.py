@@ -460,13 +460,14 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     if st.get("prefiltered"):
         # The batch was hashed from row scores and PREFILTERED (zh_set_sweep_mode): no sweep ran.  `ms_sweep` is prefilter_kernel -- one
         # wave per (query, tree) replays the pair's visits on the score table -- and one launch serves the whole internal batch.
-        # Algorithmic bytes per scored row: 4 (leaf id) + 8 (|r|^2/2, |r|) + 4 (its score); per visit: 8 (log entry) + 16 (node record).
-        # The score is a 4-byte read from a random 1-KiB row of the table: the kernel moves a 64-byte sector for it (sector_GBps).
+        # Algorithmic bytes per scored row: one 16-byte record {row id, |r|^2/2, |r|} of its leaf slot + 4 (its score); per visit: 8 (the log
+        # entry {leaf offset, take | length << 16}).  The score is a 4-byte read from a random 1-KiB row of the table: the kernel moves a
+        # 64-byte sector for it (sector_GBps).
         n_b = max(st["timed_batches"], 1)
         pf_ms = st["ms_sweep"] / n_b
         rows_b, visits_b = st["sweep_rows_accum"] / n_b, st["visits"]
-        bytes_alg = 16.0 * rows_b + 24.0 * visits_b
-        bytes_sector = (64.0 + 12.0) * rows_b + 24.0 * visits_b
+        bytes_alg = 20.0 * rows_b + 8.0 * visits_b
+        bytes_sector = (64.0 + 16.0) * rows_b + 8.0 * visits_b
         g = bytes_alg / (pf_ms * 1e-3) / 1e9 if pf_ms else 0.0
         roof = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": bytes_alg, "kernel": "prefilter_kernel<%d>" % (2 if wl["metric"] == "cosine" else 0), "launch_ms": pf_ms,
