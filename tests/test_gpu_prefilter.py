@@ -125,8 +125,10 @@ def test_prefilter_on_adversarial_rows(za):
     X[2000:2200] *= np.float32(1e18)                      # |r|^2 overflows f32
     X[3000:3200] *= np.float32(1e-30)                     # subnormal squares
     X[3500:3510] = 0                                      # zero rows
+    X[5000:5040] *= np.float32(3e18)                      # dot products with a large query overflow as well
+    X[5040:5050, ::2] *= np.float32(-1)                   # ... with cancelling signs: inf - inf in one summation order, not in another
     X[4000:4300] = X[4000] + (rng.random((300, d)) < 0.01).astype(np.float32) * np.float32(1e-3)  # near-duplicates
-    Q = np.concatenate([zo.synth_queries(B - 5, d, n), X[[0, 2000, 3000, 3500, 4000]]])
+    Q = np.concatenate([zo.synth_queries(B - 6, d, n), X[[0, 2000, 3000, 3500, 4000]], X[[5045]] * np.float32(1e15)])
     ix = _index(za, X, M, T)
     f = zo.Forest.from_arrays(X, M, ix.get_forest())
     for metric in ("l2sq", "cos_parity", "cos", "l2"):

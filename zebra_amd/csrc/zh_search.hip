@@ -2836,6 +2836,7 @@ __device__ __forceinline__ uint32_t f32_sortable(float x) {
 // distance (ZH_COSINE_PARITY keys) in the order of the key's bits.  false: nothing certain about this row (zero / tiny / infinite norms, NaN scores)
 template <int KINDA>
 __device__ __forceinline__ bool pf_value(float h, float nx, float s, float nq, float Kb, float &v, float &e) {
+    if (!(s - s == 0.f) || !(nx - nx == 0.f) || !(nq - nq == 0.f)) return false;  // an overflowed dot product or norm: the two summation orders need not overflow alike
     if (KINDA == 0) {
         const float nn = nx + nq;
         if (!(nn > 1e-12f)) return false;
