@@ -55,7 +55,7 @@ WORKLOADS = {
     # name: rows (total), dim, metric, k, batch, max_node_size (total budget over the shards), trees, kind
     "cfg1": dict(rows=10_000, dim=384, metric="cosine", k=10, batch=1, M=5, T=15, kind=0,
                  desc="10k x 384-d f32 vectors, cosine top-10, single query, reference default options (max_node_size 5)"),
-    "cfg2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, batch=256, M=1024, T=15, kind=0,
+    "cfg2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, batch=256, M=1024, T=15, kind=0, window=4,
                  desc="1M x 384-d cosine top-10, query batch=256, LSH index on 1 MI355X"),
     "cfg3": dict(rows=10_000_000, dim=768, metric="l2", k=100, batch=1024, M=4096, T=15, kind=0,
                  desc="10M x 768-d L2 top-100, query batch=1024, 1 MI355X (HBM-bound candidate sweep)"),
