@@ -154,6 +154,16 @@ typedef struct zh_stats_t {
     uint64_t prefilter_fallbacks_accum; /* batches redone with the sweep because a candidate list ran over (since zh_stats_reset) */
     uint64_t prefilter_last_overflow;   /* ... what ran over in the most recent of them: 1 | 2 a (query, tree) list, 4 the table of
                                          * visits to score exactly, 8 a leaf longer than 64 rows, 16 a query's lists together hold more than the final sort */
+    uint64_t approx_scan;           /* 1: the most recent batch's table scan read HALF-WIDTH (fp16) copies of the queries: every (row, query)
+                                     * pair got an interval that contains the reference's key, the intervals picked the candidates, and only
+                                     * the rows they could not rule out were scored with the reference's arithmetic (zh_set_sweep_mode) */
+    uint64_t approx_exact_visits;   /* ... leaf visits that take fewer than top_k rows: scored and ranked exactly */
+    uint64_t approx_survivors;      /* ... rows (over all queries) that got the reference's key for the final top_k */
+    uint64_t approx_list_entries;   /* ... candidates handed to the per-query stage (before de-duplication) */
+    uint64_t approx_batches_accum;  /* timed internal batches scanned this way */
+    uint64_t approx_fallbacks_accum; /* batches redone by the f32 scan ON THE DEVICE, in stream order, because a list ran over */
+    uint64_t approx_last_overflow;  /* ... what ran over: 1 a query's candidate list, 2 a query's survivors, 4 the table of exact
+                                     * visits, 8 their key scratch */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -1,0 +1,195 @@
+"""The table scan with HALF-WIDTH queries (zh_set_sweep_mode 4 / the default wherever it applies; zebra_amd/csrc/zh_approx.hip):
+the scan reads fp16 copies of the queries and gives every (row, query) pair an INTERVAL that contains the reference's key; the
+intervals pick the candidates, and only the rows they cannot rule out are scored with the reference's arithmetic
+(Metric::distance, /root/reference/src/distance.rs:19-49,103-114; the leaf's `take` nearest, lsh.rs:317-323; the final top_k,
+lsh.rs:557-564).  Ids, keys and counts must equal the oracle's bit for bit -- including where the intervals cannot decide:
+ties at the cut, rows within the bound of the threshold, norms that overflow, zero vectors, NaNs."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zebra_oracle as zo  # noqa: E402  (the checker)
+
+
+@pytest.fixture(scope="module")
+def za():
+    import zebra_amd
+    return zebra_amd
+
+
+def all_metrics(za):
+    return [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0),
+            (za.CosineDistance(parity=True), zo.COSINE, zo.PARITY), (za.CosineDistance(parity=False), zo.COSINE, zo.CORRECTED)]
+
+
+def check(ix, f, Q, k, m, om, omode, what=""):
+    ids, keys, counts = ix.search_batch(Q, k, m)
+    oi, ok, oc = f.search_batch(Q, k, om, omode)
+    assert (counts == oc).all(), (what, om, omode)
+    for b in range(Q.shape[0]):
+        c = int(oc[b])
+        assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), (what, om, omode, b)
+    return ix.stats()
+
+
+CASES = [
+    # n, d, M, T, k, batch, kind, approx expected
+    (20000, 384, 256, 15, 10, 64, 0, True),    # one leaf per tree; four 16-lane groups, three loads per pair
+    (12000, 768, 512, 8, 100, 48, 0, True),    # the cfg3 / cfg4 shape in small: two 32-lane groups
+    (9000, 128, 300, 10, 10, 96, 1, True),     # SIFT-style integer rows: the fp16 copy is exact
+    (9000, 256, 100, 64, 10, 12, 0, True),     # 64 trees: 4 rows per wave
+    (6000, 512, 200, 5, 10, 33, 0, True),
+    (5000, 1024, 128, 6, 20, 17, 0, True),
+    (3001, 512, 3002, 5, 10, 700, 0, True),    # ONE leaf per tree, visited by every query: more pairs than a wave's list holds
+    (7000, 768, 24, 6, 10, 9, 0, True),        # leaves ~ top_k: backup visits that take fewer than top_k rows (the exact path)
+    (4000, 1536, 64, 3, 10, 7, 0, False),      # a dimension the half-width scan does not cover: the f32 scan
+    (5000, 384, 5, 15, 10, 8, 0, False),       # reference defaults: thousands of visits per pair -- not this path's regime
+]
+
+
+@pytest.mark.parametrize("n,d,M,T,k,B,kind,expect", CASES)
+def test_half_width_scan_equals_oracle(za, n, d, M, T, k, B, kind, expect):
+    X = zo.synth_rows(n, d, kind=kind)
+    Q = zo.synth_queries(B, d, n, kind=kind)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    for m, om, omode in all_metrics(za):
+        st = check(ix, f, Q, k, m, om, omode)
+        assert st["approx_scan"] == (1 if expect else 0), (om, omode, st)
+        assert st["approx_fallbacks_accum"] == 0, st
+        if expect:
+            assert st["approx_survivors"] >= min(k, 1) and st["approx_list_entries"] > 0
+    ix.close()
+
+
+def test_exact_visits_are_exercised(za):
+    """leaves shorter than top_k send the walk to backup subtrees with n < top_k (lsh.rs:340-345): those visits must hand over
+    exactly their `take` nearest rows -- the exact path of the half-width scan"""
+    n, d, M, T, k, B = 6000, 768, 120, 8, 32, 24
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    seen = 0
+    for m, om, omode in all_metrics(za):
+        st = check(ix, f, Q, k, m, om, omode)
+        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
+        seen += st["approx_exact_visits"]
+    assert seen > 0
+    ix.close()
+
+
+def _adversarial_rows(n, d, rng):
+    """rows built to sit on the cut: exact duplicates, rows one ulp apart, integer-valued rows (ties in every metric), zero rows,
+    rows with huge / tiny norms, a NaN row and an infinite row"""
+    X = zo.synth_rows(n, d)
+    base = X[:64].copy()
+    X[100:164] = base                                   # duplicates of rows 0..63: equal keys, ids decide
+    X[200:264] = np.nextafter(base, np.float32(np.inf))  # one ulp away in every coordinate
+    X[300:364] = np.nextafter(base, np.float32(-np.inf))
+    X[400:700] = np.round(X[400:700] * 2.0)             # small integers: many exact ties
+    X[700:710] = 0.0                                    # zero rows (simsimd's zero-norm cases)
+    X[710:720] *= np.float32(1e18)                      # |x|^2 overflows f32
+    X[720:730] *= np.float32(1e-20)                     # squares underflow
+    X[730, 3] = np.nan
+    X[731, 5] = np.inf
+    X[732] = -X[0]                                      # the antipode: negative cosine (parity order)
+    return X
+
+
+def test_adversarial_rows_and_queries(za):
+    rng = np.random.default_rng(7)
+    n, d, M, T, k, B = 4000, 768, 1024, 6, 50, 40
+    X = _adversarial_rows(n, d, rng)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X)
+    ix.set_forest(f.arrays())        # (the oracle's forest: a NaN sample row makes a NaN plane, whose payload bits need not agree)
+    ix.set_sweep_mode("approx")
+    Q = zo.synth_queries(B, d, n)
+    Q[0] = X[0]                      # a stored row itself: distance 0, its duplicates tie
+    Q[1] = X[410]                    # an integer row
+    Q[2] = 0.0                       # the zero query
+    Q[3] = X[0] * np.float32(1e18)   # overflowing query norm: every L2 key is +inf, ids decide
+    Q[4] = X[5] * np.float32(1e-20)
+    Q[6] = -X[1]                     # every near row has a negative cosine
+    Q[7] = np.round(Q[7] * 3.0)
+    # (no NaN / inf QUERY: every key would be a NaN, whose sign bit differs between the host's and the GPU's arithmetic)
+    for m, om, omode in all_metrics(za):
+        st = check(ix, f, Q, k, m, om, omode, "adversarial")
+        assert st["approx_scan"] == 1
+    ix.close()
+
+
+def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch):
+    """a candidate list, the survivors, the table of exact visits or their key scratch running over raises a flag on the device
+    and the f32 scan + select + final enqueued behind redo the batch in stream order: same results, counted in the stats"""
+    n, d, M, T, k, B = 8000, 768, 120, 8, 32, 24
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    m, om, omode = za.L2Distance(), zo.L2, 0
+    st = check(ix, f, Q, k, m, om, omode)
+    assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0 and st["approx_exact_visits"] > 0
+    seen = 0
+    for caps, bit in (("64,0,0", 1), ("0,1,0", 4), ("0,0,8", 8)):
+        monkeypatch.setenv("ZH_APX_CAPS", caps)
+        ix.stats(reset=True)
+        st = check(ix, f, Q, k, m, om, omode, caps)
+        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 1 and (st["approx_last_overflow"] & bit), (caps, st)
+        seen += 1
+    monkeypatch.delenv("ZH_APX_CAPS")
+    ix.stats(reset=True)
+    st = check(ix, f, Q, k, m, om, omode)  # mode 4 keeps trying after strikes
+    assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
+    assert seen == 3
+    ix.close()
+
+
+def test_windows_through_contexts_and_default_mode(za):
+    """the pipelined window calls (results consumed in stream order) and the default sweep mode: a forest with long leaves that
+    has served a few batches takes the half-width scan by itself"""
+    import torch
+    n, d, M, T, k, B = 30000, 768, 2048, 15, 10, 64
+    X = zo.synth_rows(n, d)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    m, om, omode = za.CosineDistance(parity=True), zo.COSINE, zo.PARITY
+    Qs = [zo.synth_queries(B, d, n, b0=i * B) for i in range(3)]
+    for _ in range(5):
+        ix.search_batch(Qs[0], k, m)
+    st = check(ix, f, Qs[0], k, m, om, omode, "default mode")
+    assert st["table_scan"] == 1 and st["approx_scan"] == 1, st
+    dev = torch.device("cuda", 0)
+    dq = [torch.from_numpy(q).to(dev) for q in Qs]
+    out = [dict(ids=torch.empty((B, k), dtype=torch.int64, device=dev), keys=torch.empty((B, k), dtype=torch.int64, device=dev),
+                counts=torch.empty(B, dtype=torch.int32, device=dev)) for _ in Qs]
+    ix.set_sweep_mode("approx")  # (which sweep the cost model picks for this small window is not the point here)
+    ctx = ix.search_context()
+    s = torch.cuda.Stream(device=dev)
+    ctx.begin_window([q.data_ptr() for q in dq], B, k, m, s.cuda_stream)
+    ctx.finish_window([o["ids"].data_ptr() for o in out], [o["keys"].data_ptr() for o in out], [o["counts"].data_ptr() for o in out],
+                      ix.sweep_stream())
+    s.synchronize()  # stream order is enough: nothing is redone from the host
+    host = [(o["ids"].cpu().numpy().view(np.uint64), o["keys"].cpu().numpy().view(np.uint64), o["counts"].cpu().numpy().view(np.uint32)) for o in out]
+    ctx.wait()
+    assert ix.stats()["approx_scan"] == 1 and ix.stats()["window_batches"] == 3
+    for q, (ids, keys, counts) in zip(Qs, host):
+        oi, ok, oc = f.search_batch(q, k, om, omode)
+        assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()
+    ctx.close()
+    ix.close()

@@ -52,7 +52,10 @@ class Stats(C.Structure):
                 ("window_batches", C.c_uint64), ("table_scan", C.c_uint64), ("scan_batches_accum", C.c_uint64),
                 ("hash_from_scores", C.c_uint64), ("hash_exact_fixups", C.c_uint64),
                 ("prefiltered", C.c_uint64), ("prefilter_exact_visits", C.c_uint64), ("prefilter_exact_rows", C.c_uint64),
-                ("prefilter_fallbacks_accum", C.c_uint64), ("prefilter_last_overflow", C.c_uint64)]
+                ("prefilter_fallbacks_accum", C.c_uint64), ("prefilter_last_overflow", C.c_uint64),
+                ("approx_scan", C.c_uint64), ("approx_exact_visits", C.c_uint64), ("approx_survivors", C.c_uint64),
+                ("approx_list_entries", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
+                ("approx_last_overflow", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -102,7 +102,7 @@ struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
         wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl,
-        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl, wUnc;
+        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl, wUnc, wQh, wQmeta, wApList, wApCount, wApEx, wApExKeys, wApCtl;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -120,6 +120,10 @@ struct zh_search_ctx {
     hipStream_t s = nullptr;
     ZhTotals tot{};
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
+    // ... with half-width queries (zh_approx.hip): intervals from the scan, the reference's keys for the few rows they cannot
+    // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
+    bool approx = false;
+    uint32_t *h_ap = nullptr;
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     uint32_t score_Bp = 0;    // ... for this many (padded) queries per stored row
     bool lazy_fix = false;    // ... with the uncertain signs flagged (wUnc) for the blocked walk to recompute when it meets one
@@ -135,13 +139,15 @@ struct zh_search_ctx {
     std::vector<DevBuf *> all_bufs() {
         return {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                 &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
-                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl, &wUnc};
+                &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl, &wUnc,
+                &wQh, &wQmeta, &wApList, &wApCount, &wApEx, &wApExKeys, &wApCtl};
     }
     void release_all() {
         for (DevBuf *b : all_bufs()) b->release();
         if (ev_ok) { for (auto &e : ev) hipEventDestroy(e); hipEventDestroy(ev_totals); hipEventDestroy(ev_emit); hipEventDestroy(ev_sw0); hipEventDestroy(ev_sw1); ev_ok = false; }
         if (h_totals) { hipHostFree(h_totals); h_totals = nullptr; }
         if (h_pf) { hipHostFree(h_pf); h_pf = nullptr; }
+        if (h_ap) { hipHostFree(h_ap); h_ap = nullptr; }
     }
 };
 
@@ -195,7 +201,8 @@ struct zh_index {
 
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
-    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan, 3 = 0
+    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies
+    std::atomic<uint32_t> approx_strikes{0};  // batches in a row whose half-width scan ran over and was redone exactly: after three the exact scan until the trees change
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
@@ -252,6 +259,9 @@ static int ctx_init(zh_search_ctx *c, zh_index *ix) {
     e = hipHostMalloc((void **)&c->h_pf, 4 * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
     memset(c->h_pf, 0, 4 * sizeof(uint32_t));
+    e = hipHostMalloc((void **)&c->h_ap, ZH_APX_CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    memset(c->h_ap, 0, ZH_APX_CTL_WORDS * sizeof(uint32_t));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_emit, hipEventDisableTiming));
@@ -1117,8 +1127,9 @@ extern "C" int zh_set_hash_mode(zh_index *ix, int mode) {
 }
 extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    if (mode < 0 || mode > 3)
-        return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan, 3 = as 0: prefilter where row scores exist)", mode);
+    if (mode < 0 || mode > 4)
+        return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan with f32 queries, 3 = as 0: prefilter where row scores exist, "
+                               "4 = table scan with half-width queries wherever it applies)", mode);
     ix->sweep_mode = mode;
     return ZH_OK;
 }
@@ -1261,20 +1272,39 @@ static int build_row_leaf(zh_index *ix) {
 // fetches one query from L2 per scored (row, query) pair -- measured 0.075 + 0.00022 d ns per pair chip-wide (4.1 G pairs/s
 // at d = 768 = what the L2s deliver; 10 G pairs/s at d = 128 with the paired kernel, where the leaf-major sweep still wins at the BASELINE shapes), slower once the window's queries no
 // longer fit beside the stream in the 8 x 4 MB of L2.  zh_set_sweep_mode / ZH_SWEEP_MODE=leaf|scan force one of them.
-static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B) {
-    static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : 1); }();
+static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric);
+static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B, size_t k) {
+    static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
     const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
-    if (mode == 2) return true;
+    if (mode == 2 || mode == 4) return true;
     if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
     const double row_b = 4.0 * d;
     const double t_leaf = (double)tot.group_rows * row_b / (d >= 256 ? 6.0e12 : 5.5e12);
-    const double q_bytes = (double)B * row_b;
-    const double pair_s = d == 128 ? 0.10e-9 : 0.075e-9 + 0.00022e-9 * d;  // (d = 128: the paired kernel, two pairs per step)
+    // with half-width queries (zh_approx.hip) a pair pulls 2 d bytes through the vector L1 instead of 4 d: measured 0.157 ns per pair at
+    // d = 768 (cfg3, window 2, profiles/r04_*), and twice the queries fit beside the stream in L2
+    const bool half = use_approx(ix, tot, B, k, metric);
+    const double q_bytes = (double)B * row_b * (half ? 0.5 : 1.0);
+    const double pair_s = half ? 0.05e-9 + 0.00014e-9 * d
+                               : (d == 128 ? 0.10e-9 : 0.075e-9 + 0.00022e-9 * d);  // (d = 128: the paired kernel, two pairs per step)
     const double t_pairs = (double)tot.rows * pair_s * (q_bytes > 8e6 ? 1.25 : 1.0);
     const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 6.0e12, t_pairs) + 20e-6;
     return t_scan < 0.92 * t_leaf;
+}
+
+// The table scan with half-width queries (zh_approx.hip) instead of the f32 one?  Wherever it applies: the metrics whose key a dot
+// product determines, the dimensions its groups divide, batches in the few-visits-per-pair regime (long leaves) whose candidate
+// lists fit the per-query sort.  ZH_SWEEP_MODE=scan / zh_set_sweep_mode(2) keep the f32 scan; =approx / mode 4 say so explicitly.
+static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric) {
+    static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
+    static const bool off = getenv("ZH_NO_APPROX") != nullptr;
+    const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    if (off || mode == 2 || mode == 1) return false;
+    if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0) return false;
+    if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
+    if (mode != 4 && ix->approx_strikes.load() >= 3) return false;
+    return true;
 }
 
 // number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
@@ -1442,6 +1472,7 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
     c->nwin = nwin; c->bwin = bwin;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
+    c->approx = false;
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
@@ -1667,7 +1698,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
             if (c->wLogPool.ensure(chunks * ZH_LOG_CHUNK * sizeof(uint2)) == ZH_OK) c->log_chunks = chunks;
         }
     }
-    c->scan = choose_scan(ix, tot, c->metric, B);
+    c->scan = choose_scan(ix, tot, c->metric, B, k);
     if (c->scan && (!ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows)) {  // first table scan since the trees (or the row count) changed
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if ((!ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows) && !ix->row_leaf_failed && (rc = build_row_leaf(ix))) return rc;
@@ -1682,16 +1713,45 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     }
     if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
+    c->approx = c->scan && use_approx(ix, tot, B, k, c->metric);
+    ZhApprox ap{};
+    if (c->approx) {
+        // per query: room for twice its share of the candidates + 256 (a visit hands on the rows its intervals cannot rule out:
+        // a few more than `take`), at most what final_interval_kernel's sort holds; the exact path for visits that take fewer
+        // than top_k rows: its table and key scratch sized from the batch
+        const char *cap_e = getenv("ZH_APX_CAPS");  // tests: "capq,ex_cap,ex_rows" -- lists and tables that run over (read per batch)
+        unsigned e_capq = 0, e_excap = 0, e_exrows = 0;
+        if (cap_e) sscanf(cap_e, "%u,%u,%u", &e_capq, &e_excap, &e_exrows);
+        const uint32_t capq = e_capq ? std::min(e_capq, 4096u) : (uint32_t)std::min<uint64_t>(4096, ((2 * tot.takes / B + 256) + 63) / 64 * 64);
+        const uint32_t ex_cap = e_excap ? e_excap : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, tot.visits / 4 + 1024), 1u << 24);
+        const uint32_t ex_rows = e_exrows ? e_exrows : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, tot.rows / 16), 1u << 26);
+        if ((rc = c->wQh.ensure(B * d * 2)) || (rc = c->wQmeta.ensure(B * sizeof(float4))) || (rc = c->wApList.ensure((size_t)B * capq * 12)) ||
+            (rc = c->wApCount.ensure(B * 4)) || (rc = c->wApEx.ensure((size_t)ex_cap * 4)) || (rc = c->wApExKeys.ensure((size_t)ex_rows * 20)) ||
+            (rc = c->wApCtl.ensure(ZH_APX_CTL_WORDS * 4)))
+            return rc;
+        ap.Qh = c->wQh.p; ap.qmeta = c->wQmeta.as<float4>(); ap.iv = c->wKeys.as<uint64_t>();
+        ap.list_lo = c->wApList.as<uint32_t>(); ap.list_hi = ap.list_lo + (size_t)B * capq; ap.list_id = ap.list_hi + (size_t)B * capq;
+        ap.qcount = c->wApCount.as<uint32_t>(); ap.capq = capq;
+        ap.ex_visits = c->wApEx.as<uint32_t>(); ap.ex_cap = ex_cap;
+        ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
+        ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
+        HIPCHK(hipMemsetAsync(c->wApCtl.p, 0, ZH_APX_CTL_WORDS * 4, s));
+        HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), s));
+    }
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
     // successive batches execute back to back while everything else overlaps them on the contexts' own streams
     hipStream_t hs = heavy ? heavy : s;
     if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
-    if (c->scan)
+    if (c->approx)
+        HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
+                                     c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group, c->metric, c->mode, hs));
+    else if (c->scan)
         HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
                                     c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group,
-                                    c->metric, c->mode, c->wKeys.as<uint64_t>(), hs));
+                                    c->metric, c->mode, c->wKeys.as<uint64_t>(), nullptr, hs));
     else
         HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(),
                                c->wGroupRowOff.as<uint64_t>(), tot.groups, no_wave_table ? nullptr : c->wWaveGroup.as<uint32_t>(), f.leaf_ids,
@@ -1699,11 +1759,26 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     HIPCHK(hipEventRecord(c->ev_sw1, hs));
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
     HIPCHK(hipEventRecord(c->ev[3], s));
+    const uint32_t *run_if = nullptr;
+    if (c->approx) {
+        HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, s));
+        HIPCHK(hipEventRecord(c->ev[4], s));
+        HIPCHK(zh_launch_final_interval(c->wVisits.as<ZhVisit>(), ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), (uint32_t)B, (uint32_t)k,
+                                        f.leaf_ids, c->metric, c->mode, ix->opt.id_base, ap, dOutIds, dOutKeys, dOutCounts, s));
+        HIPCHK(hipMemcpyAsync(c->h_ap, c->wApCtl.p, ZH_APX_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
+        // A list or table ran over (ctl[1] != 0): the f32 scan, select and final, enqueued here with that word as their predicate,
+        // redo the batch in stream order -- kernels that return at once otherwise.  On the context's own stream: the shared sweep
+        // stream must not wait for this batch's light kernels.
+        run_if = ap.ctl + 1;
+        HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
+                                    c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group,
+                                    c->metric, c->mode, c->wKeys.as<uint64_t>(), run_if, s));
+    }
     HIPCHK(zh_launch_select(c->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, c->wKeys.as<uint64_t>(),
-                            c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), ix->max_leaf_len, s));
-    HIPCHK(hipEventRecord(c->ev[4], s));
+                            c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), ix->max_leaf_len, run_if, s));
+    if (!c->approx) HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(zh_launch_final(c->wCandBase.as<uint64_t>(), (uint32_t)B, T, (uint32_t)k, c->wCandKeys.as<uint64_t>(),
-                           c->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, s));
+                           c->wCandIds.as<uint32_t>(), ix->opt.id_base, dOutIds, dOutKeys, dOutCounts, run_if, s));
     for (size_t j = 0; j < nwin && nwin > 1; j++) {
         HIPCHK(hipMemcpyAsync(outIds[j], dOutIds + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(outKeys[j], dOutKeys + j * bwin * k, bwin * k * 8, hipMemcpyDeviceToDevice, s));
@@ -1768,6 +1843,17 @@ int ctx_wait(zh_search_ctx *c) {
                         : (c->scan ? ix->n_rows * ((uint64_t)4 * ix->opt.dim + 8 * ix->n_trees) + tot.rows * 8
                                    : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8);
     st.table_scan = c->scan && !pf ? 1 : 0;
+    const bool apx = c->approx && !pf;
+    st.approx_scan = apx ? 1 : 0;
+    st.approx_exact_visits = apx ? c->h_ap[0] : 0;
+    st.approx_survivors = apx ? c->h_ap[3] : 0;
+    st.approx_list_entries = apx ? c->h_ap[4] : 0;
+    if (apx && c->h_ap[1]) {
+        st.approx_fallbacks_accum++;
+        st.approx_last_overflow = c->h_ap[1];
+        ix->approx_strikes.fetch_add(1);
+    } else if (apx)
+        ix->approx_strikes = 0;
     st.prefiltered = pf ? 1 : 0;
     st.prefilter_exact_visits = pf_amb;
     st.prefilter_exact_rows = pf_exact;
@@ -1783,6 +1869,7 @@ int ctx_wait(zh_search_ctx *c) {
         const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim);
         st.sweep_launches_accum += (swept + rpl - 1) / rpl;
         st.scan_batches_accum += c->scan && !pf ? 1 : 0;
+        st.approx_batches_accum += apx ? 1 : 0;
     }
     return ZH_OK;
 }

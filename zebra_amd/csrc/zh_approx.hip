@@ -1,0 +1,752 @@
+// zh_approx.hip -- the table scan with HALF-WIDTH queries (round 4); shares zh_device.h's helpers (butterflies, select_fast /
+// select_slow, the canonical sums) with zh_search.hip.
+//
+// What bounds scan_sweep_kernel is the rate at which (row, query) pairs pull their query through TA / vector L1 / L2: 4*d bytes
+// per pair (profiles/r03_pmc_scan_mix.txt).  Here the queries of a batch are copied ONCE to fp16 (power-of-two scaled per query,
+// round to nearest even), laid out so that a lane's eight halves are one 16-byte load: 2*d bytes per pair, and every load a full
+// dwordx4.  A wave works as G groups of 64 / G lanes; all groups hold the SAME stored row (f32, from HBM, as before) and each
+// scores it against a different query of the row's pair list: x . h by v_fma_mix_f32 (f32 += f32 * f16, one rounding), a
+// 16- or 32-lane butterfly, one result per group and step.
+//
+// The f32 sum is NOT the reference's key.  It determines the key up to a rigorous interval [lo, hi] (derivation at
+// zh_approx_bound): the fp16 rounding of the query is MEASURED per query (|q - h / sigma|, not assumed 2^-11), the f32 rounding
+// of every sum involved is bounded as for the prefilter.  The intervals decide what they can:
+//   select_interval  a visit hands over its `take` nearest rows (lsh.rs:317-323).  take == top_k: ANY superset inside the leaf
+//                    gives the same final answer (a row outside the visit's top_k is beaten by top_k rows of that visit, all of
+//                    them candidates), so every row whose lo does not exceed the take-th smallest hi goes on.  take < top_k (a
+//                    backup visit after a short leaf, lsh.rs:340-345): membership matters -- exact_visit_kernel scores the
+//                    leaf with the reference's arithmetic and ranks by (key, id), as sweep + select would.
+//   final_interval   per query: duplicates out (a row reached through several trees), tau = the top_k-th smallest hi, the rows
+//                    with lo <= tau (a few more than top_k) get the reference's key (canonical sums), sort by (key, id), top_k
+//                    (lsh.rs:557-564).
+// Every key returned is the canonical one and no leaf member is left unranked: results are bit-identical to the exact scan by
+// construction.  A list or table that runs over raises a flag ON THE DEVICE, and the exact scan + select + final -- enqueued
+// behind with that flag as their predicate -- redo the batch in stream order; no host round trip, so the sharded search (which
+// consumes results in stream order) can use it too.
+
+#include "zh_internal.h"
+#include "zh_device.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// groups per wave by dimension (0: not supported -> exact scan): every lane loads NH = d * G / 512 dwordx4 of halves per pair
+uint32_t zh_approx_groups(uint32_t d) {
+    switch (d) {
+    case 128: case 256: case 384: return 4;
+    case 512: case 768: case 1024: return 2;
+    default: return 0;
+    }
+}
+
+// Half-width of the interval around the value the approximate scan computes (u = 2^-24, c0 = ceil(d / 256) + 8 = the longest
+// chain of the canonical sums; nx, nq upper estimates of |x|, |q|; dq >= |q - h / sigma|, measured by qhalf_kernel).
+// L2 family, in the scale of d* = the canonical f32 sum of (x_i - q_i)^2 (L2's sqrt is monotone): the kernel forms
+//   V = (a2 + b2) - 2 s / sigma,   a2, b2 = f32 sums of squares (<= 32 roundings each), s = f32 sum of x_i h_i (<= 32 roundings)
+// and |d* - D| <= (c0 + 3) u D, |a2 - |x|^2| <= 32 u |x|^2, |b2 - |q|^2| <= 32 u |q|^2, |s / sigma - x.q| <= |x| dq + 33 u |x||q|,
+// two roundings for V itself: |V - d*| <= (c0 + 54) u (|x| + |q|)^2 + 2 |x| dq; (c0 + 100) leaves room for V +- E and E themselves.
+// Cosine, in the scale of the clipped distance 1 - cos: the canonical sums give the reference's value within 2 c0 u of the real
+// one; s / (sigma nx nq) within dq / |q| + 73 u; + 4 u for the kernel's own roundings -> (2 c0 + 80) u + dq / |q|.
+float zh_approx_bound(int metric, uint32_t d) {
+    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0;
+    if (metric == ZH_COSINE) return (float)(1.01 * (2.0 * c0 + 80.0) * u);
+    return (float)(1.01 * (c0 + 100.0) * u);
+}
+
+// ---- the fp16 copy of a batch's queries ----
+// sigma = 2^(14 - e) with max |q_i| in [2^(e-1), 2^e): h_i = rne_f16(q_i sigma), |h_i| < 2^14.  Layout per query (2 d bytes): NH
+// blocks of LG * 16 bytes; block i, lane l holds the halves of elements 4 LG (2 i) + 4 l + t (t = 0..3) and 4 LG (2 i + 1) + 4 l + t
+// -- the elements of the row registers 2 i and 2 i + 1 of a lane whose group loads the stored row as 4 LG-element pieces.
+// qmeta = {1 / sigma, f32 |q|^2, upper estimate of |q|, upper estimate of |q - h / sigma|}; all NaN: nothing is certain about
+// this query (non-finite or out-of-range elements) -- its pairs get the interval (-inf, +inf).
+template <int G>
+__global__ __launch_bounds__(64) void qhalf_kernel(const float *__restrict__ Q, uint32_t B, uint32_t d, _Float16 *__restrict__ Qh,
+                                                    float4 *__restrict__ qmeta) {
+    constexpr uint32_t LG = 64 / G;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const float *q = Q + (size_t)b * d;
+    float m = 0.f, s2 = 0.f;
+    bool bad = false;
+    for (uint32_t e = lane; e < d; e += 64) {
+        const float v = q[e];
+        bad |= !(v - v == 0.f);
+        m = fmaxf(m, fabsf(v));
+        s2 = __builtin_fmaf(v, v, s2);
+    }
+    m = wave_butterfly<OpMax>(m);
+    s2 = wave_sum_canonical(s2);
+    bad = __ballot(bad) != 0;
+    float sigma = 1.f, inv = 1.f;
+    if (!bad && m > 0.f) {
+        int ex = 0;
+        (void)frexpf(m, &ex);
+        if (ex < -90 || ex > 90) bad = true;
+        else { sigma = ldexpf(1.f, 14 - ex); inv = ldexpf(1.f, ex - 14); }
+    }
+    float d2 = 0.f;
+    for (uint32_t e = lane; e < d; e += 64) {
+        const float v = bad ? 0.f : q[e];
+        const _Float16 h = (_Float16)(v * sigma);
+        const float df = v - (float)h * inv;
+        d2 = __builtin_fmaf(df, df, d2);
+        const uint32_t j = e / (4 * LG), rem = e % (4 * LG), l = rem / 4, t = rem % 4, i = j / 2, wh = j % 2;
+        Qh[(size_t)b * d + ((size_t)(i * LG + l)) * 8 + wh * 4 + t] = h;
+    }
+    d2 = wave_sum_canonical(d2);
+    if (lane == 0) {
+        float4 o;
+        if (bad || !(s2 - s2 == 0.f)) o = make_float4(NAN, NAN, NAN, NAN);
+        else o = make_float4(inv, s2, sqrtf(s2) * (1.0f + 1e-5f), sqrtf(d2) * 1.001f);
+        qmeta[b] = o;
+    }
+}
+
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const uint32_t G = zh_approx_groups(d);
+    if (G == 4) hipLaunchKernelGGL(qhalf_kernel<4>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    else if (G == 2) hipLaunchKernelGGL(qhalf_kernel<2>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// sum over the LG lanes of a group (LG = 16, 32 or 64): the first steps of the canonical butterfly
+template <int LG>
+__device__ __forceinline__ float group_sum(float s) {
+    s = s + dpp_mov<0xB1>(s);
+    s = s + dpp_mov<0x4E>(s);
+    s = s + dpp_mov<0x141>(s);
+    s = s + dpp_mov<0x140>(s);
+    if (LG >= 32) s = xor16<OpAdd>(s);
+    if (LG >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+        s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return s;
+}
+
+// the interval of one (row, query) pair from its sums: sortable lo | sortable hi << 32; (0, all ones) = nothing certain
+template <int KINDA>
+__device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc) {
+    uint32_t lo_s = 0u, hi_s = 0xFFFFFFFFu;
+    const float sh = s * qm.x;
+    if (KINDA == 0) {
+        const float nx = sqrtf(a2) * (1.0f + 1e-5f), nn = nx + qm.z, sum = a2 + qm.y;
+        const float V = sum - 2.0f * sh;
+        const float E = Kc * nn * nn + 2.02f * nx * qm.w;
+        if ((V - V == 0.f) && (E - E == 0.f) && nn > 1e-12f && sum < 1e37f) { lo_s = f32_sortable(V - E); hi_s = f32_sortable(V + E); }
+    } else {
+        const float nx = sqrtf(a2), nq = sqrtf(qm.y);
+        if (nx > 1e-12f && nq > 1e-12f && (sh - sh == 0.f) && (nx - nx == 0.f) && (nq - nq == 0.f)) {
+            float r = 1.0f - sh / (nx * nq);
+            r = r > 0.f ? r : 0.f;
+            const float e = Kc + 1.01f * qm.w / nq;
+            float v = r;
+            bool ok = true;
+            if (KINDA == 2) {  // ZH_COSINE_PARITY keys compare as the bits of 1 - distance: as pf_value<2>
+                const float key = 1.0f - r;
+                ok = fabsf(key) > e;
+                v = key > 0.f ? key : 2.0f - key;
+            }
+            if (ok && (v - v == 0.f) && (e - e == 0.f)) { lo_s = f32_sortable(v - e); hi_s = f32_sortable(v + e); }
+        }
+    }
+    return ((uint64_t)hi_s << 32) | lo_s;
+}
+
+#define ZH_APX_CAP 512   // pair records of a wave's LDS list
+#ifndef ZH_APX_WAVES
+#define ZH_APX_WAVES 0
+#endif
+#ifndef ZH_APX_REPL_ROWS
+#define ZH_APX_REPL_ROWS 0   // A/B: every group loads the row for itself
+#endif
+template <int D, int G, int KINDA>
+__global__ __launch_bounds__(256)
+#if ZH_APX_WAVES
+__attribute__((amdgpu_waves_per_eu(ZH_APX_WAVES, 8)))
+#endif
+void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Qh,
+                                                           const float4 *__restrict__ qmeta, const uint2 *__restrict__ rowLeaf,
+                                                           uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
+                                                           const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
+                                                           uint32_t GRP, uint64_t row_begin, uint64_t row_end, float Kc,
+                                                           uint64_t *__restrict__ iv) {
+    constexpr int LG = 64 / G, NH = D * G / 512, NR = 2 * NH;  // lanes per group; dwordx4 of halves per pair; float4 registers per row
+#ifdef ZH_APX_RB
+    constexpr int RB = ZH_APX_RB;
+#else
+    constexpr int RB = NR <= 6 ? 4 : 2;                         // rows per HBM round trip
+#endif
+    static_assert(D * G % 512 == 0 && NH >= 1, "a lane's share of a query is whole 16-byte loads");
+    __shared__ uint4 pair_list[4][ZH_APX_CAP];  // {row of the wave's RW, query, interval slot lo, hi}
+    __shared__ uint32_t row_start[4][20];
+    const uint32_t lane = threadIdx.x & 63, l = lane & (LG - 1), g = lane / LG;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r0 = row_begin + wave * RW;
+    if (r0 >= row_end) return;
+    const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
+    const uint32_t n_ent = nr * T;
+    const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+    // ---- phase 1 (as scan_sweep_kernel): the wave's nr * T (row, tree) entries -> pairs, in (row, tree, visit) order ----
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
+    uint64_t eK0[ZH_SCAN_NE];
+    uint32_t P = 0;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t e = lane + 64u * j;
+        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0; eB0[j] = 0; eK0[j] = 0;
+        if (e < n_ent) {
+            const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));
+            const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
+            eWithin[j] = rl.y;
+            if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
+                const uint4 nv = nodeVisit[rl.x];
+                eC[j] = nv.x & 0x0FFFFFFFu; eGb[j] = nv.y; eB0[j] = nv.z;
+                eK0[j] = ((uint64_t)(nv.x >> 28) << 32) | nv.w;
+            }
+        }
+        uint32_t incl = eC[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        off[j] = P + incl - eC[j];
+        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (P == 0) return;
+    const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
+    // finished sums wait in lane registers -- group g's result of step n in lane g * LG + n -- so that the interval arithmetic and
+    // the stores run for 64 pairs at once
+    float my_s = 0.f, my_a2 = 0.f;
+    uint64_t my_slot = 0;
+    uint32_t my_b = 0, nst = 0;
+    bool my_on = false;
+    auto flush = [&]() {
+        if (my_on) __builtin_nontemporal_store(approx_interval<KINDA>(my_s, my_a2, qmeta[my_b], Kc), iv + my_slot);
+        my_on = false;
+        nst = 0;
+    };
+    auto load_q = [&](uint32_t b, uint4 *hq) {
+        const uint4 *qp = Qh + (size_t)b * (D / 8) + l;
+#pragma unroll
+        for (int i = 0; i < NH; i++) hq[i] = qp[i * LG];
+    };
+    // A stored row, streamed once per window.  Every group needs the whole row as 4 LG-element pieces (register j: elements
+    // 4 LG j + 4 l + t).  G = 2: the wave loads each 1-KiB piece ONCE (64 lanes x 16 bytes) and v_permlane32_swap hands both halves
+    // to both groups -- the replicated form (each group loading for itself) put every row through the TA twice, 20 of the 64 GB
+    // a cfg3 launch pulls through the vector L1s (profiles/r04_pmc_scan_approx.txt).  G = 4: replicated loads.
+    auto load_x = [&](uint64_t row, float4 *v) {
+        if constexpr (G == 2 && !ZH_APX_REPL_ROWS) {
+            const float4 *r4 = X4 + (size_t)row * (D / 4) + lane;
+#pragma unroll
+            for (int j = 0; j < NR / 2; j++) {
+                const float4 t = ld16<true>(r4 + 64 * j);
+                const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.x), __float_as_uint(t.x), false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.y), __float_as_uint(t.y), false, false);
+                const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.z), __float_as_uint(t.z), false, false);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.w), __float_as_uint(t.w), false, false);
+                v[2 * j] = make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sz[0]), __uint_as_float(sw[0]));
+                v[2 * j + 1] = make_float4(__uint_as_float(sx[1]), __uint_as_float(sy[1]), __uint_as_float(sz[1]), __uint_as_float(sw[1]));
+            }
+        } else {
+            const float4 *r4 = X4 + (size_t)row * (D / 4) + l;
+#pragma unroll
+            for (int j = 0; j < NR; j++) v[j] = ld16<true>(r4 + LG * j);
+        }
+    };
+    auto row_sumsq = [&](const float4 *v) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NR; j++) sq4(v[j], c);
+        return group_sum<LG>((c.x + c.y) + (c.z + c.w));
+    };
+    auto dot_h = [&](const float4 *v, const uint4 *hq) {  // x . h over the lane's 8 NH elements, then over the group
+        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            f16x8 h;
+            __builtin_memcpy(&h, &hq[i], 16);
+            ax = __builtin_fmaf(v[2 * i].x, (float)h[0], ax);
+            ay = __builtin_fmaf(v[2 * i].y, (float)h[1], ay);
+            az = __builtin_fmaf(v[2 * i].z, (float)h[2], az);
+            aw = __builtin_fmaf(v[2 * i].w, (float)h[3], aw);
+            ax = __builtin_fmaf(v[2 * i + 1].x, (float)h[4], ax);
+            ay = __builtin_fmaf(v[2 * i + 1].y, (float)h[5], ay);
+            az = __builtin_fmaf(v[2 * i + 1].z, (float)h[6], az);
+            aw = __builtin_fmaf(v[2 * i + 1].w, (float)h[7], aw);
+        }
+        return group_sum<LG>((ax + ay) + (az + aw));
+    };
+    auto stash = [&](float s, float a2, uint32_t b, uint64_t slot, bool valid) {
+        if (l == nst) { my_s = s; my_a2 = a2; my_b = b; my_slot = slot; my_on = valid; }
+        if (++nst == (uint32_t)LG) flush();
+    };
+    if (P <= ZH_APX_CAP) {
+        uint4 *list = pair_list[wid];
+        uint32_t *rstart = row_start[wid];
+        uint32_t mrows = 0;
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            const uint32_t e = lane + 64u * j, c = eC[j];
+            if (e < n_ent && e % T == 0) rstart[e / T] = off[j];  // the first entry of a row: its pairs start here
+            if (c) {
+                const uint32_t rl = e / T, gb = eGb[j];
+                mrows |= 1u << rl;
+                {
+                    const uint64_t slot = eK0[j] + eWithin[j];
+                    list[off[j]] = make_uint4(rl, eB0[j], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+                for (uint32_t sidx = 1; sidx < c; sidx++) {
+                    const ZhGroup *gp = groups + gb + sidx / GRP;
+                    const uint64_t slot = gp->key_off[sidx % GRP] + eWithin[j];
+                    list[off[j] + sidx] = make_uint4(rl, gp->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
+                }
+            }
+        }
+        if (lane == 0) rstart[nr] = P;
+        uint32_t rowmask = 0;
+#pragma unroll
+        for (int bit = 0; bit < 16; bit++) rowmask |= (__ballot((mrows >> bit) & 1u) != 0 ? 1u : 0u) << bit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: rows with pairs RB at a time (one HBM round trip), a row's pairs G at a time -- group g takes pair p + g; the
+        // pairs of the wave are ONE sequence (the next row's pairs follow the current row's in the list), so the queries of the
+        // next step, whichever row it belongs to, are requested before the current step is computed ----
+        uint32_t p = 0;
+        uint4 rec = list[g < P ? g : P - 1];
+        uint4 hq[NH];
+        load_q(rec.y, hq);
+        while (rowmask) {
+            uint32_t rid[RB];
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                rid[r] = rowmask ? (uint32_t)__builtin_ctz(rowmask) : 0xFFFFFFFFu;
+                rowmask &= rowmask - 1;
+            }
+            float4 v[RB][NR];
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+                if (rid[r] != 0xFFFFFFFFu) load_x(r0 + rid[r], v[r]);
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if (rid[r] == 0xFFFFFFFFu) continue;
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)rstart[rid[r] + 1]);
+                const float a2 = row_sumsq(v[r]);
+#ifndef ZH_APX_NO_PINGPONG
+                // two steps per trip, the two query buffers swapping roles: no register copies except after a row's odd last step
+                uint4 recn, hqn[NH];
+                auto one = [&](const uint4 &ru, const uint4 *hu, uint4 &rp, uint4 *hp) {
+                    const uint32_t pn = p + G < pb ? p + G : pb;
+                    rp = list[pn + g < P ? pn + g : P - 1];
+                    load_q(rp.y, hp);
+                    const float s = dot_h(v[r], hu);
+                    stash(s, a2, ru.y, ((uint64_t)ru.w << 32) | ru.z, p + g < pb);
+                    p = pn;
+                };
+                while (p < pb) {
+                    one(rec, hq, recn, hqn);
+                    if (p < pb) one(recn, hqn, rec, hq);
+                    else {
+                        rec = recn;
+#pragma unroll
+                        for (int i = 0; i < NH; i++) hq[i] = hqn[i];
+                    }
+                }
+#else
+                while (p < pb) {
+                    const uint32_t pn = p + G < pb ? p + G : pb;
+                    const uint4 recn = list[pn + g < P ? pn + g : P - 1];
+                    uint4 hqn[NH];
+                    load_q(recn.y, hqn);
+                    const float s = dot_h(v[r], hq);
+                    stash(s, a2, rec.y, ((uint64_t)rec.w << 32) | rec.z, p + g < pb);
+                    rec = recn;
+#pragma unroll
+                    for (int i = 0; i < NH; i++) hq[i] = hqn[i];
+                    p = pn;
+                }
+#endif
+            }
+        }
+    } else {
+        // more pairs than the list holds (hot leaves): entry after entry, a leaf's visits G at a time, records from the group array
+        float4 v[NR];
+        float a2 = 0.f;
+        uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            unsigned long long m = __ballot(eC[j] != 0);
+            while (m) {
+                const int ll = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], ll);
+                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], ll);
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], ll);
+                const uint32_t rl = ((uint32_t)ll + 64u * j) / T;
+                if (rl != cur) {
+                    cur = rl;
+                    load_x(r0 + rl, v);
+                    a2 = row_sumsq(v);
+                }
+                for (uint32_t s0 = 0; s0 < c; s0 += G) {
+                    const uint32_t sidx = s0 + g < c ? s0 + g : c - 1;
+                    const ZhGroup *gp = groups + gb + sidx / GRP;
+                    const uint32_t b = gp->b[sidx % GRP];
+                    uint4 hq[NH];
+                    load_q(b, hq);
+                    const float s = dot_h(v, hq);
+                    stash(s, a2, b, gp->key_off[sidx % GRP] + w, s0 + g < c);
+                }
+            }
+        }
+    }
+    flush();
+}
+
+template <int D, int G>
+static hipError_t launch_scan_approx_d(const float *dX, uint64_t n_rows, const ZhApprox &ap, const uint2 *dRowLeaf, uint32_t T,
+                                       const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group,
+                                       int metric, int mode, hipStream_t s) {
+    const uint32_t RW = zh_scan_rows_per_wave(T);
+    uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
+    rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
+    const float Kc = zh_approx_bound(metric, D);
+    const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
+    for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
+        const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
+        const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define ZH_APX_LAUNCH(KA) \
+        hipLaunchKernelGGL((scan_approx_kernel<D, G, KA>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, (const uint4 *)ap.Qh, ap.qmeta, dRowLeaf, T, \
+                           RW, dVisitBits, dNodeVisit, dGroups, group, r, r_end, Kc, ap.iv)
+        if (kinda == 0) ZH_APX_LAUNCH(0);
+        else if (kinda == 1) ZH_APX_LAUNCH(1);
+        else ZH_APX_LAUNCH(2);
+#undef ZH_APX_LAUNCH
+    }
+    return hipGetLastError();
+}
+
+bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric) {
+    if (metric != ZH_L2 && metric != ZH_L2SQ && metric != ZH_COSINE) return false;
+    return zh_approx_groups(d) != 0 && zh_scan_rows_per_wave(T) != 0;
+}
+
+hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
+                                 const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
+                                 int mode, hipStream_t s) {
+    if (!n_rows) return hipSuccess;
+    switch (d) {
+    case 128: return launch_scan_approx_d<128, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 256: return launch_scan_approx_d<256, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 384: return launch_scan_approx_d<384, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 512: return launch_scan_approx_d<512, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 768: return launch_scan_approx_d<768, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 1024: return launch_scan_approx_d<1024, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- select on intervals: what a visit hands on ----
+// block-wide radix select: the `need`-th smallest (1-based) of the values VAL(i), i < n, 8 bits per round from the top
+#define ZH_APX_RADIX_SELECT(n, need_in, VAL, result)                                                        \
+    {                                                                                                       \
+        uint32_t prefix_ = 0, need_ = (need_in);                                                            \
+        for (int sh_ = 24; sh_ >= 0; sh_ -= 8) {                                                            \
+            __syncthreads();                                                                                \
+            hist[tid] = 0;                                                                                  \
+            __syncthreads();                                                                                \
+            const uint32_t himask_ = sh_ == 24 ? 0u : (0xFFFFFFFFu << (sh_ + 8));                           \
+            for (uint32_t i_ = tid; i_ < (n); i_ += 256) {                                                  \
+                const uint32_t x_ = (VAL(i_));                                                              \
+                if ((x_ & himask_) == prefix_) atomicAdd(&hist[(x_ >> sh_) & 255u], 1u);                    \
+            }                                                                                               \
+            __syncthreads();                                                                                \
+            if (tid < 64) { /* wave 0: the bucket that holds the need-th value */                           \
+                const uint32_t h0_ = hist[4 * tid], h1_ = hist[4 * tid + 1], h2_ = hist[4 * tid + 2], h3_ = hist[4 * tid + 3]; \
+                const uint32_t ss_ = h0_ + h1_ + h2_ + h3_;                                                 \
+                uint32_t inc_ = ss_;                                                                        \
+                for (int m_ = 1; m_ < 64; m_ <<= 1) {                                                       \
+                    const uint32_t t_ = __shfl_up(inc_, m_);                                                \
+                    if ((int)tid >= m_) inc_ += t_;                                                         \
+                }                                                                                           \
+                const uint32_t exc_ = inc_ - ss_;                                                           \
+                if (exc_ < need_ && need_ <= inc_) {                                                        \
+                    uint32_t c_ = exc_, j_ = 4 * tid;                                                       \
+                    if (need_ > c_ + h0_) { c_ += h0_; j_++;                                                \
+                        if (need_ > c_ + h1_) { c_ += h1_; j_++;                                            \
+                            if (need_ > c_ + h2_) { c_ += h2_; j_++; } } }                                  \
+                    s_u[6] = j_; s_u[7] = c_;                                                               \
+                }                                                                                           \
+            }                                                                                               \
+            __syncthreads();                                                                                \
+            prefix_ |= s_u[6] << sh_;                                                                       \
+            need_ -= s_u[7];                                                                                \
+        }                                                                                                   \
+        (result) = prefix_;                                                                                 \
+    }
+
+__global__ __launch_bounds__(256) void select_interval_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
+                                                               uint32_t k_top, const uint32_t *__restrict__ leaf_ids, ZhApprox ap) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_u[8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * chunk;
+    const uint32_t cnt = (uint32_t)(n_visits - base < chunk ? n_visits - base : chunk);
+    for (uint32_t c = 0; c < cnt; c++) {  // block-uniform
+        const ZhVisit v = visits[base + c];
+        if (!v.take) continue;
+        const uint64_t *__restrict__ kp = ap.iv + v.row_off;
+        uint32_t tau = 0xFFFFFFFFu;
+        if (v.take < v.len) {
+            if (v.take < k_top) {  // membership matters (see the header of this file): the exact path
+                if (tid == 0) {
+                    const uint32_t slot = atomicAdd(&ap.ctl[0], 1u);
+                    if (slot < ap.ex_cap) ap.ex_visits[slot] = (uint32_t)(base + c);
+                    else atomicOr(&ap.ctl[1], 4u);
+                }
+                continue;
+            }
+#define ZH_APX_HI(i) ((uint32_t)(kp[i] >> 32))
+            ZH_APX_RADIX_SELECT(v.len, v.take, ZH_APX_HI, tau);
+#undef ZH_APX_HI
+        }
+        __syncthreads();
+        if (tid == 0) { s_u[0] = 0; s_u[2] = 0; }
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < v.len; i += 256) mine += ((uint32_t)kp[i] <= tau) ? 1u : 0u;
+        if (mine) atomicAdd(&s_u[0], mine);
+        __syncthreads();
+        const uint32_t M = s_u[0];
+        if (tid == 0) {
+            const uint32_t b0 = atomicAdd(&ap.qcount[v.b], M);
+            s_u[1] = b0;
+            if (b0 + M > ap.capq) atomicOr(&ap.ctl[1], 1u);
+        }
+        __syncthreads();
+        const uint32_t b0 = s_u[1];
+        if (b0 + M <= ap.capq) {
+            const size_t ob = (size_t)v.b * ap.capq + b0;
+            for (uint32_t i = tid; i < v.len; i += 256) {
+                const uint64_t w = kp[i];
+                if ((uint32_t)w <= tau) {
+                    const uint32_t pos = atomicAdd(&s_u[2], 1u);
+                    ap.list_lo[ob + pos] = (uint32_t)w;
+                    ap.list_hi[ob + pos] = (uint32_t)(w >> 32);
+                    ap.list_id[ob + pos] = leaf_ids[(size_t)v.leaf_off + i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// a visit that hands over fewer than top_k rows: the leaf scored with the canonical sums, the `take` smallest (key, id) -- what
+// sweep + select do -- join the query's list with their intervals (their keys are computed again with the other survivors')
+template <int KIND>
+__global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restrict__ visits, const float *__restrict__ X, uint32_t d,
+                                                           const float *__restrict__ Q, const float *__restrict__ QQ,
+                                                           const uint32_t *__restrict__ leaf_ids, int metric, int param, ZhApprox ap) {
+    __shared__ uint64_t sk[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t si[2048];
+    __shared__ uint32_t s_u32[8];
+    __shared__ uint64_t s_red[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t total = ap.ctl[0] < ap.ex_cap ? ap.ctl[0] : ap.ex_cap;
+    if (ap.ctl[0] > ap.ex_cap) return;  // the table ran over (flagged by select_interval): the batch is redone
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {  // block-uniform
+        const ZhVisit v = visits[ap.ex_visits[e]];
+        __syncthreads();
+        if (tid == 0) s_u32[5] = atomicAdd(&ap.ctl[2], v.len);
+        __syncthreads();
+        const uint32_t eb = s_u32[5];
+        if ((uint64_t)eb + v.len > ap.ex_rows_cap) {
+            if (tid == 0) atomicOr(&ap.ctl[1], 8u);
+            continue;
+        }
+        for (uint32_t i = wv; i < v.len; i += 4) {
+            const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
+            float s0, s1;
+            lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)v.b * d, d, lane, param, s0, s1);
+            if (lane == 0) ap.ex_keys[(size_t)eb + i] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[v.b] : 0.f);
+        }
+        __syncthreads();
+        ZhVisit v2 = v;
+        v2.row_off = eb; v2.cand_off = eb;
+        bool need_slow = false;
+        select_fast<false>(v2, leaf_ids, ap.ex_keys, ap.ex_ckeys, ap.ex_cids, sk, si, s_u32, need_slow);
+        if (need_slow) {
+            __syncthreads();
+            select_slow(v2, leaf_ids, ap.ex_keys, ap.ex_ckeys, ap.ex_cids, sk, si, 2048);
+        }
+        __syncthreads();
+        // the largest (key, id) of the take chosen = the visit's threshold
+        uint64_t tk = 0, ti = 0;
+        for (uint32_t i = tid; i < v.take; i += 256) {
+            const uint64_t kk = ap.ex_ckeys[(size_t)eb + i], ii = ap.ex_cids[(size_t)eb + i];
+            if (kk > tk || (kk == tk && ii > ti)) { tk = kk; ti = ii; }
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint64_t ok = __shfl_xor(tk, m), oi = __shfl_xor(ti, m);
+            if (ok > tk || (ok == tk && oi > ti)) { tk = ok; ti = oi; }
+        }
+        if (lane == 0) { s_red[wv] = tk; s_red[4 + wv] = ti; }
+        __syncthreads();
+        tk = s_red[0]; ti = s_red[4];
+        for (int w = 1; w < 4; w++)
+            if (s_red[w] > tk || (s_red[w] == tk && s_red[4 + w] > ti)) { tk = s_red[w]; ti = s_red[4 + w]; }
+        if (tid == 0) {
+            const uint32_t b0 = atomicAdd(&ap.qcount[v.b], v.take);
+            s_u32[6] = b0; s_u32[7] = 0;
+            if (b0 + v.take > ap.capq) atomicOr(&ap.ctl[1], 1u);
+        }
+        __syncthreads();
+        const uint32_t b0 = s_u32[6];
+        if (b0 + v.take <= ap.capq) {
+            const size_t ob = (size_t)v.b * ap.capq + b0;
+            for (uint32_t i = tid; i < v.len; i += 256) {
+                const uint64_t kk = ap.ex_keys[(size_t)eb + i];
+                const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
+                if (kk < tk || (kk == tk && id <= ti)) {
+                    const uint32_t pos = atomicAdd(&s_u32[7], 1u);
+                    const uint64_t w = ap.iv[v.row_off + i];
+                    if (pos < v.take) {
+                        ap.list_lo[ob + pos] = (uint32_t)w;
+                        ap.list_hi[ob + pos] = (uint32_t)(w >> 32);
+                        ap.list_id[ob + pos] = id;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- per query: duplicates out, tau, the survivors' canonical keys, top_k (lsh.rs:557-564) ----
+#define ZH_APX_LCAP 4096  // entries of a query's list the sort holds
+#define ZH_APX_SCAP 512   // survivors per query
+template <int KIND>
+__global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_t k, const float *__restrict__ X, uint32_t d,
+                                                              const float *__restrict__ Q, const float *__restrict__ QQ, int metric,
+                                                              int param, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
+                                                              uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
+    __shared__ uint64_t sk[ZH_APX_LCAP];  // id << 32 | sortable hi: equal ids end up side by side
+    __shared__ uint32_t sl[ZH_APX_LCAP];  // sortable lo
+    __shared__ uint64_t vk[ZH_APX_SCAP], vi[ZH_APX_SCAP];
+    __shared__ uint32_t hist[256], scan[256], s_u[8];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // something ran over in select_interval / exact_visit (complete by now: same stream): a list whose count ran past its
+    // capacity has slots nobody wrote -- nothing here may be dereferenced, and the f32 scan behind redoes the batch anyway
+    if (ap.ctl[1] & (1u | 4u | 8u)) return;
+    uint32_t n = ap.qcount[b];
+    if (n > ap.capq) n = ap.capq;  // (flagged by whoever appended past the end)
+    if (n > ZH_APX_LCAP) n = ZH_APX_LCAP;  // capq <= ZH_APX_LCAP
+    const size_t ob = (size_t)b * ap.capq;
+    for (uint32_t i = tid; i < n; i += 256) {
+        sk[i] = ((uint64_t)ap.list_id[ob + i] << 32) | ap.list_hi[ob + i];
+        sl[i] = ap.list_lo[ob + i];
+    }
+    const uint32_t np2 = next_pow2(n);
+    for (uint32_t i = n + tid; i < np2; i += 256) { sk[i] = ~0ull; sl[i] = ~0u; }
+    block_bitonic_sort<uint32_t>(sk, sl, np2);
+    // first entry of every id (the smallest hi of its copies -- the copies are identical in fact: same row registers, same
+    // group arithmetic -- ), compacted to the front
+    constexpr uint32_t PER = ZH_APX_LCAP / 256;
+    uint64_t ek[PER];
+    uint32_t el[PER], cntl = 0;
+    bool keep[PER];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t i = tid * PER + j;
+        keep[j] = i < n && (i == 0 || (uint32_t)(sk[i] >> 32) != (uint32_t)(sk[i - 1] >> 32));
+        ek[j] = i < n ? sk[i] : 0ull;
+        el[j] = i < n ? sl[i] : 0u;
+        cntl += keep[j] ? 1u : 0u;
+    }
+    scan[tid] = cntl;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t a = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += a;
+        __syncthreads();
+    }
+    uint32_t rank = scan[tid] - cntl;
+    const uint32_t nu = scan[255];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++)
+        if (keep[j]) { sk[rank] = ek[j]; sl[rank] = el[j]; rank++; }
+    __syncthreads();
+    // tau = the k-th smallest hi among the distinct rows; fewer than k: everything stays
+    uint32_t tau = 0xFFFFFFFFu;
+    if (nu > k && k > 0) {
+#define ZH_APX_HI(i) ((uint32_t)sk[i])
+        ZH_APX_RADIX_SELECT(nu, k, ZH_APX_HI, tau);
+#undef ZH_APX_HI
+    }
+    __syncthreads();
+    if (tid == 0) s_u[0] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nu; i += 256)
+        if (sl[i] <= tau) {
+            const uint32_t pos = atomicAdd(&s_u[0], 1u);
+            if (pos < ZH_APX_SCAP) vi[pos] = sk[i] >> 32;
+        }
+    __syncthreads();
+    uint32_t ns = s_u[0];
+    if (ns > ZH_APX_SCAP) {
+        if (tid == 0) atomicOr(&ap.ctl[1], 2u);
+        ns = ZH_APX_SCAP;
+    }
+    // the survivors' keys, the reference's arithmetic (canonical sums)
+    for (uint32_t i = wv; i < ns; i += 4) {
+        const uint32_t id = (uint32_t)vi[i];
+        float s0, s1;
+        lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)b * d, d, lane, param, s0, s1);
+        if (lane == 0) vk[i] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
+    }
+    const uint32_t sp2 = next_pow2(ns);
+    __syncthreads();
+    for (uint32_t i = ns + tid; i < sp2; i += 256) { vk[i] = ~0ull; vi[i] = ~0ull; }
+    block_bitonic_sort<uint64_t>(vk, vi, sp2);
+    const uint32_t have = ns < k ? ns : k;
+    for (uint32_t i = tid; i < k; i += 256) {
+        out_ids[(size_t)b * k + i] = i < have ? id_base + vi[i] : ~0ull;
+        out_keys[(size_t)b * k + i] = i < have ? vk[i] : ~0ull;
+    }
+    if (tid == 0) {
+        out_counts[b] = have;
+        atomicAdd(&ap.ctl[3], ns);
+        atomicAdd(&ap.ctl[4], n);
+    }
+}
+
+hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, const uint32_t *dLeafIds, ZhApprox ap,
+                                     hipStream_t s) {
+    if (!n_visits) return hipSuccess;
+    if (n_visits > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    uint64_t chunk = (n_visits + 16383) / 16384;
+    if (chunk > 256) chunk = 256;
+    const uint64_t blocks = (n_visits + chunk - 1) / chunk;
+    hipLaunchKernelGGL(select_interval_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, dLeafIds, ap);
+    return hipGetLastError();
+}
+
+hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
+                                    uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (metric == ZH_COSINE) {
+        hipLaunchKernelGGL(exact_visit_kernel<K_COS>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
+        hipLaunchKernelGGL(final_interval_kernel<K_COS>, dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds,
+                           dOutKeys, dOutCounts);
+    } else {
+        hipLaunchKernelGGL(exact_visit_kernel<K_L2>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
+        hipLaunchKernelGGL(final_interval_kernel<K_L2>, dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds,
+                           dOutKeys, dOutCounts);
+    }
+    return hipGetLastError();
+}

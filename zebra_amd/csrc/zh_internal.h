@@ -179,6 +179,7 @@ hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupR
 // ---- the table-scan sweep (zh_search.hip): the stored rows streamed once, each scored against every query that visits
 // one of its leaves.  rowLeaf is n_rows x T {leaf node, position in the leaf}, built per forest by zh_launch_row_leaf from
 // node_pack, a node -> tree map (UINT32_MAX for nodes no root reaches) and leaf_ids.
+#define ZH_SCAN_NE 4     // (row, tree) entries per lane of a table-scan wave: RW * T <= 64 * ZH_SCAN_NE
 bool zh_scan_sweep_supported(uint32_t d, uint32_t T, int metric);
 uint32_t zh_scan_rows_per_wave(uint32_t T);
 hipError_t zh_launch_row_leaf(const int4 *dNodePack, const uint32_t *dNodeTree, uint32_t n_nodes, const uint32_t *dLeafIds,
@@ -189,16 +190,17 @@ hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGr
                                  uint32_t *dBits, uint4 *dNodeVisit, hipStream_t s);
 hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, const float *dQ, const float *dQQ,
                                 const uint2 *dRowLeaf, uint32_t T, const uint32_t *dVisitBits, const uint4 *dNodeVisit,
-                                const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys, hipStream_t s);
+                                const ZhGroup *dGroups, uint32_t group, int metric, int param, uint64_t *dKeys,
+                                const uint32_t *dRunIf /* null, or: run only when this device word is nonzero */, hipStream_t s);
 // flat rows covered by one sweep launch (a batch is issued as ceil(R / this) launches)
 uint64_t zh_sweep_rows_per_launch(uint32_t d);
 // max_leaf_len: the longest leaf of the forest (picks the LDS footprint of the select blocks)
 hipError_t zh_launch_select(const ZhVisit *dVisits, uint64_t n_visits, const uint32_t *dLeafIds,
                             const uint64_t *dKeys, uint64_t *dCandKeys, uint32_t *dCandIds, uint32_t max_leaf_len,
-                            hipStream_t s);
+                            const uint32_t *dRunIf, hipStream_t s);
 hipError_t zh_launch_final(const uint64_t *dCandBase, uint32_t B, uint32_t T, uint32_t k, const uint64_t *dCandKeys,
                            const uint32_t *dCandIds, uint64_t id_base, uint64_t *dOutIds, uint64_t *dOutKeys,
-                           uint32_t *dOutCounts, hipStream_t s);
+                           uint32_t *dOutCounts, const uint32_t *dRunIf, hipStream_t s);
 // stride64 / stride32: distance between consecutive shards' ids (= keys) in u64 units and counts in u32 units
 // (0 = contiguous [S][B][k] / [S][B])
 hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *dIds, const uint64_t *dKeys,
@@ -208,6 +210,39 @@ hipError_t zh_launch_merge(uint32_t S, uint32_t B, uint32_t k, const uint64_t *d
 #define ZH_DISTANCE_SCRATCH_BYTES (sizeof(ZhGroup) + 16)
 hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, const float *dq, int metric, int mode,
                                    uint64_t *dKeys, void *dScratch, hipStream_t s);
+
+// ---- the table scan with half-width queries (zh_approx.inl): intervals instead of keys, exact keys for the few rows they cannot
+// decide.  ctl[0] = visits sent to the exact path, ctl[1] = overflow bits (1 a query's candidate list, 2 a query's survivors,
+// 4 the table of exact visits, 8 the exact visits' key scratch) -- nonzero: the exact scan + select + final enqueued behind
+// redo the batch (their predicate), ctl[2] = key scratch handed out, ctl[3] = survivors scored exactly, ctl[4] = list entries.
+#define ZH_APX_CTL_WORDS 8
+struct ZhApprox {
+    const void *Qh;          // the fp16 copy of the batch's queries (2 * d bytes each, qhalf_kernel's layout)
+    const float4 *qmeta;     // per query {1 / sigma, |q|^2, upper estimate of |q|, upper estimate of |q - h / sigma|}
+    uint64_t *iv;            // per (row, query) pair, in the pair's key slot: sortable lo | sortable hi << 32
+    uint32_t *list_lo, *list_hi, *list_id;  // per query: capq slots
+    uint32_t *qcount;
+    uint32_t capq;
+    uint32_t *ex_visits;     // indices of the visits for the exact path
+    uint32_t ex_cap;
+    uint64_t *ex_keys, *ex_ckeys;  // their rows' canonical keys; the `take` chosen
+    uint32_t *ex_cids;
+    uint32_t ex_rows_cap;
+    uint32_t *ctl;
+};
+uint32_t zh_approx_groups(uint32_t d);
+float zh_approx_bound(int metric, uint32_t d);
+bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s);
+hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
+                                 const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
+                                 int mode, hipStream_t s);
+hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, const uint32_t *dLeafIds, ZhApprox ap,
+                                     hipStream_t s);
+// the exact visits, then per query: duplicates out, tau, the survivors' canonical keys, top_k
+hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
+                                    uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s);
 
 // ---- launchers (zh_score.hip): every sign of a forest built from stored rows, from N row scores per query --------
 // Prefilter (zh_search.hip, "Prefilter"): a batch hashed from row scores picks the rows that can be among a pair's k best from
