@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the LSH bucket-scan + distance hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N >= 1: for N > 1 this process starts the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (the same ranks, started by torchrun)
 
 One "step" = one batch of B synthetic queries through the library: hash -> walk -> sweep -> select -> final, plus,
 for N > 1, the RCCL all-gather of every rank's packed top-k and the merge kernel (zh_shard_search_*: the exchange is
@@ -49,6 +49,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GATHER_CEILING_GBS = [6410.0, 6560.0]  # random 512-byte .. 3-KiB rows gathered from HBM into registers, two boxes (profiles/micro/r03_gather512.csv)
 L2_GATHER_PEAK_GBS = 18800.0
 L2_GATHER_RANGE_GBS = [16800.0, 18800.0]
+# what the bare gather of the scan's access shape reaches from an L2-sized table on this chip with nothing else going on
+# (profiles/micro/gather512.hip, r03_gather512.csv: 6-MB table 22.7 TB/s, 3-MB table 31.3 TB/s): the MEASURED ceiling, above the guide's figure
+L2_GATHER_MEASURED_GBS = [22700.0, 31300.0]
 SEED_ROWS, SEED_Q, SEED_INDEX = 0x5EB2A001, 0x5EB2A002, 0x5EB2A003
 
 WORKLOADS = {
@@ -81,6 +84,45 @@ OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg2", "cfg2", 1, 4
                  ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6)]
 
 
+def rank_env(base, rank, world, port):
+    """environment of rank `rank` of a `world`-rank run on this node (what torch.distributed.run would set)"""
+    e = dict(base)
+    e.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+              "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL across processes)
+    return e
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU; this parent never touches
+    a GPU and never execs), relay rank 0's JSON line, return the worst exit code.  Fewer than N devices: an error line, rc 3."""
+    import socket
+    import subprocess
+    import torch  # (device_count does not initialise the GPU)
+    found = torch.cuda.device_count()
+    if found < n:
+        print(json.dumps({"error": "needs %d devices, found %d" % (n, found), "n_gpus": n}))
+        return 3
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=rank_env(os.environ, r, n, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        if not any(l.startswith("{") for l in out.splitlines()):
+            print(json.dumps({"error": "ranks failed: %s" % bad, "n_gpus": n}))
+    return max((abs(rc) for rc in rcs), default=0)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +133,7 @@ def parse():
     ap.add_argument("--max-node-size", type=int, default=None, help="override max_node_size (debug)")
     ap.add_argument("--batch", type=int, default=None, help="override the query batch (debug)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH CPU baseline leg (0 = skip)")
-    ap.add_argument("--recall-queries", type=int, default=64)
+    ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: only the bench line's own workload")
     ap.add_argument("--only-other", default=None, help="debug: comma list of other_configs keys to run")
@@ -159,8 +201,8 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus and self.world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
+        if self.world != args.gpus:
+            print(json.dumps({"error": "--gpus %d but WORLD_SIZE is %d" % (args.gpus, self.world), "n_gpus": args.gpus}))
             sys.exit(2)
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
@@ -267,11 +309,23 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             rs = sl["res"][:sl["nw"]]
             sl["ctx"].finish_window([r["ids"].data_ptr() for r in rs], [r["keys"].data_ptr() for r in rs],
                                     [r["counts"].data_ptr() for r in rs], heavy)
-            for r in rs:
+            sl["held"] = True
+
+        def retire(sl):
+            """zh_search_wait FIRST, then the D2H copies: the header says a batch's outputs are complete only when wait has returned
+            (a prefiltered batch whose lists ran over is redone from the host inside it) -- copies queued right behind finish could
+            carry the discarded results to the host.  Called when the slot is needed again (two windows later) and at the end."""
+            if not sl.get("held"):
+                return
+            sl["ctx"].wait()
+            for r in sl["res"][:sl["nw"]]:
                 to_host(r, sl["stream"])
+            sl["held"] = False
+            if "t_begin" in sl:
+                _mark_end(sl)
 
         def drain(sl):
-            sl["ctx"].wait()
+            retire(sl)
             sl["stream"].synchronize()
 
         def blocking(i):
@@ -290,6 +344,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         def begin(sl, i, nw):
             sl["nw"] = nw
             sl["ctx"].begin_window([queries[i + j].data_ptr() for j in range(nw)], B, k, metric)
+
+        def retire(sl):
+            pass  # (the sharded contexts never take a path that is redone from the host: results are final in stream order)
 
         def finish(sl):
             rs = sl["res"][:sl["nw"]]
@@ -322,7 +379,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         if "ev_b" not in sl:
             sl["ev_b"], sl["ev_e"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sl["ev_b"].record(sl["stream"])
-        sl["t_begin"] = True
+        sl["t_begin"] = True  # (the end event goes behind the D2H copies, in retire)
 
     def _mark_end(sl):
         sl["ev_e"].record(sl["stream"])
@@ -357,14 +414,15 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         elif not look["ahead"]:  # begin + finish of a window back to back, NS windows in flight
             for w in range(len(wins)):
                 sl = slots[w % NS]
+                retire(sl)  # the window this slot held (two windows ago: long done): wait, then its results to the host
                 if lat is not None:
-                    if "t_begin" in sl:  # the window this slot held before (two windows ago) is done by now
+                    if "t_begin" in sl:
                         lat.append(_window_latency(sl))
                     _mark_begin(sl)
+                elif "t_begin" in sl:
+                    del sl["t_begin"]
                 begin(sl, *wins[w])
                 finish(sl)
-                if lat is not None:
-                    _mark_end(sl)
             if lat is not None:
                 for sl in slots[:NS]:
                     drain(sl)
@@ -373,9 +431,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                         del sl["t_begin"]
         else:                  # LA more slots: LA windows begun ahead, one being finished, NS - 1 sweeping
             for w in range(min(LA, len(wins))):
+                retire(slots[w % (NS + LA)])
                 begin(slots[w % (NS + LA)], *wins[w])
             for w in range(len(wins)):
                 if w + LA < len(wins):
+                    retire(slots[(w + LA) % (NS + LA)])
                     begin(slots[(w + LA) % (NS + LA)], *wins[w + LA])
                 finish(slots[w % (NS + LA)])
         for sl in slots:
@@ -451,8 +511,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     bytes_alg = 4.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
     bytes_nosharing = (4.0 * d + 12.0) * rows_per_launch
     scan = st["scan_batches_accum"] > 0
+    half = st.get("approx_batches_accum", 0) > 0  # the scan read fp16 copies of the queries (zh_approx.hip)
     kind = 1 if wl["metric"] == "cosine" else 0
     kname = ("scan_sweep_kernel<%d, %d>" if scan else "sweep_kernel<%d, %d, ...>") % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
+    if half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
+        kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
     s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
               "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
@@ -497,8 +560,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # comparable with the leaf-major sweep and round 1, which exceeds the HBM peak because one HBM read of a row serves every
         # tree that wants it: those bytes are not bytes this kernel moves.
         stored = st["swept_rows_accum"] / n_launch
-        l2_bytes = 4.0 * d * (rows_per_launch + stored)
-        by_design = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + 4.0 * d * B / launches_per_batch
+        qb = 2.0 * d if half else 4.0 * d  # bytes of one query as the scan reads it: fp16 copy (round 4) or f32
+        l2_bytes = qb * rows_per_launch + 4.0 * d * stored
+        by_design = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + qb * B / launches_per_batch
         l2_GBps = l2_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
         roof = {"bound": "l2", "achieved": l2_GBps, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_GBps / L2_GATHER_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": l2_bytes,
@@ -508,11 +572,19 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                 "hbm_bytes_by_design_per_launch": by_design,
                 "hbm_frac": by_design / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms else 0.0,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
+                "measured_l2_gather_ceiling_GBps": L2_GATHER_MEASURED_GBS,
+                "frac_of_measured_l2_gather": [l2_GBps / L2_GATHER_MEASURED_GBS[0], l2_GBps / L2_GATHER_MEASURED_GBS[1]],
+                "measured_l2_gather_note": "the bare register gather of the same shape from a 6-MB / 3-MB table with nothing else running "
+                                           "(profiles/micro/gather512.hip): the measured ceiling, above the guide's 16.8-18.8 TB/s quoted as `peak`",
+                "query_bytes_per_pair": qb,
                 "s8d_equivalent_GBps": s8d_GBps, "s8d_bytes_per_launch": bytes_alg,
                 "s8d_note": "SURVEY s8(d) numerator / launch time: comparable with the leaf-major sweep, NOT a roofline fraction (a stored row "
                             "is read once for every tree that wants it)",
-                "sweep_mode": "table scan: stored rows streamed once per batch window, each scored against every query that visits one of "
-                              "its leaves (queries from L2)"}
+                "sweep_mode": ("table scan with HALF-WIDTH queries: stored rows (f32) streamed once per batch window, each scored against the fp16 "
+                               "copy of every query that visits one of its leaves (2*d bytes per pair from L2) -> an interval per pair; the intervals "
+                               "pick the candidates and only the survivors get the reference's key (zh_approx.hip)") if half else
+                              ("table scan: stored rows streamed once per batch window, each scored against every query that visits one of "
+                               "its leaves (queries from L2)")}
         roof.update(common)
 
     out = {
@@ -529,6 +601,12 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         "window_batches": WIN,
         "setup_s": {"fill": t_fill, "build": t_build},
     }
+    if st.get("approx_batches_accum"):
+        # the table scan read half-width (fp16) copies of the queries; what the intervals left for the exact passes (last internal batch)
+        out["half_width_scan"] = {"batches": st["approx_batches_accum"], "redone_by_the_f32_scan": st["approx_fallbacks_accum"],
+                                  "last_overflow_bits": st["approx_last_overflow"], "list_entries_per_query": st["approx_list_entries"] / max(st["batch"], 1),
+                                  "survivors_scored_exactly_per_query": st["approx_survivors"] / max(st["batch"], 1),
+                                  "visits_ranked_exactly": st["approx_exact_visits"]}
     if lat_store["ms"]:
         ls = sorted(lat_store["ms"])
         out["latency_ms"] = {"p50_window_submit_to_host": ls[len(ls) // 2], "max_window_submit_to_host": ls[-1], "windows": len(ls),
@@ -583,18 +661,23 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         else:
             true_ids = true_local
 
-        def rec(g):
-            gt, tt = g.cpu().numpy(), true_ids.cpu().numpy()
-            return sum(len(set(gt[b].tolist()) & set(tt[b].tolist())) for b in range(nq)) / (nq * k)
-
         # the planted neighbour (query = stored row + 0.3 * noise): is it among the returned ids?
         pl = np.array([_planted_row(SEED_Q, (n_batches - 1) * B + b, n_total) for b in range(nq)], dtype=np.int64)
         here = (pl >= first_row) & (pl < first_row + rows_local) if group is None or group.ranks() < S else np.ones(nq, bool)
+
+        def rec(g):
+            # one shard of S: only the queries planted next to one of THIS shard's rows have their neighbourhood here (for the others
+            # this shard's true top-k are random far rows, which no index finds): recall over those queries
+            gt, tt = g.cpu().numpy(), true_ids.cpu().numpy()
+            idx = [b for b in range(nq) if here[b]]
+            return sum(len(set(gt[b].tolist()) & set(tt[b].tolist())) for b in idx) / (len(idx) * k) if idx else None
+
         out["planted_neighbour_hit_rate"] = float((got.cpu().numpy()[here] == pl[here, None]).any(1).mean()) if here.any() else None
         out[f"recall_at_{k}"] = rec(got)
         out[f"recall_at_{k}_reference_key"] = rec(got_parity) if got_parity is not None else out[f"recall_at_{k}"]
         if S > 1 and (group is None or group.ranks() < S):
-            out["recall_note"] = "one shard of %d: recall is against this shard's rows only" % S
+            out["recall_note"] = ("one shard of %d: recall is against this shard's rows only, over the %d of %d sampled queries whose planted "
+                                  "neighbour lives in this shard" % (S, int(here.sum()), nq))
 
     # sanity of the last timed batch as it arrived on the host
     assert (last_host[1] <= k).all() and (last_host[1] > 0).all(), "empty results in the last timed batch"
@@ -731,6 +814,8 @@ def pmc_traffic(args, name, S, roof):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: be one
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     env = Env(args)
     torch = env.torch
     emu = args.emulate_ranks if env.world == 1 else 0
@@ -757,19 +842,46 @@ def main():
         for key, wname, shards, steps, *win in OTHER_CONFIGS:
             if only and key not in only:
                 continue
-            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=False, window_override=win[0] if win else None)
+            is_cos = WORKLOADS[wname]["metric"] == "cosine" and not args.no_recall
+            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=is_cos, window_override=win[0] if win else None)
             ix2.close()
             del ix2
             torch.cuda.empty_cache()
+            rec10 = None
+            if is_cos:
+                # BASELINE.json's metric is "queries/sec + recall@10" on the 768-d cosine top-10 shape: recall against GPU brute force under
+                # BOTH keys -- the corrected one (cosine distance) and the reference's literal one (distance.rs:23-25 sorts by similarity:
+                # ~0 by construction) -- on the bench's iid rows (where only the planted neighbour can be found) and on
+                # clustered rows (128 consecutive rows share a centre: informative), same shape, same index options
+                kq = WORKLOADS[wname]["k"]
+                rcl, ix3, _, _, _ = run_workload(env, wname, shards, 0, 2, 1, exchange=False, recall=True, kind_override=2,
+                                                 window_override=win[0] if win else None)
+                ix3.close()
+                del ix3
+                torch.cuda.empty_cache()
+                rec10 = {"top_k": kq,
+                         "iid_rows": {"corrected_key": r.get(f"recall_at_{kq}"), "reference_key": r.get(f"recall_at_{kq}_reference_key"),
+                                      "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")},
+                         "clustered_rows": {"corrected_key": rcl.get(f"recall_at_{kq}"), "reference_key": rcl.get(f"recall_at_{kq}_reference_key"),
+                                            "planted_neighbour_hit_rate": rcl.get("planted_neighbour_hit_rate"),
+                                            "queries_per_s_this_gpu": rcl["qps"]},
+                         "against": "GPU brute force over this GPU's stored rows" + ((" (one shard of %d: over the sampled queries planted in this "
+                                                                                       "shard -- %s)" % (shards, rcl.get("recall_note"))) if shards > 1 else ""),
+                         "note": "iid rows in 768-d: every non-planted neighbour is a random row, recall@k ~ rows scanned / rows for ANY index; "
+                                 "the literal key returns the LEAST similar candidates, so its recall is ~0 by construction"}
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",
                                                                "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
                                                                "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling",
+                                                               "measured_l2_gather_ceiling_GBps", "frac_of_measured_l2_gather", "query_bytes_per_pair",
                                                                "visits_per_launch", "sector_GBps", "exact_rows_per_launch", "exact_visits_per_launch", "prefilter_fallbacks", "note")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
-                          "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms")}
+                          "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms"),
+                          "half_width_scan": r.get("half_width_scan")}
+            if rec10:
+                other[key]["recall_at_10"] = rec10
         if not only or "recall_clustered" in only:
             # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative
             r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=2)
@@ -788,6 +900,7 @@ def main():
             "timed_span": "queries resident in HBM -> merged top-k in pinned host memory (D2H inside the span)",
             "config": res["config"],
             "latency_ms": res.get("latency_ms"),
+            "half_width_scan": res.get("half_width_scan"),
             "recall": None,  # filled below
             f"recall_at_{k}": res.get(f"recall_at_{k}"), f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
             "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
@@ -823,8 +936,15 @@ def main():
                                        "the planted neighbour is what an index can find"},
             "cosine_key_note": ("this workload's metric is cosine with the reference's LITERAL key (distance.rs:23-25 sorts by similarity, SURVEY F4): "
                                 f"recall_at_{k}_reference_key is ~0 by construction; recall_at_{k} is measured with the corrected key, same cost")
-            if cos_literal else None,
+            if cos_literal else ("the bench line's own workload is L2; the metric's cosine top-10 shape is measured under both keys in "
+                                 "other_configs.cfg4_one_of_8_shards.recall_at_10 and other_configs.scale64m_n1.recall_at_10 (corrected key: cosine "
+                                 "distance; reference key: distance.rs:23-25 sorts by SIMILARITY, recall ~0 by construction, SURVEY F4)"),
         }
+        if S > 1 or emu:
+            out["recall"]["at_this_point"] = {"max_node_size_per_shard": M_shard, f"recall_at_{k}": res.get(f"recall_at_{k}"),
+                                              f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
+                                              "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"), "data": args.data,
+                                              "note": res.get("recall_note")}
     # RCCL writes a version banner through C stdio: every rank flushes it before the last barrier, so that rank 0's JSON
     # line is the LAST line of the job's stdout
     sys.stdout.flush()

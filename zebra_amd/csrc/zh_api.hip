@@ -61,11 +61,19 @@ struct DevBuf {
     // meanwhile (rocprofv3 kernel trace, r03: a 1.3-2.9 ms hole in front of the next window's sweep each time).  Buffers of a
     // search context therefore keep the outgrown allocation (geometric growth: at most twice the final size in total) until
     // the context is released, and ask for 1/8 more than a batch needs so that batch-to-batch variation rarely grows them at all.
+    // ... but not without bound: a score table grows to 12 GB per context, and three generations of it would be held until the
+    // context is destroyed.  Past 2 GiB of outgrown allocations they are freed on the spot (one drain, rare).
     bool defer = false;
     std::vector<void *> old;
+    size_t old_bytes = 0;
     int ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
         if (bytes <= cap) return ZH_OK;
         if (defer) bytes += bytes / 8;
+        if (defer && old_bytes + cap > (size_t(2) << 30)) {
+            for (void *o : old) hipFree(o);
+            old.clear();
+            old_bytes = 0;
+        }
         size_t ncap = std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~size_t(255);
         void *np = nullptr;
@@ -80,7 +88,7 @@ struct DevBuf {
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) { hipFree(np); return fail(ZH_EHIP, "grow copy: %s", hipGetErrorString(e)); }
         }
-        if (p) { if (defer) old.push_back(p); else hipFree(p); }
+        if (p) { if (defer) { old.push_back(p); old_bytes += cap; } else hipFree(p); }
         p = np;
         cap = ncap;
         return ZH_OK;
@@ -89,6 +97,7 @@ struct DevBuf {
         if (p) hipFree(p);
         for (void *o : old) hipFree(o);
         old.clear();
+        old_bytes = 0;
         p = nullptr;
         cap = 0;
     }
@@ -202,7 +211,10 @@ struct zh_index {
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
     int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies
-    std::atomic<uint32_t> approx_strikes{0};  // batches in a row whose half-width scan ran over and was redone exactly: after three the exact scan until the trees change
+    // a batch whose half-width scan ran over was redone by the f32 scan: both scans paid.  Data whose keys are dense around the cut (the
+    // parity cosine key on iid rows in 20k-row leaves: thousands of rows per query inside the bound) would do so batch after batch:
+    // after the first such batch -- or one whose lists came close -- the index keeps the f32 scan until its trees change
+    std::atomic<uint32_t> approx_strikes{0};
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
@@ -333,7 +345,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
-    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0;
+    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     ix->plane_samples.release(); ix->samples_valid = false;
     ix->plane_hab.release(); ix->hab_planes = 0; ix->hab_rows = 0; ix->hab_gen = 0;
@@ -486,7 +498,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
-    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0;
+    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0;
     ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->batches_since_change = 0;
     ix->max_leaf_len = 0;
@@ -1303,10 +1315,20 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
     if (off || mode == 2 || mode == 1) return false;
     if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0) return false;
     if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
-    if (mode != 4 && ix->approx_strikes.load() >= 3) return false;
+    // by itself only where it pays: its per-pair cost is half the f32 scan's, its per-row cost higher (cfg3: 0.057 against 0.118 ns per
+    // pair, 0.74 against 0.52 ns per stored row, + the interval stages): from ~5 pairs per stored row on
+    if (mode != 4 && (ix->approx_strikes.load() >= 1 || !zh_approx_pays(ix->opt.dim) || tot.rows < 5 * ix->n_rows)) return false;
     return true;
 }
 
+static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense);
+// estimated time of the row-score hash of a batch: the score GEMM (or its row-streaming bound), the gather of two score rows per
+// plane (>= one 64-byte sector each), the exact fix-ups
+static double score_hash_seconds(const zh_index *ix, size_t B) {
+    const size_t Bp = (B + 3) & ~(size_t)3;
+    const double d = ix->opt.dim, P = ix->n_planes, N = ix->n_rows;
+    return std::max(2.0 * Bp * N * d / 9e13, N * d * 4.0 / 5e12) + P * 2.0 * std::max(64.0, Bp * 4.0) / 4e12 + 0.003 * B * P * 0.55e-9 + 30e-6;
+}
 // number of leading planes hashed densely (MFMA kernel, before the walk) for a batch of B queries asking for k neighbours
 static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     const auto &below = ix->planes_below_level;
@@ -1334,11 +1356,11 @@ static uint32_t choose_dense_planes(zh_index *ix, size_t B, size_t k) {
     // the dense kernel: MFMA-bound for real batches, a plane-streaming GEMV (HBM-bound) for a handful of queries
     const double t_dense = std::max((double)ix->n_planes * per_plane / 9e13, (double)ix->n_planes * d * 4.0 / 5e12);
     const double bits_bytes = (double)ix->n_planes * (double)B / 8.0;
-    // ... or every sign from the row scores (zh_score.hip) where the forest allows: B * rows dot products + a gather per plane
+    // ... or every sign from the row scores (zh_score.hip) -- counted only where use_score_hash would in fact take that path for an
+    // all-dense batch (same mode switch, same ZH_HASH_MODE, same limits, same threshold: ONE decision), so that "all-dense because the
+    // scores are cheap" is never followed by the per-plane dense hash
     double t_all = t_dense;
-    if (ix->samples_valid && ix->hash_mode != 1 && (double)ix->n_rows * (double)((B + 3) & ~(size_t)3) * 4.0 <= (double)(12ull << 30))
-        t_all = std::min(t_all, std::max(2.0 * (double)B * (double)ix->n_rows * d / 9e13, (double)ix->n_rows * d * 4.0 / 5e12) +
-                                    (double)ix->n_planes * 2.0 * std::max(64.0, (double)B * 4.0) / 4e12);
+    if (use_score_hash(ix, B, ix->n_planes)) t_all = std::min(t_all, score_hash_seconds(ix, B));
     if (t_all < t_chain && bits_bytes < 2e9) return ix->n_planes;  // (every context in flight holds its own sign bits)
     return top;
 }
@@ -1354,11 +1376,9 @@ static bool use_score_hash(const zh_index *ix, size_t B, uint32_t P_dense) {
     if (mode == 2) return true;
     // per-plane hash: MFMA-bound for real batches, a plane-streaming GEMV for a handful of queries; row scores: the same two
     // bounds over the ROWS, + the gather of two score rows per plane (>= one 64-byte sector each) + the exact fix-ups
-    const double d = ix->opt.dim, P = ix->n_planes, N = ix->n_rows;
+    const double d = ix->opt.dim, P = ix->n_planes;
     const double t_dense = std::max(2.0 * B * P * d / 9e13, P * d * 4.0 / 5e12);
-    const double t_score = std::max(2.0 * Bp * N * d / 9e13, N * d * 4.0 / 5e12) + P * 2.0 * std::max(64.0, Bp * 4.0) / 4e12 +
-                           0.003 * B * P * 0.55e-9 + 30e-6;
-    return t_score < 0.7 * t_dense;
+    return score_hash_seconds(ix, B) < 0.7 * t_dense;
 }
 
 static int launch_score_hash(zh_search_ctx *c, const float *dQ, size_t B, bool lazy, hipStream_t s) {
@@ -1427,7 +1447,9 @@ int ctx_wait(zh_search_ctx *c);
 // determine, leaves short enough for the per-lane selection, and forests this library built (a row is in one leaf per tree).
 static bool use_prefilter(const zh_index *ix, const zh_search_ctx *c, size_t k, int metric) {
     static const bool off = getenv("ZH_NO_PREFILTER") != nullptr;  // A/B: sweep + select for every batch
-    if (off || !c->score_hash || c->prefilter_off_once || c->stream_ordered || (ix->prefilter_strikes.load() >= 2 && ix->sweep_mode != 3)) return false;
+    // (mode 3 keeps trying past two strikes -- a caller who knows the overflows are rare -- but not past eight in a row: every one is a batch computed twice)
+    const uint32_t strikes = ix->prefilter_strikes.load();
+    if (off || !c->score_hash || c->prefilter_off_once || c->stream_ordered || (strikes >= 2 && ix->sweep_mode != 3) || strikes >= 8) return false;
     static const bool env_sweep = getenv("ZH_SWEEP_MODE") != nullptr;
     if ((ix->sweep_mode != 0 && ix->sweep_mode != 3) || (env_sweep && ix->sweep_mode != 3)) return false;  // a sweep was asked for
     if (metric != ZH_L2SQ && metric != ZH_L2 && metric != ZH_COSINE) return false;
@@ -1716,26 +1738,28 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     c->approx = c->scan && use_approx(ix, tot, B, k, c->metric);
     ZhApprox ap{};
     if (c->approx) {
-        // per query: room for twice its share of the candidates + 256 (a visit hands on the rows its intervals cannot rule out:
-        // a few more than `take`), at most what final_interval_kernel's sort holds; the exact path for visits that take fewer
-        // than top_k rows: its table and key scratch sized from the batch
+        // per query: what final_interval_kernel's sort holds (48 KB per query of HBM).  A visit hands on the rows its intervals cannot
+        // rule out: a few more than `take` -- or dozens more where the keys are dense around the cut: the parity cosine key on iid
+        // rows, whose "nearest" are the similarities just above zero, sends ~100 rows per visit of a 20k-row leaf.  The exact path
+        // for visits that take fewer than top_k rows: its table and key scratch sized from the batch
         const char *cap_e = getenv("ZH_APX_CAPS");  // tests: "capq,ex_cap,ex_rows" -- lists and tables that run over (read per batch)
         unsigned e_capq = 0, e_excap = 0, e_exrows = 0;
         if (cap_e) sscanf(cap_e, "%u,%u,%u", &e_capq, &e_excap, &e_exrows);
-        const uint32_t capq = e_capq ? std::min(e_capq, 4096u) : (uint32_t)std::min<uint64_t>(4096, ((2 * tot.takes / B + 256) + 63) / 64 * 64);
+        const uint32_t capq = e_capq ? std::min(e_capq, 4096u) : 4096u;
         const uint32_t ex_cap = e_excap ? e_excap : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, tot.visits / 4 + 1024), 1u << 24);
         const uint32_t ex_rows = e_exrows ? e_exrows : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, tot.rows / 16), 1u << 26);
         if ((rc = c->wQh.ensure(B * d * 2)) || (rc = c->wQmeta.ensure(B * sizeof(float4))) || (rc = c->wApList.ensure((size_t)B * capq * 12)) ||
-            (rc = c->wApCount.ensure(B * 4)) || (rc = c->wApEx.ensure((size_t)ex_cap * 4)) || (rc = c->wApExKeys.ensure((size_t)ex_rows * 20)) ||
+            (rc = c->wApCount.ensure(B * 8 + std::max<uint64_t>(tot.visits, 1) * 4)) || (rc = c->wApEx.ensure((size_t)ex_cap * 4)) || (rc = c->wApExKeys.ensure((size_t)ex_rows * 20)) ||
             (rc = c->wApCtl.ensure(ZH_APX_CTL_WORDS * 4)))
             return rc;
         ap.Qh = c->wQh.p; ap.qmeta = c->wQmeta.as<float4>(); ap.iv = c->wKeys.as<uint64_t>();
         ap.list_lo = c->wApList.as<uint32_t>(); ap.list_hi = ap.list_lo + (size_t)B * capq; ap.list_id = ap.list_hi + (size_t)B * capq;
-        ap.qcount = c->wApCount.as<uint32_t>(); ap.capq = capq;
+        ap.qcount = c->wApCount.as<uint32_t>(); ap.capq = capq; ap.qtau = ap.qcount + B; ap.tauv = ap.qtau + B;
         ap.ex_visits = c->wApEx.as<uint32_t>(); ap.ex_cap = ex_cap;
         ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
+        HIPCHK(hipMemsetAsync(ap.qtau, 0xFF, B * 4, s));
         HIPCHK(hipMemsetAsync(c->wApCtl.p, 0, ZH_APX_CTL_WORDS * 4, s));
         HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), s));
     }
@@ -1852,8 +1876,8 @@ int ctx_wait(zh_search_ctx *c) {
         st.approx_fallbacks_accum++;
         st.approx_last_overflow = c->h_ap[1];
         ix->approx_strikes.fetch_add(1);
-    } else if (apx)
-        ix->approx_strikes = 0;
+    } else if (apx && (uint64_t)c->h_ap[4] > (uint64_t)c->B * 2400)  // lists 60 % full on average: some query's will run over
+        ix->approx_strikes.fetch_add(1);
     st.prefiltered = pf ? 1 : 0;
     st.prefilter_exact_visits = pf_amb;
     st.prefilter_exact_rows = pf_exact;

@@ -37,6 +37,10 @@ uint32_t zh_approx_groups(uint32_t d) {
     default: return 0;
     }
 }
+// ... and where it pays by itself (the cost model's side): all groups of a wave work on ONE stored row, so a row wanted by fewer
+// queries than the wave has groups leaves lanes idle -- d = 128 / 256 (four groups) at the BASELINE shapes' 3-6 pairs per row
+// (cfg5: 14.9 against 2.4 ms x launches of the leaf-major sweep, profiles/r04_*): only when asked for (zh_set_sweep_mode 4)
+bool zh_approx_pays(uint32_t d) { return d >= 384; }
 
 // Half-width of the interval around the value the approximate scan computes (u = 2^-24, c0 = ceil(d / 256) + 8 = the longest
 // chain of the canonical sums; nx, nq upper estimates of |x|, |q|; dq >= |q - h / sigma|, measured by qhalf_kernel).
@@ -488,8 +492,10 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
         (result) = prefix_;                                                                                 \
     }
 
-__global__ __launch_bounds__(256) void select_interval_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
-                                                               uint32_t k_top, const uint32_t *__restrict__ leaf_ids, ZhApprox ap) {
+// pass 1: per visit that takes top_k of a longer leaf, tau = the take-th smallest hi (top_k rows of the visit have keys at or
+// below it); the smallest tau of a query's visits bounds the query's top_k-th key as well (those rows are candidates)
+__global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
+                                                          uint32_t k_top, ZhApprox ap) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_u[8];
     const uint32_t tid = threadIdx.x;
@@ -497,22 +503,40 @@ __global__ __launch_bounds__(256) void select_interval_kernel(const ZhVisit *__r
     const uint32_t cnt = (uint32_t)(n_visits - base < chunk ? n_visits - base : chunk);
     for (uint32_t c = 0; c < cnt; c++) {  // block-uniform
         const ZhVisit v = visits[base + c];
-        if (!v.take) continue;
-        const uint64_t *__restrict__ kp = ap.iv + v.row_off;
         uint32_t tau = 0xFFFFFFFFu;
-        if (v.take < v.len) {
+        if (v.take && v.take < v.len) {
             if (v.take < k_top) {  // membership matters (see the header of this file): the exact path
                 if (tid == 0) {
                     const uint32_t slot = atomicAdd(&ap.ctl[0], 1u);
                     if (slot < ap.ex_cap) ap.ex_visits[slot] = (uint32_t)(base + c);
                     else atomicOr(&ap.ctl[1], 4u);
+                    ap.tauv[base + c] = 0u;  // (its rows join the list from exact_visit_kernel, not from the emit pass)
                 }
                 continue;
             }
+            const uint64_t *__restrict__ kp = ap.iv + v.row_off;
 #define ZH_APX_HI(i) ((uint32_t)(kp[i] >> 32))
             ZH_APX_RADIX_SELECT(v.len, v.take, ZH_APX_HI, tau);
 #undef ZH_APX_HI
+            if (tid == 0) atomicMin(&ap.qtau[v.b], tau);
         }
+        if (tid == 0) ap.tauv[base + c] = tau;
+    }
+}
+
+// pass 2: a visit hands on the rows whose lo exceeds neither its own tau nor the query's
+__global__ __launch_bounds__(256) void select_emit_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
+                                                           uint32_t k_top, const uint32_t *__restrict__ leaf_ids, ZhApprox ap) {
+    __shared__ uint32_t s_u[8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * chunk;
+    const uint32_t cnt = (uint32_t)(n_visits - base < chunk ? n_visits - base : chunk);
+    for (uint32_t c = 0; c < cnt; c++) {  // block-uniform
+        const ZhVisit v = visits[base + c];
+        if (!v.take || (v.take < v.len && v.take < k_top)) continue;
+        const uint64_t *__restrict__ kp = ap.iv + v.row_off;
+        const uint32_t tv = ap.tauv[base + c], tq = ap.qtau[v.b];
+        const uint32_t tau = tv < tq ? tv : tq;
         __syncthreads();
         if (tid == 0) { s_u[0] = 0; s_u[2] = 0; }
         __syncthreads();
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(256) void select_interval_kernel(const ZhVisit *__r
         if (mine) atomicAdd(&s_u[0], mine);
         __syncthreads();
         const uint32_t M = s_u[0];
+        if (!M) continue;
         if (tid == 0) {
             const uint32_t b0 = atomicAdd(&ap.qcount[v.b], M);
             s_u[1] = b0;
@@ -540,7 +565,6 @@ __global__ __launch_bounds__(256) void select_interval_kernel(const ZhVisit *__r
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -598,26 +622,38 @@ __global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restr
         tk = s_red[0]; ti = s_red[4];
         for (int w = 1; w < 4; w++)
             if (s_red[w] > tk || (s_red[w] == tk && s_red[4 + w] > ti)) { tk = s_red[w]; ti = s_red[4 + w]; }
+        // of the `take` chosen, those the query's tau does not rule out join the list
+        if (tid == 0) s_u32[7] = 0;
+        __syncthreads();
+        const uint32_t tq = ap.qtau[v.b];
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < v.len; i += 256) {
+            const uint64_t kk = ap.ex_keys[(size_t)eb + i];
+            const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
+            if ((kk < tk || (kk == tk && id <= ti)) && (uint32_t)ap.iv[v.row_off + i] <= tq) mine++;
+        }
+        if (mine) atomicAdd(&s_u32[7], mine);
+        __syncthreads();
+        const uint32_t M = s_u32[7];
+        __syncthreads();
         if (tid == 0) {
-            const uint32_t b0 = atomicAdd(&ap.qcount[v.b], v.take);
+            const uint32_t b0 = M ? atomicAdd(&ap.qcount[v.b], M) : 0u;
             s_u32[6] = b0; s_u32[7] = 0;
-            if (b0 + v.take > ap.capq) atomicOr(&ap.ctl[1], 1u);
+            if (M && b0 + M > ap.capq) atomicOr(&ap.ctl[1], 1u);
         }
         __syncthreads();
         const uint32_t b0 = s_u32[6];
-        if (b0 + v.take <= ap.capq) {
+        if (M && b0 + M <= ap.capq) {
             const size_t ob = (size_t)v.b * ap.capq + b0;
             for (uint32_t i = tid; i < v.len; i += 256) {
                 const uint64_t kk = ap.ex_keys[(size_t)eb + i];
                 const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
-                if (kk < tk || (kk == tk && id <= ti)) {
+                const uint64_t w = ap.iv[v.row_off + i];
+                if ((kk < tk || (kk == tk && id <= ti)) && (uint32_t)w <= tq) {
                     const uint32_t pos = atomicAdd(&s_u32[7], 1u);
-                    const uint64_t w = ap.iv[v.row_off + i];
-                    if (pos < v.take) {
-                        ap.list_lo[ob + pos] = (uint32_t)w;
-                        ap.list_hi[ob + pos] = (uint32_t)(w >> 32);
-                        ap.list_id[ob + pos] = id;
-                    }
+                    ap.list_lo[ob + pos] = (uint32_t)w;
+                    ap.list_hi[ob + pos] = (uint32_t)(w >> 32);
+                    ap.list_id[ob + pos] = id;
                 }
             }
         }
@@ -626,23 +662,46 @@ __global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restr
 }
 
 // ---- per query: duplicates out, tau, the survivors' canonical keys, top_k (lsh.rs:557-564) ----
-#define ZH_APX_LCAP 4096  // entries of a query's list the sort holds
-#define ZH_APX_SCAP 512   // survivors per query
-template <int KIND>
+#define ZH_APX_LCAP 4096  // entries of a query's list the sort holds (and, after it, its survivors)
+// the reference's key of stored row `id` against the block's query: canonical sums (D > 0: the specialised row loads, the query's
+// float4s in registers; D == 0: any d)
+template <int D, int KIND>
+__device__ __forceinline__ uint64_t exact_key(const float *__restrict__ X, uint32_t d, uint32_t id, const float *__restrict__ q,
+                                              const float4 *qreg, float qq, uint32_t lane, int metric, int param) {
+    float s0 = 0.f, s1 = 0.f;
+    if constexpr (D > 0) {
+        constexpr int NV = RowVec<D>::NV;
+        float4 v[NV];
+        load_row<D>(X + (size_t)id * D, lane, v);
+        row_pair_sums<D, KIND>(v, qreg, lane, param, s0, s1);
+        if (KIND == K_COS) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+                if (act) sq4(v[j], c);
+            }
+            s1 = wave_sum_canonical((c.x + c.y) + (c.z + c.w));
+        }
+    } else
+        lane_sums_generic<KIND>(X + (size_t)id * d, q, d, lane, param, s0, s1);
+    return key_of(metric, param, s0, s1, qq);
+}
+
+template <int D, int KIND>
 __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_t k, const float *__restrict__ X, uint32_t d,
                                                               const float *__restrict__ Q, const float *__restrict__ QQ, int metric,
                                                               int param, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
                                                               uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
-    __shared__ uint64_t sk[ZH_APX_LCAP];  // id << 32 | sortable hi: equal ids end up side by side
-    __shared__ uint32_t sl[ZH_APX_LCAP];  // sortable lo
-    __shared__ uint64_t vk[ZH_APX_SCAP], vi[ZH_APX_SCAP];
+    __shared__ uint64_t sk[ZH_APX_LCAP];  // id << 32 | sortable hi: equal ids end up side by side; later: the survivors' keys
+    __shared__ uint32_t sl[ZH_APX_LCAP];  // sortable lo; later: the survivors' ids
     __shared__ uint32_t hist[256], scan[256], s_u[8];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // something ran over in select_interval / exact_visit (complete by now: same stream): a list whose count ran past its
     // capacity has slots nobody wrote -- nothing here may be dereferenced, and the f32 scan behind redoes the batch anyway
     if (ap.ctl[1] & (1u | 4u | 8u)) return;
     uint32_t n = ap.qcount[b];
-    if (n > ap.capq) n = ap.capq;  // (flagged by whoever appended past the end)
+    if (n > ap.capq) n = ap.capq;
     if (n > ZH_APX_LCAP) n = ZH_APX_LCAP;  // capq <= ZH_APX_LCAP
     const size_t ob = (size_t)b * ap.capq;
     for (uint32_t i = tid; i < n; i += 256) {
@@ -666,16 +725,20 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
         el[j] = i < n ? sl[i] : 0u;
         cntl += keep[j] ? 1u : 0u;
     }
-    scan[tid] = cntl;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256; o <<= 1) {
-        const uint32_t a = tid >= o ? scan[tid - o] : 0;
+    auto block_scan = [&](uint32_t mine) {  // exclusive prefix of `mine` over the threads; scan[255] = the total
+        scan[tid] = mine;
         __syncthreads();
-        scan[tid] += a;
-        __syncthreads();
-    }
-    uint32_t rank = scan[tid] - cntl;
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const uint32_t a = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += a;
+            __syncthreads();
+        }
+        return scan[tid] - mine;
+    };
+    uint32_t rank = block_scan(cntl);
     const uint32_t nu = scan[255];
+    __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++)
         if (keep[j]) { sk[rank] = ek[j]; sl[rank] = el[j]; rank++; }
@@ -688,34 +751,47 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
 #undef ZH_APX_HI
     }
     __syncthreads();
-    if (tid == 0) s_u[0] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < nu; i += 256)
-        if (sl[i] <= tau) {
-            const uint32_t pos = atomicAdd(&s_u[0], 1u);
-            if (pos < ZH_APX_SCAP) vi[pos] = sk[i] >> 32;
-        }
-    __syncthreads();
-    uint32_t ns = s_u[0];
-    if (ns > ZH_APX_SCAP) {
-        if (tid == 0) atomicOr(&ap.ctl[1], 2u);
-        ns = ZH_APX_SCAP;
+    // the survivors (lo <= tau), compacted in place: their ids into sl (a thread's slice is read whole before anything is written)
+    cntl = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t i = tid * PER + j;
+        keep[j] = i < nu && sl[i] <= tau;
+        el[j] = i < nu ? (uint32_t)(sk[i] >> 32) : 0u;
+        cntl += keep[j] ? 1u : 0u;
     }
-    // the survivors' keys, the reference's arithmetic (canonical sums)
-    for (uint32_t i = wv; i < ns; i += 4) {
-        const uint32_t id = (uint32_t)vi[i];
-        float s0, s1;
-        lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)b * d, d, lane, param, s0, s1);
-        if (lane == 0) vk[i] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[b] : 0.f);
+    rank = block_scan(cntl);
+    const uint32_t ns = scan[255];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++)
+        if (keep[j]) sl[rank++] = el[j];
+    __syncthreads();
+    // the survivors' keys, the reference's arithmetic (canonical sums): a wave takes every fourth, two rows in flight
+    {
+        const float *q = Q + (size_t)b * d;
+        const float qq = KIND == K_COS ? QQ[b] : 0.f;
+        float4 qreg[D > 0 ? RowVec<(D > 0 ? D : 4)>::NV : 1];
+        if constexpr (D > 0) load_row<D>(q, lane, qreg);
+        for (uint32_t i = wv; i < ns; i += 8) {
+            const uint32_t i2 = i + 4;
+            const uint64_t k0 = exact_key<D, KIND>(X, d, sl[i], q, qreg, qq, lane, metric, param);
+            uint64_t k1 = 0;
+            if (i2 < ns) k1 = exact_key<D, KIND>(X, d, sl[i2], q, qreg, qq, lane, metric, param);
+            if (lane == 0) {
+                sk[i] = k0;
+                if (i2 < ns) sk[i2] = k1;
+            }
+        }
     }
     const uint32_t sp2 = next_pow2(ns);
     __syncthreads();
-    for (uint32_t i = ns + tid; i < sp2; i += 256) { vk[i] = ~0ull; vi[i] = ~0ull; }
-    block_bitonic_sort<uint64_t>(vk, vi, sp2);
+    for (uint32_t i = ns + tid; i < sp2; i += 256) { sk[i] = ~0ull; sl[i] = ~0u; }
+    block_bitonic_sort<uint32_t>(sk, sl, sp2);
     const uint32_t have = ns < k ? ns : k;
     for (uint32_t i = tid; i < k; i += 256) {
-        out_ids[(size_t)b * k + i] = i < have ? id_base + vi[i] : ~0ull;
-        out_keys[(size_t)b * k + i] = i < have ? vk[i] : ~0ull;
+        out_ids[(size_t)b * k + i] = i < have ? id_base + sl[i] : ~0ull;
+        out_keys[(size_t)b * k + i] = i < have ? sk[i] : ~0ull;
     }
     if (tid == 0) {
         out_counts[b] = have;
@@ -731,22 +807,35 @@ hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, 
     uint64_t chunk = (n_visits + 16383) / 16384;
     if (chunk > 256) chunk = 256;
     const uint64_t blocks = (n_visits + chunk - 1) / chunk;
-    hipLaunchKernelGGL(select_interval_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, dLeafIds, ap);
+    hipLaunchKernelGGL(select_tau_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, ap);
+    hipLaunchKernelGGL(select_emit_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, dLeafIds, ap);
     return hipGetLastError();
+}
+
+template <int KIND>
+static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
+                                    uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, const ZhApprox &ap,
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+    hipLaunchKernelGGL(exact_visit_kernel<KIND>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
+#define ZH_APX_FIN(DD) \
+    hipLaunchKernelGGL((final_interval_kernel<DD, KIND>), dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds, \
+                       dOutKeys, dOutCounts)
+    switch (d) {
+    case 128: ZH_APX_FIN(128); break;
+    case 384: ZH_APX_FIN(384); break;
+    case 768: ZH_APX_FIN(768); break;
+    default: ZH_APX_FIN(0); break;
+    }
+#undef ZH_APX_FIN
 }
 
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
                                     uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
     if (!B) return hipSuccess;
-    if (metric == ZH_COSINE) {
-        hipLaunchKernelGGL(exact_visit_kernel<K_COS>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
-        hipLaunchKernelGGL(final_interval_kernel<K_COS>, dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds,
-                           dOutKeys, dOutCounts);
-    } else {
-        hipLaunchKernelGGL(exact_visit_kernel<K_L2>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
-        hipLaunchKernelGGL(final_interval_kernel<K_L2>, dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds,
-                           dOutKeys, dOutCounts);
-    }
+    if (metric == ZH_COSINE)
+        launch_final_interval_k<K_COS>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, s);
+    else
+        launch_final_interval_k<K_L2>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, s);
     return hipGetLastError();
 }

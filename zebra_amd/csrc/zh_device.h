@@ -230,6 +230,20 @@ __device__ __forceinline__ void load_row(const float *__restrict__ row, uint32_t
 }
 
 
+// one stored row (in the canonical lane layout) against one query: the canonical sums of the pair
+template <int D, int KIND>
+__device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, uint32_t lane, int power, float &s0, float &s1) {
+    constexpr int NV = RowVec<D>::NV;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
+        if (act) acc4<KIND>(v[j], q[j], a, e, power);
+    }
+    s0 = wave_combine<KIND>(a.x, a.y, a.z, a.w);
+    if (KIND == K_BRAY) s1 = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS bitonic sort of (key, id) ascending; n is a power of two
 // ------------------------------------------------------------------------------------------------

@@ -223,6 +223,8 @@ struct ZhApprox {
     uint32_t *list_lo, *list_hi, *list_id;  // per query: capq slots
     uint32_t *qcount;
     uint32_t capq;
+    uint32_t *tauv;          // per visit: the take-th smallest hi (sortable) of a visit that takes top_k rows of a longer leaf
+    uint32_t *qtau;          // per query: the smallest of them -- top_k candidates of the query have keys at or below it
     uint32_t *ex_visits;     // indices of the visits for the exact path
     uint32_t ex_cap;
     uint64_t *ex_keys, *ex_ckeys;  // their rows' canonical keys; the `take` chosen
@@ -231,6 +233,7 @@ struct ZhApprox {
     uint32_t *ctl;
 };
 uint32_t zh_approx_groups(uint32_t d);
+bool zh_approx_pays(uint32_t d);
 float zh_approx_bound(int metric, uint32_t d);
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
 hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s);

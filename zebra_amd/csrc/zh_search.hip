@@ -1608,20 +1608,6 @@ hipError_t zh_launch_node_visits(const uint32_t *dLeafCount, const uint32_t *dGr
     return hipGetLastError();
 }
 
-// one stored row (in the canonical lane layout) against one query: the canonical sums of the pair
-template <int D, int KIND>
-__device__ __forceinline__ void row_pair_sums(const float4 *v, const float4 *q, uint32_t lane, int power, float &s0, float &s1) {
-    constexpr int NV = RowVec<D>::NV;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-        const bool act = (j < RowVec<D>::NJ) || (lane < (uint32_t)RowVec<D>::REM4);
-        if (act) acc4<KIND>(v[j], q[j], a, e, power);
-    }
-    s0 = wave_combine<KIND>(a.x, a.y, a.z, a.w);
-    if (KIND == K_BRAY) s1 = wave_combine<K_L2>(e.x, e.y, e.z, e.w);
-}
-
 // A stored row of the table scan: streamed exactly once per batch window.  ZH_SCAN_ROWPOL (build-time, A/B) picks the cache
 // policy of these loads: 0 = global_load ... nt; n > 0 = buffer_load with aux bits n (1 = sc0, 2 = nt, 16 = sc1).
 #ifndef ZH_SCAN_ROWPOL
@@ -2765,7 +2751,10 @@ hipError_t zh_launch_final_lists(uint32_t T, uint32_t B, uint32_t k, uint32_t ca
     // one wave per query over the PACKED lists, 16 KB of LDS (the 256-thread kernel's 50 KB wait for room beside the walks).  The
     // lists are mostly empty (~15-50 of 64-128 slots): up to 4x as many slots as the sort holds are tried this way; a query whose
     // lists do hold more than the sort reports it and the batch is redone with the sweep
-    if ((uint64_t)T * cap <= 4 * MERGE_WAVE_N) {
+    // ... but not where the lists CANNOT fit it: every list of a pair that walked >= k rows keeps at least k survivors, so T * k
+    // entries are certain (15 trees, k = 64: 960 + extras > 1024 raised the overflow flag on every batch): those shapes go
+    // to the streaming block kernel, which takes any length
+    if ((uint64_t)T * cap <= 4 * MERGE_WAVE_N && (uint64_t)T * k <= MERGE_WAVE_N * 3 / 4) {
         hipLaunchKernelGGL(merge_wave_kernel, dim3(B), dim3(64), 0, s, B, T, k, dKeys, dIds, dCounts, dOutIds, dOutKeys, dOutCounts,
                            (uint64_t)B * cap, (uint64_t)B, cap, dOver);
         return hipGetLastError();

@@ -231,7 +231,17 @@ static int shard_begin(zh_shard_ctx *c, const float *const *d_q, size_t nwin, si
     if (c->g->dead.load()) return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it");
     int rc = set_dev(c->g);
     if (rc) return rc;
-    if (c->state == 2) zh_shard_search_wait(c);  // retire the previous batch (its verdict was the caller's to collect)
+    if (c->state == 2) {
+        // Retire the batch the context still holds.  Its verdict was the caller's to collect; one that was not OK is reported HERE and
+        // the new batch is not begun: the merged outputs of the retired window are invalid on every rank, and every rank sees a
+        // failed verdict for it (its own code, or ZH_EPEER), so every rank's begin returns alike and the collective sequence stays aligned.
+        const int v = zh_shard_search_wait(c);
+        if (v != ZH_OK) {
+            const std::string why = zh_last_error();
+            return FAIL(v, "zh_shard_search_begin retired the batch this context still held, and it had FAILED (its outputs are invalid on "
+                           "every rank; nothing new was begun): %s", why.c_str());
+        }
+    }
     if (c->g->dead.load()) return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it");
     // From here on the call is part of a collective sequence: whatever happens locally, this rank joins the exchange in
     // finish.  A failed local begin is remembered and travels in the status word.
@@ -259,7 +269,11 @@ static int shard_finish(zh_shard_ctx *c, uint64_t *const *out_ids, uint64_t *con
     zh_shard_group *g = c->g;
     if (g->dead.load()) { c->state = 0; return FAIL(ZH_EPEER, "the shard group is dead (an earlier exchange timed out or failed): destroy it"); }
     int rc = set_dev(g);
-    if (rc) return rc;
+    if (rc) {  // this rank cannot join the exchange its peers are about to enter: fail together, fast (not after ZH_SHARD_TIMEOUT_MS)
+        c->state = 0;
+        kill_group(g);
+        return rc;
+    }
     const size_t B = c->B, k = c->k, nwin = c->nwin, b = c->bwin;
     const size_t W = zh_packed_result_words(B, k), SW = W + 1, need = SW * g->n_ranks;
     // a rank that cannot even hold the gather buffer cannot join: it kills the group (peers time out in wait -> ZH_EPEER)
@@ -399,7 +413,13 @@ extern "C" int zh_shard_search_wait(zh_shard_ctx *c) {
     while (vmax > cur && !g->peer_vpq.compare_exchange_weak(cur, vmax)) {}
     c->all_elimit = all_el != 0;
     if (verdict) return c->verdict = verdict;
-    if (rc_local) return c->verdict = rc_local;
+    if (rc_local) {
+        // the exchange said OK everywhere but this rank's own local wait failed AFTER its status word had left (a HIP error): its
+        // peers believe the batch and would go on to the next collective without it -- the group cannot continue
+        const std::string why = zh_last_error();
+        kill_group(g);
+        return c->verdict = FAIL(rc_local, "local search failed after the exchange (%s); the shard group is dead", why.c_str());
+    }
     return ZH_OK;
 }
 
