@@ -164,6 +164,8 @@ typedef struct zh_stats_t {
     uint64_t approx_fallbacks_accum; /* batches redone by the f32 scan ON THE DEVICE, in stream order, because a list ran over */
     uint64_t approx_last_overflow;  /* ... what ran over: 1 a query's candidate list, 2 a query's survivors, 4 the table of exact
                                      * visits, 8 their key scratch */
+    uint64_t combined_batches_accum; /* zh_search_batch: internal batches that served MORE than one concurrent caller (since reset) */
+    uint64_t combined_calls_accum;   /* ... and the calls they served */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -218,7 +220,12 @@ ZH_API int zh_index_read_rows(zh_index *idx, uint64_t first, size_t n, float *ou
 ZH_API int zh_hash_signs(zh_index *idx, const float *q, size_t b, uint32_t *out_bits, float *out_dots);
 
 /* LSHIndex::search for a batch: q is b x dim; out_ids/out_keys are b x k (entries past
- * out_counts[i] are set to UINT64_MAX); ascending by (key, id).  Host pointers. */
+ * out_counts[i] are set to UINT64_MAX); ascending by (key, id).  Host pointers.
+ * Callable from many threads at once -- the crate calls search with ONE query from every rayon worker (core.rs:299-303) -- and
+ * built for that: callers that arrive while a batch is on the GPU queue up, the thread that finds the engine idle leads a round
+ * and runs every queued request with the same top_k / metric / mode as ONE internal batch (answers are those of separate calls,
+ * bit for bit: the queries of a batch never interact); the others sleep until theirs is done.  No timer: a lone caller is served
+ * at once, a crowd is batched by the time the batch before it takes.  zh_stats_t::combined_* count it. */
 ZH_API int zh_search_batch(zh_index *idx, const float *q, size_t b, size_t k, int metric, int cosine_mode,
                     uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts);
 /* The same with queries and results already resident in device memory; kernels are enqueued on
@@ -265,7 +272,12 @@ ZH_API int zh_search_finish_window(zh_search_ctx *ctx, uint64_t *const *d_out_id
                                    uint32_t *const *d_out_counts, void *sweep_stream);
 
 /* Metric::distance(stored=a[i], query=q) for n stored rows against one query (host pointers).  Device buffers are kept
- * per calling thread between calls (a pair costs two small copies in, three small kernels, one copy out). */
+ * per calling thread between calls (a pair costs two small copies in, three small kernels, one copy out).
+ * COST of the single-pair forms (n = 1, zh_distance_pair): tens of microseconds -- a host -> device copy, three launches and a
+ * blocking copy back -- where the crate's Metric::distance spends ~100 ns in simsimd (distance.rs:21-31).  There is deliberately
+ * no host-side arithmetic behind this ABI (every key this library returns comes from the gfx950 kernels: one implementation
+ * to hold bit-exact, and nothing that could pass for a CPU fallback): a caller that needs isolated pairs at CPU speed keeps the
+ * crate's own metric for them (the shim routes Metric::distance to the crate, batches to this library). */
 ZH_API int zh_distance_batch(int metric, int cosine_mode, const float *a, const float *q, size_t n, size_t dim,
                       uint64_t *out_keys, int device);
 ZH_API int zh_distance_pair(int metric, int cosine_mode, const float *a, const float *b, size_t dim, uint64_t *out_key,

@@ -4,12 +4,18 @@
 // that produces distances, signs or neighbours launches gfx950 kernels.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cmath>
+#include <deque>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zh_internal.h"
@@ -165,7 +171,9 @@ struct zh_index {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t sweep_stream = nullptr;  // lowest priority: shared by the sweeps of pipelined contexts
-    std::mutex mu;
+    // exclusive: everything that changes the index or uses its one blocking context (dctx); shared: the combining front end's lanes,
+    // which search on contexts of their own (searches on different contexts run side by side, as the pipelined calls do)
+    std::shared_mutex mu;
 
     // stored vectors: n_rows x dim row-major f32 (Embedding<N>, lib.rs:18)
     DevBuf X;
@@ -238,6 +246,35 @@ struct zh_index {
     int profiling = 0;
     std::mutex stats_mu;
     zh_stats_t stats{};
+    // Combining front end of zh_search_batch (the crate calls LSHIndex::search with ONE query from many rayon workers,
+    // core.rs:299-303): callers that arrive while a batch is on the GPU queue their requests; the thread that finds the engine
+    // idle leads -- it runs every compatible queued request (same top_k, metric, mode) as ONE internal batch and hands out the
+    // results -- and the others sleep on the condition variable until theirs is done.
+    struct CombineReq {
+        const float *q; size_t b, k; int metric, mode;
+        uint64_t *ids, *keys; uint32_t *counts;
+        int rc = 0; std::string err;
+        // completion and the appointment as next leader travel on the request's OWN mutex / condition variable: a finished round
+        // wakes its callers side by side (one shared condition variable made 64 woken threads queue for one mutex)
+        std::mutex m; std::condition_variable cv; bool done = false, lead = false;
+    };
+    // The lane a round runs on: a search context, a stream and staging of its own (not the index's blocking context: zh_search_batch
+    // holds the index lock SHARED, zh_search_batch_device / add / remove exclusively).  One lane: a second one, so that one round's
+    // host work overlaps the other's kernels, was measured slower (67 k against 80 k calls/s from 64 threads: rounds half the
+    // size, and the HIP runtime serialises the two host threads' launches anyway).
+    struct Lane {
+        zh_search_ctx ctx;
+        bool init = false, busy = false;
+        hipStream_t s = nullptr;
+        DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
+        void *h_stage = nullptr;  // pinned staging of a combined batch: queries in, results out (one H2D, three D2H per round)
+        size_t h_stage_cap = 0;
+    };
+    std::mutex cmu;
+    std::deque<CombineReq *> cpend;
+    bool cleader = false;   // some thread is leading (running rounds or about to)
+    size_t clast = 0;       // callers served by the previous round
+    Lane lanes[1];
 };
 
 static int set_device(const zh_index *ix) {
@@ -362,6 +399,13 @@ static void free_forest(zh_index *ix) {
 }
 
 extern "C" void zh_index_destroy(zh_index *ix) {
+    if (ix)
+        for (auto &ln : ix->lanes) {
+            if (ln.init) { hipSetDevice(ix->device); ln.ctx.release_all(); }
+            ln.wQ.release(); ln.wOutIds.release(); ln.wOutKeys.release(); ln.wOutCounts.release();
+            if (ln.s) hipStreamDestroy(ln.s);
+            if (ln.h_stage) hipHostFree(ln.h_stage);
+        }
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
@@ -379,7 +423,7 @@ extern "C" void zh_index_destroy(zh_index *ix) {
 
 extern "C" int zh_index_clear(zh_index *ix) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     hipStreamSynchronize(ix->stream);
@@ -430,13 +474,13 @@ static int append_locked(zh_index *ix, const float *rows, size_t n, uint64_t *ou
 }
 extern "C" int zh_index_append(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
     if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_append: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     return append_locked(ix, rows, n, out_ids);
 }
 
 extern "C" int zh_index_read_rows(zh_index *ix, uint64_t first, size_t n, float *out) {
     if (!ix || (n && !out)) return fail(ZH_EINVAL, "zh_index_read_rows: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     if (first + n > ix->n_rows) return fail(ZH_EINVAL, "zh_index_read_rows: rows [%llu, %llu) out of range (%llu stored)",
@@ -447,7 +491,7 @@ extern "C" int zh_index_read_rows(zh_index *ix, uint64_t first, size_t n, float 
 
 extern "C" int zh_index_append_device(zh_index *ix, const float *d_rows, size_t n) {
     if (!ix || (!d_rows && n)) return fail(ZH_EINVAL, "zh_index_append_device: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     if ((rc = grow_rows(ix, n))) return rc;
@@ -462,7 +506,7 @@ extern "C" int zh_index_append_device(zh_index *ix, const float *d_rows, size_t 
 
 extern "C" int zh_index_append_synthetic(zh_index *ix, size_t n, uint64_t seed, uint64_t first_row, int kind) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     if ((rc = grow_rows(ix, n))) return rc;
@@ -509,7 +553,7 @@ static int upload_nodes(zh_index *ix) {
 
 extern "C" int zh_index_set_forest(zh_index *ix, const zh_forest_view *fv) {
     if (!ix || !fv) return fail(ZH_EINVAL, "zh_index_set_forest: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     const uint32_t nn = fv->n_nodes, np = fv->n_planes, nt = fv->n_trees, d = ix->opt.dim;
@@ -617,7 +661,7 @@ extern "C" int zh_index_forest_sizes(zh_index *ix, zh_forest_sizes *out) {
 extern "C" int zh_index_get_forest(zh_index *ix, int32_t *plane, int32_t *left, int32_t *right, uint32_t *roots,
                                    float *planes, float *consts, uint32_t *leaf_ids) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     if (plane) memcpy(plane, ix->h_plane.data(), ix->h_plane.size() * 4);
@@ -917,7 +961,7 @@ static int insert_rows_locked(zh_index *ix, uint64_t n_prev, uint64_t n_new) {
 extern "C" int zh_index_build(zh_index *ix) {
     if (!ix) return fail(ZH_EINVAL, "null index");
     if (ix->opt.max_node_size == 0) return fail(ZH_EINVAL, "max_node_size must be >= 1");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     return build_forest_locked(ix);
@@ -926,7 +970,7 @@ extern "C" int zh_index_build(zh_index *ix) {
 extern "C" int zh_index_add(zh_index *ix, const float *rows, size_t n, uint64_t *out_ids) {
     if (!ix || (!rows && n)) return fail(ZH_EINVAL, "zh_index_add: null argument");
     if (ix->opt.max_node_size == 0) return fail(ZH_EINVAL, "max_node_size must be >= 1");
-    std::lock_guard<std::mutex> lk(ix->mu);  // one critical section: state is read, rows stored and trees updated under it
+    std::unique_lock<std::shared_mutex> lk(ix->mu);  // one critical section: state is read, rows stored and trees updated under it
     if (ix->broken) return fail(ZH_ESTATE, "an earlier add failed half way: call zh_index_build before adding or searching");
     const bool had_trees = ix->n_trees != 0;  // lsh.rs:441: no_trees() decides between build_index and insert
     const uint64_t n_prev = ix->n_rows;
@@ -1018,7 +1062,7 @@ static int remove_rows_locked(zh_index *ix, const std::vector<uint32_t> &rows, s
 
 extern "C" int zh_index_remove(zh_index *ix, const uint64_t *ids, size_t n, uint8_t *out_found, size_t *out_n_removed) {
     if (!ix || (n && !ids)) return fail(ZH_EINVAL, "zh_index_remove: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     std::vector<uint32_t> rows;
@@ -1046,7 +1090,7 @@ extern "C" int zh_index_remove(zh_index *ix, const uint64_t *ids, size_t n, uint
 // removed.  Rows are hashed on the GPU (one pass over the stored vectors), equal hashes are confirmed byte for byte.
 extern "C" int zh_index_deduplicate(zh_index *ix, uint64_t *out_ids, size_t cap, size_t *out_n_removed) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     const uint64_t N = ix->n_rows;
@@ -1120,7 +1164,7 @@ extern "C" int zh_index_deduplicate(zh_index *ix, uint64_t *out_ids, size_t cap,
 // ------------------------------------------------------------------------------------------------
 extern "C" int zh_set_profiling(zh_index *ix, int level) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     ix->profiling = level;
@@ -1899,11 +1943,11 @@ int ctx_wait(zh_search_ctx *c) {
 }
 
 static int search_once(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
-                       uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
-    int rc = ctx_begin(&ix->dctx, &dQ, 1, B, k, metric, mode, s);
+                       uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s, zh_search_ctx *c) {
+    int rc = ctx_begin(c, &dQ, 1, B, k, metric, mode, s);
     if (rc) return rc;
-    if ((rc = ctx_finish(&ix->dctx, &dOutIds, &dOutKeys, &dOutCounts, nullptr))) return rc;
-    return ctx_wait(&ix->dctx);
+    if ((rc = ctx_finish(c, &dOutIds, &dOutKeys, &dOutCounts, nullptr))) return rc;
+    return ctx_wait(c);
 }
 
 // The blocking entry points take any batch: a batch that would pass a per-launch limit (batch * num_trees < 2^26 pairs,
@@ -1911,9 +1955,10 @@ static int search_once(zh_index *ix, const float *dQ, size_t B, size_t k, int me
 // where a query visits ~10^4..10^5 leaves) is split into sub-batches whose outputs land side by side.  The
 // first split is sized from the visits per pair seen so far; a sub-batch that still overflows is halved and retried.
 static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int metric, int mode, uint64_t *dOutIds,
-                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+                         uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s, zh_search_ctx *c = nullptr) {
+    if (!c) c = &ix->dctx;
     const uint32_t T = ix->n_trees, d = ix->opt.dim;
-    if (B == 0 || T == 0) return search_once(ix, dQ, B, k, metric, mode, dOutIds, dOutKeys, dOutCounts, s);
+    if (B == 0 || T == 0) return search_once(ix, dQ, B, k, metric, mode, dOutIds, dOutKeys, dOutCounts, s, c);
     size_t chunk = std::min<size_t>(B, ((1ull << 26) - 1) / T);
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -1925,7 +1970,7 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
     if (chunk == 0) chunk = 1;
     for (size_t b0 = 0; b0 < B;) {
         const size_t nb = std::min(chunk, B - b0);
-        const int rc = search_once(ix, dQ + b0 * d, nb, k, metric, mode, dOutIds + b0 * k, dOutKeys + b0 * k, dOutCounts + b0, s);
+        const int rc = search_once(ix, dQ + b0 * d, nb, k, metric, mode, dOutIds + b0 * k, dOutKeys + b0 * k, dOutCounts + b0, s, c);
         if (rc == ZH_ELIMIT && nb > 1) { chunk = (nb + 1) / 2; continue; }  // the context is idle again: retry smaller
         if (rc) return rc;
         b0 += nb;
@@ -1947,7 +1992,7 @@ extern "C" int zh_search_batch_device(zh_index *ix, const float *d_q, size_t b, 
     if (k > ZH_MAX_TOPK) return fail(ZH_ELIMIT, "top_k %zu > ZH_MAX_TOPK (%u)", k, ZH_MAX_TOPK);
     int rc = check_metric(metric, mode);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     if ((rc = set_device(ix))) return rc;
     return search_locked(ix, d_q, b, k, metric, mode, d_out_ids, d_out_keys, d_out_counts,
                          stream ? (hipStream_t)stream : ix->stream);
@@ -2026,6 +2071,74 @@ extern "C" int zh_search_wait(zh_search_ctx *c) {
     return ctx_wait(c);
 }
 
+// one round of the combining front end: the requests of `grp` (same top_k, metric, mode) as ONE internal batch on lane `ln`
+static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_index::CombineReq *> &grp) {
+    auto all_fail = [&](int rc) {
+        const std::string why = g_err;
+        for (auto *r : grp) { r->rc = rc; r->err = why; }
+    };
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return all_fail(rc);
+    hipError_t e;
+    auto hip_fail = [&](hipError_t err, const char *what) { all_fail(fail(ZH_EHIP, "%s: %s", what, hipGetErrorString(err))); };
+    if (!ln.init) {
+        if ((rc = ctx_init(&ln.ctx, ix))) return all_fail(rc);
+        ln.init = true;
+        if ((e = hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    }
+    hipStream_t s = ln.s;
+    const uint32_t d = ix->opt.dim;
+    const size_t k = grp[0]->k;
+    size_t B = 0;
+    for (auto *r : grp) B += r->b;
+    if ((rc = ln.wQ.ensure(B * d * 4)) || (rc = ln.wOutIds.ensure(std::max<size_t>(B * k, 1) * 8)) ||
+        (rc = ln.wOutKeys.ensure(std::max<size_t>(B * k, 1) * 8)) || (rc = ln.wOutCounts.ensure(B * 4)))
+        return all_fail(rc);
+    const bool staged = grp.size() > 1;  // a lone caller's buffers are used as they are
+    uint8_t *hs = nullptr;
+    const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;
+    if (staged) {
+        if (need > ln.h_stage_cap) {
+            if (ln.h_stage) hipHostFree(ln.h_stage);
+            ln.h_stage = nullptr; ln.h_stage_cap = 0;
+            const size_t cap = need + need / 2;
+            if ((e = hipHostMalloc(&ln.h_stage, cap, hipHostMallocDefault)) != hipSuccess) { all_fail(fail(ZH_ENOMEM, "hipHostMalloc(%zu): %s", cap, hipGetErrorString(e))); return; }
+            ln.h_stage_cap = cap;
+        }
+        hs = static_cast<uint8_t *>(ln.h_stage);
+        size_t o = 0;
+        for (auto *r : grp) { memcpy(hs + o, r->q, r->b * d * 4); o += r->b * d * 4; }
+        if ((e = hipMemcpyAsync(ln.wQ.p, hs, B * d * 4, hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e, "H2D");
+    } else if ((e = hipMemcpyAsync(ln.wQ.p, grp[0]->q, B * d * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+        return hip_fail(e, "H2D");
+    rc = search_locked(ix, ln.wQ.as<float>(), B, k, grp[0]->metric, grp[0]->mode, ln.wOutIds.as<uint64_t>(), ln.wOutKeys.as<uint64_t>(),
+                       ln.wOutCounts.as<uint32_t>(), s, &ln.ctx);
+    if (rc) return all_fail(rc);
+    uint64_t *hi = staged ? reinterpret_cast<uint64_t *>(hs + off_ids) : grp[0]->ids;
+    uint64_t *hk = staged ? reinterpret_cast<uint64_t *>(hs + off_keys) : grp[0]->keys;
+    uint32_t *hc = staged ? reinterpret_cast<uint32_t *>(hs + off_counts) : grp[0]->counts;
+    e = hipSuccess;
+    if (k) {
+        e = hipMemcpyAsync(hi, ln.wOutIds.p, B * k * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(hk, ln.wOutKeys.p, B * k * 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hc, ln.wOutCounts.p, B * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "D2H");
+    if (staged) {
+        size_t b0 = 0;
+        for (auto *r : grp) {
+            if (k) { memcpy(r->ids, hi + b0 * k, r->b * k * 8); memcpy(r->keys, hk + b0 * k, r->b * k * 8); }
+            memcpy(r->counts, hc + b0, r->b * 4);
+            b0 += r->b;
+        }
+        std::lock_guard<std::mutex> ls(ix->stats_mu);
+        ix->stats.combined_batches_accum++;
+        ix->stats.combined_calls_accum += grp.size();
+    }
+}
+
 extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k, int metric, int mode,
                                uint64_t *out_ids, uint64_t *out_keys, uint32_t *out_counts) {
     if (!ix || (b && (!q || !out_counts || (k && (!out_ids || !out_keys))))) return fail(ZH_EINVAL, "zh_search_batch: null argument");
@@ -2033,30 +2146,83 @@ extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k,
     int rc = check_metric(metric, mode);
     if (rc) return rc;
     if (b == 0) return ZH_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if ((rc = set_device(ix))) return rc;
-    hipStream_t s = ix->stream;
-    const uint32_t d = ix->opt.dim;
-    if ((rc = ix->wQ.ensure(b * d * 4))) return rc;
-    if ((rc = ix->wOutIds.ensure(std::max<size_t>(b * k, 1) * 8))) return rc;
-    if ((rc = ix->wOutKeys.ensure(std::max<size_t>(b * k, 1) * 8))) return rc;
-    if ((rc = ix->wOutCounts.ensure(b * 4))) return rc;
-    HIPCHK(hipMemcpyAsync(ix->wQ.p, q, b * d * 4, hipMemcpyHostToDevice, s));
-    rc = search_locked(ix, ix->wQ.as<float>(), b, k, metric, mode, ix->wOutIds.as<uint64_t>(),
-                       ix->wOutKeys.as<uint64_t>(), ix->wOutCounts.as<uint32_t>(), s);
-    if (rc) return rc;
-    if (k) {
-        HIPCHK(hipMemcpyAsync(out_ids, ix->wOutIds.p, b * k * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(out_keys, ix->wOutKeys.p, b * k * 8, hipMemcpyDeviceToHost, s));
+    zh_index::CombineReq me;
+    me.q = q; me.b = b; me.k = k; me.metric = metric; me.mode = mode; me.ids = out_ids; me.keys = out_keys; me.counts = out_counts;
+    bool lead;
+    {
+        std::lock_guard<std::mutex> lk(ix->cmu);
+        ix->cpend.push_back(&me);
+        lead = !ix->cleader;  // nobody leads: this caller does, at once
+        if (lead) ix->cleader = true;
     }
-    HIPCHK(hipMemcpyAsync(out_counts, ix->wOutCounts.p, b * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    for (;;) {
+        if (!lead) {  // sleep until my request is done, or until a finishing leader hands me the lead
+            std::unique_lock<std::mutex> l(me.m);
+            me.cv.wait(l, [&] { return me.done || me.lead; });
+            if (me.done) break;
+            me.lead = false;
+        }
+        // ---- lead one round ----
+        std::unique_lock<std::mutex> lk(ix->cmu);
+        if (ix->clast >= 2) {
+            // The round before served a crowd whose threads are on their way back with their next requests.  Taking the queue as it
+            // stands would split a crowd of N into two cohorts of N / 2 that take turns (one is served while the other queues), and a
+            // round costs about the same for 30 queries as for 60: wait until the arrivals pause (nothing new for ~10 us), 120 us at most.
+            // (polled with yields: sleep_for(10 us) takes ~60 us with the default timer slack)
+            const auto t0 = std::chrono::steady_clock::now();
+            auto tq = t0;
+            size_t n0 = ix->cpend.size();
+            for (;;) {
+                lk.unlock();
+                std::this_thread::yield();
+                lk.lock();
+                const auto now = std::chrono::steady_clock::now();
+                if (ix->cpend.size() != n0) { n0 = ix->cpend.size(); tq = now; }
+                if (now - tq > std::chrono::microseconds(10) || now - t0 > std::chrono::microseconds(120)) break;
+            }
+        }
+        // the head of the queue and everything behind it that can share its batch (same top_k, metric, mode; arrival order kept)
+        std::vector<zh_index::CombineReq *> grp;
+        const zh_index::CombineReq *head = ix->cpend.front();  // (never empty: the leader's own request is in it until served)
+        size_t total = 0;
+        for (auto it = ix->cpend.begin(); it != ix->cpend.end();) {
+            zh_index::CombineReq *r = *it;
+            if (r->k == head->k && r->metric == head->metric && r->mode == head->mode && (grp.empty() || total + r->b <= 8192)) {
+                grp.push_back(r);
+                total += r->b;
+                it = ix->cpend.erase(it);
+            } else
+                ++it;
+        }
+        lk.unlock();
+        run_group(ix, ix->lanes[0], grp);
+        bool mine = false;
+        for (auto *r : grp) {
+            if (r == &me) { mine = true; continue; }
+            std::lock_guard<std::mutex> l(r->m);  // (notify under the lock: the owner destroys r as soon as it sees done)
+            r->done = true;
+            r->cv.notify_one();
+        }
+        lk.lock();
+        ix->clast = grp.size();
+        if (!mine) { lk.unlock(); lead = true; continue; }  // my own request waits in the queue (it could not share the head's batch): lead on
+        // served: hand the lead to the head of the queue, or retire it
+        if (ix->cpend.empty()) ix->cleader = false;
+        else {
+            zh_index::CombineReq *nx = ix->cpend.front();
+            std::lock_guard<std::mutex> l(nx->m);
+            nx->lead = true;
+            nx->cv.notify_one();
+        }
+        break;
+    }
+    if (me.rc) return fail(me.rc, "%s", me.err.c_str());
     return ZH_OK;
 }
 
 extern "C" int zh_hash_signs(zh_index *ix, const float *q, size_t b, uint32_t *out_bits, float *out_dots) {
     if (!ix || (b && (!q || !out_bits))) return fail(ZH_EINVAL, "zh_hash_signs: null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     const uint32_t P = ix->n_planes, d = ix->opt.dim;
