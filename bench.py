@@ -149,7 +149,7 @@ def parse():
                          "own streams and run beside the current window's walk / sweep)")
     ap.add_argument("--window", type=int, default=None,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
-    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan"], default="auto",
+    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx"], default="auto",
                     help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Instruction mix and wait counters of the table scan (cfg3, --serial-windows: one window on the GPU at a time), one rocprofv3
 # --pmc pass per group:   gpurun -- bash profiles/pmc_scan_mix.sh      -> gpurun_out/pmc_scan_mix.txt
-# KERNEL=<substring of the kernel name> (default: the scan the bench line runs, scan_approx_kernel since round 4; ZH_NO_APPROX=1
+# ARGS="<bench.py workload args>" (default: cfg3, 6 steps); KERNEL=<substring of the kernel name> (default: the scan the bench line runs, scan_approx_kernel since round 4; ZH_NO_APPROX=1
 # KERNEL=scan_sweep_kernel for the f32 scan)
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export KERNEL=${KERNEL:-scan_approx_kernel}
 OUT=gpurun_out/pmc_mix; rm -rf $OUT; mkdir -p $OUT
-args="bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-recall --no-other-configs --profile-run --serial-windows"
+args="bench.py ${ARGS:---steps 6 --warmup 2} --cpu-seconds 0 --no-recall --no-other-configs --profile-run --serial-windows"
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" \
            "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY" \

@@ -1,7 +1,8 @@
 //! Shim that keeps the reference crate's signatures for the hot path on top of `libzebra_hip.so`.
 //!
 //! NOT COMPILED in this repository's build image (no Rust toolchain there); it mirrors
-//! `include/zebra_hip.h` one to one and is kept mechanical on purpose.  What it replaces in emmyoh/zebra:
+//! `include/zebra_hip.h` one to one and is kept mechanical on purpose.  It is a PATCH to the crate, not a parallel crate:
+//! without the `standalone` feature it binds the crate's own `Embedding<N>` / `DistanceUnit` (see below).  What it replaces in emmyoh/zebra:
 //! `src/distance.rs` (the metric structs' `Metric::distance`), `src/database/index/lsh.rs`
 //! (`LSHIndex<N>`: new / add / search / remove / deduplicate / clear / is_empty / no_vectors / no_trees) and the
 //! rayon loop of `Database::query_vectors` (`src/database/core.rs:299-303`) through `search_batch`.
@@ -16,36 +17,59 @@ use dashmap::{DashMap, DashSet};
 use space::Metric;
 use uuid::Uuid;
 
+// ---- the vector type and the key type: the CRATE'S OWN (round 4) -----------------------------------------------------------
+// As a patch to emmyoh/zebra this file lives INSIDE the crate (src/hip.rs, feature `hip`) and binds the
+// crate's `Embedding<N>` / `DistanceUnit` -- it does not re-declare them: one type, no conversion at the boundary, and a
+// `&[Embedding<N>]` handed to `insert_records` / `query_vectors` crosses the FFI as it is.  The stand-alone re-declaration
+// below exists only behind the `standalone` feature, for building and testing this shim without the crate.
+#[cfg(not(feature = "standalone"))]
+pub use crate::{Embedding, EmbeddingPrecision}; // src/lib.rs:15-48 (as `zebra::...` when built as an external crate: `--cfg zebra_external`)
+#[cfg(not(feature = "standalone"))]
+pub use crate::distance::DistanceUnit; // src/distance.rs:13
+// The reference's `Embedding<N>` is a plain newtype over `[f32; N]` (src/lib.rs:18) WITHOUT `#[repr(transparent)]`; the layout of a
+// single-field struct is that of its field in practice, and this shim asserts what it relies on instead of assuming it:
+#[cfg(not(feature = "standalone"))]
+const _: () = {
+    assert!(std::mem::size_of::<Embedding<4>>() == 16 && std::mem::align_of::<Embedding<4>>() == 4);
+};
+
+#[cfg(feature = "standalone")]
 pub type DistanceUnit = u64; // src/distance.rs:13
+#[cfg(feature = "standalone")]
 pub type EmbeddingPrecision = f32; // src/lib.rs:48
 
-/// `Embedding<N>` as in the reference (src/lib.rs:15-46): a newtype over `[f32; N]` with Deref / DerefMut / Default /
-/// From / TryFrom.  `repr(transparent)`: a `&[Embedding<N>]` is `len * N` contiguous f32, which is what crosses the FFI.
-/// (The reference also derives serde's Serialize / Deserialize through `serde_with`; unchanged, omitted here.)
+/// (feature `standalone` only) `Embedding<N>` as in the reference (src/lib.rs:15-46): a newtype over `[f32; N]` with Deref / DerefMut /
+/// Default / From / TryFrom.  `repr(transparent)`: a `&[Embedding<N>]` is `len * N` contiguous f32, which is what crosses the FFI.
+#[cfg(feature = "standalone")]
 #[repr(transparent)]
 #[derive(Debug, Clone)]
 pub struct Embedding<const N: usize>([EmbeddingPrecision; N]);
+#[cfg(feature = "standalone")]
 impl<const N: usize> std::ops::Deref for Embedding<N> {
     type Target = [EmbeddingPrecision; N];
     fn deref(&self) -> &[EmbeddingPrecision; N] {
         &self.0
     }
 }
+#[cfg(feature = "standalone")]
 impl<const N: usize> std::ops::DerefMut for Embedding<N> {
     fn deref_mut(&mut self) -> &mut [EmbeddingPrecision; N] {
         &mut self.0
     }
 }
+#[cfg(feature = "standalone")]
 impl<const N: usize> Default for Embedding<N> {
     fn default() -> Self {
         Self([0.0; N])
     }
 }
+#[cfg(feature = "standalone")]
 impl<const N: usize> From<[EmbeddingPrecision; N]> for Embedding<N> {
     fn from(value: [EmbeddingPrecision; N]) -> Self {
         Self(value)
     }
 }
+#[cfg(feature = "standalone")]
 impl<const N: usize> TryFrom<Vec<EmbeddingPrecision>> for Embedding<N> {
     type Error = Vec<EmbeddingPrecision>;
     fn try_from(value: Vec<EmbeddingPrecision>) -> Result<Self, Self::Error> {

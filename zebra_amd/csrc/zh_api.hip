@@ -221,7 +221,8 @@ struct zh_index {
     int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies
     // a batch whose half-width scan ran over was redone by the f32 scan: both scans paid.  Data whose keys are dense around the cut (the
     // parity cosine key on iid rows in 20k-row leaves: thousands of rows per query inside the bound) would do so batch after batch:
-    // after the first such batch -- or one whose lists came close -- the index keeps the f32 scan until its trees change
+    // after the first such batch -- or one whose lists came close -- the per-query lists get 8192 slots instead of 4096 (a final
+    // kernel with twice the LDS); after the second the index keeps the f32 scan until its trees change
     std::atomic<uint32_t> approx_strikes{0};
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
@@ -1357,11 +1358,11 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
     static const bool off = getenv("ZH_NO_APPROX") != nullptr;
     const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
     if (off || mode == 2 || mode == 1) return false;
-    if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0) return false;
+    if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0 || B >= (1u << 24)) return false;  // (24 bits of a packed pair record)
     if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
     // by itself only where it pays: its per-pair cost is half the f32 scan's, its per-row cost higher (cfg3: 0.057 against 0.118 ns per
     // pair, 0.74 against 0.52 ns per stored row, + the interval stages): from ~5 pairs per stored row on
-    if (mode != 4 && (ix->approx_strikes.load() >= 1 || !zh_approx_pays(ix->opt.dim) || tot.rows < 5 * ix->n_rows)) return false;
+    if (mode != 4 && (ix->approx_strikes.load() >= 2 || !zh_approx_pays(ix->opt.dim) || tot.rows < 5 * ix->n_rows)) return false;
     return true;
 }
 
@@ -1789,7 +1790,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         const char *cap_e = getenv("ZH_APX_CAPS");  // tests: "capq,ex_cap,ex_rows" -- lists and tables that run over (read per batch)
         unsigned e_capq = 0, e_excap = 0, e_exrows = 0;
         if (cap_e) sscanf(cap_e, "%u,%u,%u", &e_capq, &e_excap, &e_exrows);
-        const uint32_t capq = e_capq ? std::min(e_capq, 4096u) : 4096u;
+        const uint32_t capq = e_capq ? std::min(e_capq, 8192u) : (ix->approx_strikes.load() ? 8192u : 4096u);
         const uint32_t ex_cap = e_excap ? e_excap : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, tot.visits / 4 + 1024), 1u << 24);
         const uint32_t ex_rows = e_exrows ? e_exrows : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, tot.rows / 16), 1u << 26);
         if ((rc = c->wQh.ensure(B * d * 2)) || (rc = c->wQmeta.ensure(B * sizeof(float4))) || (rc = c->wApList.ensure((size_t)B * capq * 12)) ||
@@ -1920,7 +1921,7 @@ int ctx_wait(zh_search_ctx *c) {
         st.approx_fallbacks_accum++;
         st.approx_last_overflow = c->h_ap[1];
         ix->approx_strikes.fetch_add(1);
-    } else if (apx && (uint64_t)c->h_ap[4] > (uint64_t)c->B * 2400)  // lists 60 % full on average: some query's will run over
+    } else if (apx && (uint64_t)c->h_ap[4] > (uint64_t)c->B * (ix->approx_strikes.load() ? 5600 : 2800))  // lists 70 % full on average: some query's will run over
         ix->approx_strikes.fetch_add(1);
     st.prefiltered = pf ? 1 : 0;
     st.prefilter_exact_visits = pf_amb;

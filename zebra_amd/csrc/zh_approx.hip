@@ -24,6 +24,8 @@
 // behind with that flag as their predicate -- redo the batch in stream order; no host round trip, so the sharded search (which
 // consumes results in stream order) can use it too.
 
+#include <cstdlib>
+
 #include "zh_internal.h"
 #include "zh_device.h"
 
@@ -38,8 +40,10 @@ uint32_t zh_approx_groups(uint32_t d) {
     }
 }
 // ... and where it pays by itself (the cost model's side): all groups of a wave work on ONE stored row, so a row wanted by fewer
-// queries than the wave has groups leaves lanes idle -- d = 128 / 256 (four groups) at the BASELINE shapes' 3-6 pairs per row
-// (cfg5: 14.9 against 2.4 ms x launches of the leaf-major sweep, profiles/r04_*): only when asked for (zh_set_sweep_mode 4)
+// queries than the wave has groups leaves lanes idle -- d = 256 (four groups) at 3-6 pairs per row: only when asked for
+// (zh_set_sweep_mode 4).  d = 128 has a kernel of its own (rows in LDS, every group its own pair), but
+// its per-(row, tree) entry work -- 15 entries per row for 5.5 pairs at cfg5 -- keeps it level with the leaf-major sweep there (29.5
+// against 27.7 ms per batch at window 2, 22.7 against 24.4 at window 4; profiles/r04_pmc_scan_approx128_cfg5*.txt): also only when asked for.
 bool zh_approx_pays(uint32_t d) { return d >= 384; }
 
 // Half-width of the interval around the value the approximate scan computes (u = 2^-24, c0 = ceil(d / 256) + 8 = the longest
@@ -157,6 +161,54 @@ __device__ __forceinline__ uint64_t approx_interval(float s, float a2, const flo
     return ((uint64_t)hi_s << 32) | lo_s;
 }
 
+// Phase 1 of a table-scan wave: its nr * T (row, tree) entries -> which leaves this batch visits, by which query, where the result
+// goes, and the exclusive scan of the visit counts (= positions in the wave's pair list).  Three dependent fetches per entry -- the
+// entry (streamed), a word of the visited-leaf bitmap, the leaf's visit record -- issued STAGE BY STAGE for all of a lane's
+// entries (clamped / dummy addresses instead of branches), so that a wave pays three memory round trips, not three per entry:
+// the scan of a 125M x 128 shard spends more line requests here than on its pairs (profiles/r04_pmc_scan_approx128_cfg5*.txt).
+__device__ __forceinline__ uint32_t scan_phase1(uint32_t lane, uint32_t n_ent, const uint2 *__restrict__ ent,
+                                                const uint32_t *__restrict__ visitBits, const uint4 *__restrict__ nodeVisit,
+                                                uint32_t *eGb, uint32_t *eWithin, uint32_t *eC, uint32_t *off, uint32_t *eB0, uint64_t *eK0) {
+    unsigned long long rlw[ZH_SCAN_NE];
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t e = lane + 64u * j;
+        rlw[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + (e < n_ent ? e : 0)));
+    }
+    uint32_t word[ZH_SCAN_NE];
+    bool in[ZH_SCAN_NE];
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t node = (uint32_t)rlw[j];
+        in[j] = lane + 64u * j < n_ent && node != 0xFFFFFFFFu;
+        word[j] = visitBits[in[j] ? node >> 5 : 0];
+    }
+    uint4 nv[ZH_SCAN_NE];
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t node = (uint32_t)rlw[j];
+        in[j] = in[j] && ((word[j] >> (node & 31)) & 1u);
+        nv[j] = nodeVisit[in[j] ? node : 0];
+    }
+    uint32_t P = 0;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        eWithin[j] = (uint32_t)(rlw[j] >> 32);
+        eC[j] = in[j] ? nv[j].x & 0x0FFFFFFFu : 0u;
+        eGb[j] = nv[j].y; eB0[j] = nv[j].z;
+        eK0[j] = ((uint64_t)(nv[j].x >> 28) << 32) | nv[j].w;
+        uint32_t incl = eC[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        off[j] = P + incl - eC[j];
+        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    return P;
+}
+
 #define ZH_APX_CAP 512   // pair records of a wave's LDS list
 #ifndef ZH_APX_WAVES
 #define ZH_APX_WAVES 0
@@ -195,30 +247,7 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     // ---- phase 1 (as scan_sweep_kernel): the wave's nr * T (row, tree) entries -> pairs, in (row, tree, visit) order ----
     uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
     uint64_t eK0[ZH_SCAN_NE];
-    uint32_t P = 0;
-#pragma unroll
-    for (int j = 0; j < ZH_SCAN_NE; j++) {
-        const uint32_t e = lane + 64u * j;
-        eGb[j] = 0; eWithin[j] = 0; eC[j] = 0; eB0[j] = 0; eK0[j] = 0;
-        if (e < n_ent) {
-            const unsigned long long rlw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ent + e));
-            const uint2 rl = make_uint2((uint32_t)rlw, (uint32_t)(rlw >> 32));
-            eWithin[j] = rl.y;
-            if (rl.x != 0xFFFFFFFFu && ((visitBits[rl.x >> 5] >> (rl.x & 31)) & 1u)) {
-                const uint4 nv = nodeVisit[rl.x];
-                eC[j] = nv.x & 0x0FFFFFFFu; eGb[j] = nv.y; eB0[j] = nv.z;
-                eK0[j] = ((uint64_t)(nv.x >> 28) << 32) | nv.w;
-            }
-        }
-        uint32_t incl = eC[j];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= (uint32_t)o) incl += t;
-        }
-        off[j] = P + incl - eC[j];
-        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    }
+    const uint32_t P = scan_phase1(lane, n_ent, ent, visitBits, nodeVisit, eGb, eWithin, eC, off, eB0, eK0);
     if (P == 0) return;
     const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
     // finished sums wait in lane registers -- group g's result of step n in lane g * LG + n -- so that the interval arithmetic and
@@ -409,6 +438,143 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     flush();
 }
 
+// ---- d = 128 (SIFT-style shards, cfg5): a row or a query is ONE 16-lane group's worth (8 elements per lane), and a stored row is
+// wanted by only 3-6 queries of a window -- four groups on the same row (the kernel above) would idle half the wave.  Here the
+// wave's 16 consecutive rows (8 KB, contiguous in memory: eight coalesced 1-KiB loads) wait in LDS and every group takes ANY pair
+// of the wave's list: per step four pairs, each with its own row (two conflict-free ds_read_b128) and its own query (one
+// dwordx4 of halves per lane), eight v_fma_mix_f32, four DPP adds.  Same intervals, same stages behind it.
+template <int KINDA>
+__global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__restrict__ X, const uint4 *__restrict__ Qh,
+                                                              const float4 *__restrict__ qmeta, const uint2 *__restrict__ rowLeaf,
+                                                              uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
+                                                              const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
+                                                              uint32_t GRP, uint64_t row_begin, uint64_t row_end, float Kc,
+                                                              uint64_t *__restrict__ iv) {
+    constexpr int LG = 16, G = 4;
+    // pair records packed into 8 bytes (interval slot: 36 bits | query: 24 bits | row of the wave: 4 bits) and a list of 240: 40 KB of
+    // LDS per block with the rows, four blocks per CU
+    constexpr uint32_t CAP = 240;
+    __shared__ uint64_t pair_list[4][CAP];
+    __shared__ float4 row_lds[4][16 * 32];  // the wave's rows, as in memory
+    __shared__ float a2_lds[4][16];
+    const uint32_t lane = threadIdx.x & 63, l = lane & (LG - 1), g = lane / LG;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r0 = row_begin + wave * RW;
+    if (r0 >= row_end) return;
+    const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
+    const uint32_t n_ent = nr * T;
+    const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
+    uint64_t eK0[ZH_SCAN_NE];
+    const uint32_t P = scan_phase1(lane, n_ent, ent, visitBits, nodeVisit, eGb, eWithin, eC, off, eB0, eK0);
+    if (P == 0) return;
+    // the wave's rows into LDS (rows r0 .. r0 + nr - 1 are one contiguous piece of the table), and their squared norms
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(X) + (size_t)r0 * 32;
+        float4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = (lane + 64u * i < nr * 32u) ? ld16<true>(src + lane + 64 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; i++) row_lds[wid][lane + 64 * i] = t[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {  // group g: rows g, g + 4, g + 8, g + 12
+        const uint32_t row = g + 4u * rr;
+        const float4 v0 = row_lds[wid][row * 32 + l], v1 = row_lds[wid][row * 32 + 16 + l];
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        sq4(v0, c);
+        sq4(v1, c);
+        const float a2 = group_sum<LG>((c.x + c.y) + (c.z + c.w));
+        if (l == 0) a2_lds[wid][row] = a2;
+    }
+    float my_s = 0.f;
+    uint64_t my_slot = 0;
+    uint32_t my_b = 0, my_row = 0, nst = 0;
+    bool my_on = false;
+    auto flush = [&]() {
+        if (my_on) __builtin_nontemporal_store(approx_interval<KINDA>(my_s, a2_lds[wid][my_row], qmeta[my_b], Kc), iv + my_slot);
+        my_on = false;
+        nst = 0;
+    };
+    auto dot8 = [&](const float4 &v0, const float4 &v1, const uint4 &hq) {
+        f16x8 h;
+        __builtin_memcpy(&h, &hq, 16);
+        float ax = __builtin_fmaf(v0.x, (float)h[0], 0.f), ay = __builtin_fmaf(v0.y, (float)h[1], 0.f);
+        float az = __builtin_fmaf(v0.z, (float)h[2], 0.f), aw = __builtin_fmaf(v0.w, (float)h[3], 0.f);
+        ax = __builtin_fmaf(v1.x, (float)h[4], ax); ay = __builtin_fmaf(v1.y, (float)h[5], ay);
+        az = __builtin_fmaf(v1.z, (float)h[6], az); aw = __builtin_fmaf(v1.w, (float)h[7], aw);
+        return group_sum<LG>((ax + ay) + (az + aw));
+    };
+    auto stash = [&](float s, uint32_t row, uint32_t b, uint64_t slot, bool valid) {
+        if (l == nst) { my_s = s; my_row = row; my_b = b; my_slot = slot; my_on = valid; }
+        if (++nst == (uint32_t)LG) flush();
+    };
+    auto pack = [](uint32_t rl, uint32_t b, uint64_t slot) { return slot | ((uint64_t)b << 36) | ((uint64_t)rl << 60); };
+    if (P <= CAP) {
+        uint64_t *list = pair_list[wid];
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            const uint32_t e = lane + 64u * j, c = eC[j];
+            if (c) {
+                const uint32_t rl = e / T, gb = eGb[j];
+                {
+                    const uint64_t slot = eK0[j] + eWithin[j];
+                    list[off[j]] = pack(rl, eB0[j], slot);
+                }
+                for (uint32_t sidx = 1; sidx < c; sidx++) {
+                    const ZhGroup *gp = groups + gb + sidx / GRP;
+                    const uint64_t slot = gp->key_off[sidx % GRP] + eWithin[j];
+                    list[off[j] + sidx] = pack(rl, gp->b[sidx % GRP], slot);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // four pairs per step, the next step's records, queries and rows requested before the current step is computed
+        auto r_row = [](uint64_t r) { return (uint32_t)(r >> 60); };
+        auto r_b = [](uint64_t r) { return (uint32_t)(r >> 36) & 0xFFFFFFu; };
+        uint64_t rec = list[g < P ? g : P - 1];
+        uint4 hq = Qh[(size_t)r_b(rec) * 16 + l];
+        float4 v0 = row_lds[wid][r_row(rec) * 32 + l], v1 = row_lds[wid][r_row(rec) * 32 + 16 + l];
+        for (uint32_t p = 0; p < P; p += G) {
+            const uint32_t pn = p + G + g;
+            const uint64_t recn = list[pn < P ? pn : P - 1];
+            const uint4 hqn = Qh[(size_t)r_b(recn) * 16 + l];
+            const float4 v0n = row_lds[wid][r_row(recn) * 32 + l], v1n = row_lds[wid][r_row(recn) * 32 + 16 + l];
+            const float s = dot8(v0, v1, hq);
+            stash(s, r_row(rec), r_b(rec), rec & 0xFFFFFFFFFull, p + g < P);
+            rec = recn; hq = hqn; v0 = v0n; v1 = v1n;
+        }
+    } else {
+        // more pairs than the list holds (hot leaves): entry after entry, a leaf's visits four at a time
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            unsigned long long m = __ballot(eC[j] != 0);
+            while (m) {
+                const int ll = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], ll);
+                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], ll);
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], ll);
+                const uint32_t rl = ((uint32_t)ll + 64u * j) / T;
+                const float4 v0 = row_lds[wid][rl * 32 + l], v1 = row_lds[wid][rl * 32 + 16 + l];
+                for (uint32_t s0 = 0; s0 < c; s0 += G) {
+                    const uint32_t sidx = s0 + g < c ? s0 + g : c - 1;
+                    const ZhGroup *gp = groups + gb + sidx / GRP;
+                    const uint32_t b = gp->b[sidx % GRP];
+                    const uint4 hq = Qh[(size_t)b * 16 + l];
+                    const float s = dot8(v0, v1, hq);
+                    stash(s, rl, b, gp->key_off[sidx % GRP] + w, s0 + g < c);
+                }
+            }
+        }
+    }
+    flush();
+}
+
 template <int D, int G>
 static hipError_t launch_scan_approx_d(const float *dX, uint64_t n_rows, const ZhApprox &ap, const uint2 *dRowLeaf, uint32_t T,
                                        const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group,
@@ -443,7 +609,28 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
                                  int mode, hipStream_t s) {
     if (!n_rows) return hipSuccess;
     switch (d) {
-    case 128: return launch_scan_approx_d<128, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 128: {
+        static const bool generic = getenv("ZH_APX128_GENERIC") != nullptr;  // A/B: the four-groups-on-one-row kernel at d = 128
+        if (generic) return launch_scan_approx_d<128, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+        const uint32_t RW = zh_scan_rows_per_wave(T);
+        uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+        rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
+        const float Kc = zh_approx_bound(metric, 128);
+        const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
+        for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
+            const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
+            const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
+            if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define ZH_APX_LAUNCH(KA) \
+            hipLaunchKernelGGL((scan_approx128_kernel<KA>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, (const uint4 *)ap.Qh, ap.qmeta, dRowLeaf, T, RW, \
+                               dVisitBits, dNodeVisit, dGroups, group, r, r_end, Kc, ap.iv)
+            if (kinda == 0) ZH_APX_LAUNCH(0);
+            else if (kinda == 1) ZH_APX_LAUNCH(1);
+            else ZH_APX_LAUNCH(2);
+#undef ZH_APX_LAUNCH
+        }
+        return hipGetLastError();
+    }
     case 256: return launch_scan_approx_d<256, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     case 384: return launch_scan_approx_d<384, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     case 512: return launch_scan_approx_d<512, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
@@ -662,7 +849,9 @@ __global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restr
 }
 
 // ---- per query: duplicates out, tau, the survivors' canonical keys, top_k (lsh.rs:557-564) ----
-#define ZH_APX_LCAP 4096  // entries of a query's list the sort holds (and, after it, its survivors)
+// LCAP = entries of a query's list the sort holds (and, after it, its survivors): 4096 (48 KB of LDS per block), or 8192 (96 KB: one
+// block per CU) for an index whose lists ran over 4096 once -- keys that are dense around the cut (the parity cosine key on iid rows in
+// 20k-row leaves: ~3000 rows per query inside the bound)
 // the reference's key of stored row `id` against the block's query: canonical sums (D > 0: the specialised row loads, the query's
 // float4s in registers; D == 0: any d)
 template <int D, int KIND>
@@ -688,13 +877,13 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ X, uint3
     return key_of(metric, param, s0, s1, qq);
 }
 
-template <int D, int KIND>
+template <int D, int KIND, int LCAP>
 __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_t k, const float *__restrict__ X, uint32_t d,
                                                               const float *__restrict__ Q, const float *__restrict__ QQ, int metric,
                                                               int param, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
                                                               uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
-    __shared__ uint64_t sk[ZH_APX_LCAP];  // id << 32 | sortable hi: equal ids end up side by side; later: the survivors' keys
-    __shared__ uint32_t sl[ZH_APX_LCAP];  // sortable lo; later: the survivors' ids
+    __shared__ uint64_t sk[LCAP];  // id << 32 | sortable hi: equal ids end up side by side; later: the survivors' keys
+    __shared__ uint32_t sl[LCAP];  // sortable lo; later: the survivors' ids
     __shared__ uint32_t hist[256], scan[256], s_u[8];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // something ran over in select_interval / exact_visit (complete by now: same stream): a list whose count ran past its
@@ -702,7 +891,7 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
     if (ap.ctl[1] & (1u | 4u | 8u)) return;
     uint32_t n = ap.qcount[b];
     if (n > ap.capq) n = ap.capq;
-    if (n > ZH_APX_LCAP) n = ZH_APX_LCAP;  // capq <= ZH_APX_LCAP
+    if (n > (uint32_t)LCAP) n = LCAP;  // capq <= LCAP
     const size_t ob = (size_t)b * ap.capq;
     for (uint32_t i = tid; i < n; i += 256) {
         sk[i] = ((uint64_t)ap.list_id[ob + i] << 32) | ap.list_hi[ob + i];
@@ -713,7 +902,7 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
     block_bitonic_sort<uint32_t>(sk, sl, np2);
     // first entry of every id (the smallest hi of its copies -- the copies are identical in fact: same row registers, same
     // group arithmetic -- ), compacted to the front
-    constexpr uint32_t PER = ZH_APX_LCAP / 256;
+    constexpr uint32_t PER = LCAP / 256;
     uint64_t ek[PER];
     uint32_t el[PER], cntl = 0;
     bool keep[PER];
@@ -817,14 +1006,19 @@ static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uin
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, const ZhApprox &ap,
                                     uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
     hipLaunchKernelGGL(exact_visit_kernel<KIND>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
-#define ZH_APX_FIN(DD) \
-    hipLaunchKernelGGL((final_interval_kernel<DD, KIND>), dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds, \
+#define ZH_APX_FIN(DD, LC) \
+    hipLaunchKernelGGL((final_interval_kernel<DD, KIND, LC>), dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds, \
                        dOutKeys, dOutCounts)
+    if (ap.capq > 4096) {
+        if (d == 768) ZH_APX_FIN(768, 8192);
+        else ZH_APX_FIN(0, 8192);
+        return;
+    }
     switch (d) {
-    case 128: ZH_APX_FIN(128); break;
-    case 384: ZH_APX_FIN(384); break;
-    case 768: ZH_APX_FIN(768); break;
-    default: ZH_APX_FIN(0); break;
+    case 128: ZH_APX_FIN(128, 4096); break;
+    case 384: ZH_APX_FIN(384, 4096); break;
+    case 768: ZH_APX_FIN(768, 4096); break;
+    default: ZH_APX_FIN(0, 4096); break;
     }
 #undef ZH_APX_FIN
 }
