@@ -438,6 +438,12 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     flush();
 }
 
+// (Measured and not kept, round 4: phase 1 as a kernel of its own -- scan_pairs_kernel wrote every 16-row unit's pair records (8 bytes
+// each, compacted through one atomic per unit) and a "listed" scan kernel started from them with independent loads only.  cfg3, window
+// 2: the pairs kernel ~4 ms per batch, the listed scan 6.5 against 4.7 ms per launch beside it, 100 k against 142 k QPS.  Phase 1 is
+// gather WORK -- one visit record per (row, visited tree), a third as many line requests as the rows themselves -- not a latency the
+// fused kernel fails to hide: other waves' pair loops already run beside it.)
+
 // ---- d = 128 (SIFT-style shards, cfg5): a row or a query is ONE 16-lane group's worth (8 elements per lane), and a stored row is
 // wanted by only 3-6 queries of a window -- four groups on the same row (the kernel above) would idle half the wave.  Here the
 // wave's 16 consecutive rows (8 KB, contiguous in memory: eight coalesced 1-KiB loads) wait in LDS and every group takes ANY pair
