@@ -3,7 +3,7 @@
 # `--`, as MI355X_MICROARCH.md prescribes):   gpurun -- bash profiles/collect.sh r02 <commit> [configs...]
 # then, back in the container:                python profiles/summarize.py r02 <commit>
 # Every configuration is its own command, so that a kernel name in a stats file belongs to ONE workload.
-TAG=${1:-r03}; COMMIT=${2:-unknown}; shift 2
+TAG=${1:-r04}; COMMIT=${2:-unknown}; shift 2
 CFGS=${@:-"cfg3 cfg2 cfg4shard cfg5shard refdefault scale64m hashbig"}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
@@ -35,7 +35,7 @@ for c in $CFGS; do
   echo "$args --serial-windows" > $OUT/$c.pmccmd
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$c/fetch -- python3 $args --serial-windows > $OUT/$c.fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$c/write -- python3 $args --serial-windows > $OUT/$c.write.log 2>&1
-  if [ "$c" = cfg3 ]; then  # the scan's L2 side: requests, hit rate
+  if [ "$c" != refdefault ]; then  # the sweep's L2 side: requests, hit rate
     rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/$c/l2 -- python3 $args --serial-windows > $OUT/$c.l2.log 2>&1
   fi
   if [ "$c" = refdefault ]; then

@@ -42,6 +42,25 @@ def agg_counters(d):
     return out
 
 
+def launch_classes(cfg_dir):
+    """the sweep / scan kernels' dispatches of the --kernel-trace run, split by grid size: a batch's last launch covers fewer stored rows
+    than the full ones, and one mixed average hides a slow launch"""
+    fs = glob.glob(os.path.join(cfg_dir, "stats", "**", "*kernel_trace.csv"), recursive=True)
+    if not fs:
+        return {}
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        k = kname(r["Kernel_Name"])
+        if not any(t in k for t in ("scan_approx", "scan_sweep", "sweep_kernel", "sweep128", "prefilter_kernel", "walk_blocked")):
+            continue
+        grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+        a[k][str(grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {}
+    for k, gs in a.items():
+        out[k] = {g: {"launches": len(v), "avg_ms": sum(v) / len(v) / 1e6, "min_ms": min(v) / 1e6, "max_ms": max(v) / 1e6} for g, v in sorted(gs.items(), key=lambda x: -len(x[1]))}
+    return out
+
+
 def box(cfg_dir, out_json):
     fetch, write = agg_counters(os.path.join(cfg_dir, "fetch")), agg_counters(os.path.join(cfg_dir, "write"))
     sq, mfma = agg_counters(os.path.join(cfg_dir, "sq")), agg_counters(os.path.join(cfg_dir, "mfma"))
@@ -64,6 +83,8 @@ def box(cfg_dir, out_json):
             hm = l2[k].get("TCC_HIT_sum", 0) + l2[k].get("TCC_MISS_sum", 0)
             e["l2_hit_rate"] = l2[k].get("TCC_HIT_sum", 0) / hm if hm else None
         out[k] = e
+    for k, cl in launch_classes(cfg_dir).items():
+        out.setdefault(k, {})["launches_by_grid_size"] = cl
     json.dump(out, open(out_json, "w"), indent=1)
     for k, v in out.items():
         if "hbm_bytes_per_launch" in v:
