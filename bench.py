@@ -514,6 +514,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     half = st.get("approx_batches_accum", 0) > 0  # the scan read fp16 copies of the queries (zh_approx.hip)
     kind = 1 if wl["metric"] == "cosine" else 0
     kname = ("scan_sweep_kernel<%d, %d>" if scan else "sweep_kernel<%d, %d, ...>") % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
+    if not scan and d == 128:
+        kname = "sweep128_kernel<%d, ...>" % kind  # the half-wave kernel of the 512-byte rows
     if half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
     s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
@@ -780,16 +782,20 @@ def pmc_traffic(args, name, S, roof):
     under profiles/ by profiles/summarize.py.  bench.py cannot collect counters on itself: it quotes the newest committed
     summary, and only when that summary was taken at the same launch granularity AND window; the commit it was collected at
     travels with it, next to the last commit that touched the kernel sources."""
-    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3_pmc.json")))
-    if not cands or name != "cfg3" or S != 1 or args.rows:
+    prof_name = {("cfg3", 1): "cfg3", ("cfg2", 1): "cfg2", ("cfg4", 8): "cfg4shard", ("cfg5", 8): "cfg5shard", ("refdefault", 1): "refdefault",
+                 ("scale64m", 1): "scale64m"}.get((name, S))
+    cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % prof_name)))
+    if not cands or not prof_name or args.rows:
         return
     try:
         pm = json.load(open(cands[-1]))
-        kn = roof["kernel"].split(" ...")[0]
+        kn = roof["kernel"].split(" ...")[0].rstrip(",")
         ent = [v for k_, v in pm.items() if k_.startswith(kn)][0]
         meta = pm.get("_meta", {})
         traffic = ent["hbm_bytes_per_launch"]
         prof = (meta.get("bench_line_under_kernel_trace") or {}).get("roofline") or {}
+        if "hbm_bytes_per_launch" not in ent:
+            return
         key = "rows_loaded_per_launch" if roof["bound"] == "l2" else "rows_per_launch"
         if prof.get(key) and abs(prof[key] / roof[key] - 1) > 0.10:
             return  # collected at another launch granularity
@@ -800,6 +806,9 @@ def pmc_traffic(args, name, S, roof):
             roof["traffic_over_hbm_by_design"] = traffic / roof["hbm_bytes_by_design_per_launch"]
         else:
             roof["traffic_over_algorithmic"] = traffic / roof["bytes_per_launch"]
+        if ent.get("l2_hit_rate") is not None:
+            roof["l2_hit_rate"] = ent["l2_hit_rate"]
+            roof["l2_request_bytes_per_launch"] = ent.get("l2_request_bytes_per_launch")
         roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
                                   "collected_at_kernel_sources_sha": meta.get("kernel_sources_sha"),
                                   "kernel_sources_sha_now": kernel_sources_sha(),
@@ -869,12 +878,14 @@ def main():
                                                                                        "shard -- %s)" % (shards, rcl.get("recall_note"))) if shards > 1 else ""),
                          "note": "iid rows in 768-d: every non-planted neighbour is a random row, recall@k ~ rows scanned / rows for ANY index; "
                                  "the literal key returns the LEAST similar candidates, so its recall is ~0 by construction"}
+            pmc_traffic(args, wname, shards, r["roofline"])
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",
                                                                "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
                                                                "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling",
                                                                "measured_l2_gather_ceiling_GBps", "frac_of_measured_l2_gather", "query_bytes_per_pair",
+                                                               "traffic", "traffic_over_hbm_by_design", "traffic_over_algorithmic", "traffic_source", "l2_hit_rate",
                                                                "visits_per_launch", "sector_GBps", "exact_rows_per_launch", "exact_visits_per_launch", "prefilter_fallbacks", "note")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
