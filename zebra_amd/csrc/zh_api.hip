@@ -1794,13 +1794,13 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         const uint32_t ex_cap = e_excap ? e_excap : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, tot.visits / 4 + 1024), 1u << 24);
         const uint32_t ex_rows = e_exrows ? e_exrows : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, tot.rows / 16), 1u << 26);
         if ((rc = c->wQh.ensure(B * d * 2)) || (rc = c->wQmeta.ensure(B * sizeof(float4))) || (rc = c->wApList.ensure((size_t)B * capq * 12)) ||
-            (rc = c->wApCount.ensure(B * 8 + std::max<uint64_t>(tot.visits, 1) * 4)) || (rc = c->wApEx.ensure((size_t)ex_cap * 4)) || (rc = c->wApExKeys.ensure((size_t)ex_rows * 20)) ||
+            (rc = c->wApCount.ensure(B * 8 + std::max<uint64_t>(tot.visits, 1) * 4)) || (rc = c->wApEx.ensure((size_t)ex_cap * 8)) || (rc = c->wApExKeys.ensure((size_t)ex_rows * 20)) ||
             (rc = c->wApCtl.ensure(ZH_APX_CTL_WORDS * 4)))
             return rc;
         ap.Qh = c->wQh.p; ap.qmeta = c->wQmeta.as<float4>(); ap.iv = c->wKeys.as<uint64_t>();
         ap.list_lo = c->wApList.as<uint32_t>(); ap.list_hi = ap.list_lo + (size_t)B * capq; ap.list_id = ap.list_hi + (size_t)B * capq;
         ap.qcount = c->wApCount.as<uint32_t>(); ap.capq = capq; ap.qtau = ap.qcount + B; ap.tauv = ap.qtau + B;
-        ap.ex_visits = c->wApEx.as<uint32_t>(); ap.ex_cap = ex_cap;
+        ap.ex_visits = c->wApEx.as<uint2>(); ap.ex_cap = ex_cap;
         ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
@@ -1833,7 +1833,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, s));
         HIPCHK(hipEventRecord(c->ev[4], s));
         HIPCHK(zh_launch_final_interval(c->wVisits.as<ZhVisit>(), ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), (uint32_t)B, (uint32_t)k,
-                                        f.leaf_ids, c->metric, c->mode, ix->opt.id_base, ap, dOutIds, dOutKeys, dOutCounts, s));
+                                        f.leaf_ids, c->metric, c->mode, ix->opt.id_base, ap, dOutIds, dOutKeys, dOutCounts, ix->max_leaf_len, s));
         HIPCHK(hipMemcpyAsync(c->h_ap, c->wApCtl.p, ZH_APX_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
         // A list or table ran over (ctl[1] != 0): the f32 scan, select and final, enqueued here with that word as their predicate,
         // redo the batch in stream order -- kernels that return at once otherwise.  On the context's own stream: the shared sweep

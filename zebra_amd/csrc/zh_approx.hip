@@ -701,8 +701,10 @@ __global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restri
             if (v.take < k_top) {  // membership matters (see the header of this file): the exact path
                 if (tid == 0) {
                     const uint32_t slot = atomicAdd(&ap.ctl[0], 1u);
-                    if (slot < ap.ex_cap) ap.ex_visits[slot] = (uint32_t)(base + c);
-                    else atomicOr(&ap.ctl[1], 4u);
+                    const uint32_t eb = atomicAdd(&ap.ctl[2], v.len);  // its slice of the exact-key scratch
+                    if (slot >= ap.ex_cap) atomicOr(&ap.ctl[1], 4u);
+                    else if ((uint64_t)eb + v.len > ap.ex_rows_cap) { atomicOr(&ap.ctl[1], 8u); ap.ex_visits[slot] = make_uint2(0xFFFFFFFFu, 0u); }
+                    else ap.ex_visits[slot] = make_uint2((uint32_t)(base + c), eb);
                     ap.tauv[base + c] = 0u;  // (its rows join the list from exact_visit_kernel, not from the emit pass)
                 }
                 continue;
@@ -761,35 +763,43 @@ __global__ __launch_bounds__(256) void select_emit_kernel(const ZhVisit *__restr
     }
 }
 
-// a visit that hands over fewer than top_k rows: the leaf scored with the canonical sums, the `take` smallest (key, id) -- what
+// a visit that hands over fewer than top_k rows: the leaf scored with the canonical sums (exact_keys_kernel: a block per 256 rows of
+// a visit, so that a handful of long leaves does not serialise on a handful of blocks), the `take` smallest (key, id) -- what
 // sweep + select do -- join the query's list with their intervals (their keys are computed again with the other survivors')
 template <int KIND>
-__global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restrict__ visits, const float *__restrict__ X, uint32_t d,
-                                                           const float *__restrict__ Q, const float *__restrict__ QQ,
-                                                           const uint32_t *__restrict__ leaf_ids, int metric, int param, ZhApprox ap) {
+__global__ __launch_bounds__(256) void exact_keys_kernel(const ZhVisit *__restrict__ visits, const float *__restrict__ X, uint32_t d,
+                                                          const float *__restrict__ Q, const float *__restrict__ QQ,
+                                                          const uint32_t *__restrict__ leaf_ids, int metric, int param, ZhApprox ap) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (ap.ctl[0] > ap.ex_cap) return;  // the table ran over (flagged by select_tau): the batch is redone
+    const uint32_t total = ap.ctl[0];
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint2 ev = ap.ex_visits[e];
+        if (ev.x == 0xFFFFFFFFu) continue;
+        const ZhVisit v = visits[ev.x];
+        const uint32_t i0 = blockIdx.y * 256u + wv * 64u;
+        for (uint32_t i = i0; i < v.len && i < i0 + 64u; i++) {
+            const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
+            float s0, s1;
+            lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)v.b * d, d, lane, param, s0, s1);
+            if (lane == 0) ap.ex_keys[(size_t)ev.y + i] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[v.b] : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void exact_visit_kernel(const ZhVisit *__restrict__ visits, const uint32_t *__restrict__ leaf_ids, ZhApprox ap) {
     __shared__ uint64_t sk[2048];
     __shared__ __attribute__((aligned(16))) uint32_t si[2048];
     __shared__ uint32_t s_u32[8];
     __shared__ uint64_t s_red[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t total = ap.ctl[0] < ap.ex_cap ? ap.ctl[0] : ap.ex_cap;
-    if (ap.ctl[0] > ap.ex_cap) return;  // the table ran over (flagged by select_interval): the batch is redone
+    if (ap.ctl[0] > ap.ex_cap) return;
+    const uint32_t total = ap.ctl[0];
     for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {  // block-uniform
-        const ZhVisit v = visits[ap.ex_visits[e]];
-        __syncthreads();
-        if (tid == 0) s_u32[5] = atomicAdd(&ap.ctl[2], v.len);
-        __syncthreads();
-        const uint32_t eb = s_u32[5];
-        if ((uint64_t)eb + v.len > ap.ex_rows_cap) {
-            if (tid == 0) atomicOr(&ap.ctl[1], 8u);
-            continue;
-        }
-        for (uint32_t i = wv; i < v.len; i += 4) {
-            const uint32_t id = leaf_ids[(size_t)v.leaf_off + i];
-            float s0, s1;
-            lane_sums_generic<KIND>(X + (size_t)id * d, Q + (size_t)v.b * d, d, lane, param, s0, s1);
-            if (lane == 0) ap.ex_keys[(size_t)eb + i] = key_of(metric, param, s0, s1, KIND == K_COS ? QQ[v.b] : 0.f);
-        }
+        const uint2 ev = ap.ex_visits[e];
+        if (ev.x == 0xFFFFFFFFu) continue;
+        const ZhVisit v = visits[ev.x];
+        const uint32_t eb = ev.y;
         __syncthreads();
         ZhVisit v2 = v;
         v2.row_off = eb; v2.cand_off = eb;
@@ -1010,8 +1020,9 @@ hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, 
 template <int KIND>
 static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, const ZhApprox &ap,
-                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
-    hipLaunchKernelGGL(exact_visit_kernel<KIND>, dim3(1024), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint32_t max_leaf_len, hipStream_t s) {
+    hipLaunchKernelGGL(exact_keys_kernel<KIND>, dim3(512, (max_leaf_len + 255) / 256), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
+    hipLaunchKernelGGL(exact_visit_kernel, dim3(1024), dim3(256), 0, s, dVisits, dLeafIds, ap);
 #define ZH_APX_FIN(DD, LC) \
     hipLaunchKernelGGL((final_interval_kernel<DD, KIND, LC>), dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds, \
                        dOutKeys, dOutCounts)
@@ -1031,11 +1042,12 @@ static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uin
 
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
-                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s) {
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint32_t max_leaf_len, hipStream_t s) {
     if (!B) return hipSuccess;
+    if (max_leaf_len == 0) max_leaf_len = 1;
     if (metric == ZH_COSINE)
-        launch_final_interval_k<K_COS>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, s);
+        launch_final_interval_k<K_COS>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, max_leaf_len, s);
     else
-        launch_final_interval_k<K_L2>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, s);
+        launch_final_interval_k<K_L2>(dVisits, dX, d, dQ, dQQ, B, k, dLeafIds, metric, mode, id_base, ap, dOutIds, dOutKeys, dOutCounts, max_leaf_len, s);
     return hipGetLastError();
 }

@@ -225,7 +225,7 @@ struct ZhApprox {
     uint32_t capq;
     uint32_t *tauv;          // per visit: the take-th smallest hi (sortable) of a visit that takes top_k rows of a longer leaf
     uint32_t *qtau;          // per query: the smallest of them -- top_k candidates of the query have keys at or below it
-    uint32_t *ex_visits;     // indices of the visits for the exact path
+    uint2 *ex_visits;        // the visits for the exact path: {index, their slice of the key scratch}
     uint32_t ex_cap;
     uint64_t *ex_keys, *ex_ckeys;  // their rows' canonical keys; the `take` chosen
     uint32_t *ex_cids;
@@ -245,7 +245,7 @@ hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, 
 // the exact visits, then per query: duplicates out, tau, the survivors' canonical keys, top_k
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
-                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, hipStream_t s);
+                                    uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint32_t max_leaf_len, hipStream_t s);
 
 // ---- launchers (zh_score.hip): every sign of a forest built from stored rows, from N row scores per query --------
 // Prefilter (zh_search.hip, "Prefilter"): a batch hashed from row scores picks the rows that can be among a pair's k best from
