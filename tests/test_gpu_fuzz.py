@@ -42,7 +42,7 @@ def test_fuzz_config(seed):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
     ix.set_dense_levels(int(rng.choice([-1, -1, 0, 1, 3, 64])))
-    ix.set_sweep_mode(str(rng.choice(["auto", "leaf", "scan"])))  # (scan falls back to leaf where it has no kernel: odd d)
+    ix.set_sweep_mode(str(rng.choice(["auto", "leaf", "scan", "approx"])))  # (scan / approx fall back where they have no kernel: odd d, other metrics)
     f = zo.Forest.build(X, M, T, seed=seed)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
     mets = _metrics(za, rng)
@@ -171,3 +171,53 @@ def test_fuzz_prefilter_was_exercised():
     if not _pf_seen:
         pytest.skip("no prefilter seeds ran in this process")
     assert sum(1 for s_ in _pf_seen if s_ >= 2) >= 0.6 * len(_pf_seen), _pf_seen
+
+
+_afirst, _acount = (int(x) for x in os.environ.get("ZH_FUZZ_APPROX_SEEDS", "0:16").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_afirst, _afirst + _acount))
+def test_fuzz_half_width_scan(seed):
+    """the table scan with half-width queries (zh_approx.hip) forced wherever it is implemented: every dimension it has a kernel for,
+    leaves from far below to far above top_k (backup visits -> the exact path), duplicates and integer rows (ties at every cut), rows and
+    queries scaled by large powers of two (the per-query fp16 scale), all four simsimd-path keys.  ZH_FUZZ_APPROX_SEEDS=first:count soaks."""
+    import zebra_amd as za
+    rng = np.random.default_rng(77000 + seed)
+    d = int(rng.choice([128, 256, 384, 512, 768, 1024]))
+    n = int(rng.integers(300, 7000))
+    M = int(rng.choice([12, 40, 150, 600, 3000, 9000]))
+    T = int(rng.choice([1, 3, 6, 15, 16]))
+    k = int(rng.choice([1, 5, 10, 50, 100, 256]))
+    B = int(rng.integers(1, 48))
+    kind = int(rng.choice([0, 0, 1, 2]))
+    X = zo.synth_rows(n, d, seed=seed, kind=kind)
+    Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
+    if rng.random() < 0.4:
+        X[rng.integers(0, n, 8)] = X[0]
+    if rng.random() < 0.3:  # small integers: exact ties everywhere
+        X = np.round(X).astype(np.float32)
+        Q = np.round(Q).astype(np.float32)
+    if rng.random() < 0.3:  # a large power-of-two scale on everything (norms near the f32 range's ends stay finite at 2^+-40)
+        sc = np.float32(2.0 ** int(rng.choice([-40, -20, 20, 40])))
+        X, Q = X * sc, Q * sc
+    if rng.random() < 0.2:
+        Q[0] = X[int(rng.integers(0, n))]
+    if rng.random() < 0.2:
+        Q[B - 1] = 0.0
+    f = zo.Forest.build(X, M, T, seed=seed)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
+    ix.add(X)
+    assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    used = 0
+    for m, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
+                         (za.CosineDistance(False), zo.COSINE, zo.CORRECTED)):
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        used += ix.stats()["approx_scan"]
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), (seed, d, n, M, T, k, om, omode)
+        for b in range(B):
+            c = int(oc[b])
+            assert (keys[b, :c] == ok[b, :c]).all() and (ids[b, :c] == oi[b, :c]).all(), (seed, d, n, M, T, k, om, omode, b)
+    ix.close()
