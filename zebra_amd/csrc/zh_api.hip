@@ -1360,8 +1360,8 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
     if (off || mode == 2 || mode == 1) return false;
     if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0 || B >= (1u << 24)) return false;  // (24 bits of a packed pair record)
     if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
-    // by itself only where it pays: its per-pair cost is half the f32 scan's, its per-row cost higher (cfg3: 0.057 against 0.118 ns per
-    // pair, 0.74 against 0.52 ns per stored row, + the interval stages): from ~5 pairs per stored row on
+    // by itself only where it pays: per pair it moves half the bytes, but a window of ONE cfg3 batch (4.3 pairs per stored row) gains 4 % on
+    // the scan (3.28 against 3.42 ms per launch) and pays more than that for the interval stages: from ~5 pairs per stored row on
     if (mode != 4 && (ix->approx_strikes.load() >= 2 || !zh_approx_pays(ix->opt.dim) || tot.rows < 5 * ix->n_rows)) return false;
     return true;
 }
@@ -1830,7 +1830,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     HIPCHK(hipEventRecord(c->ev[3], s));
     const uint32_t *run_if = nullptr;
     if (c->approx) {
-        HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, s));
+        HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, c->metric, c->mode, d, s));
         HIPCHK(hipEventRecord(c->ev[4], s));
         HIPCHK(zh_launch_final_interval(c->wVisits.as<ZhVisit>(), ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), (uint32_t)B, (uint32_t)k,
                                         f.leaf_ids, c->metric, c->mode, ix->opt.id_base, ap, dOutIds, dOutKeys, dOutCounts, ix->max_leaf_len, s));

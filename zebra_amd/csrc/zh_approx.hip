@@ -252,16 +252,22 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(X);
     // finished sums wait in lane registers -- group g's result of step n in lane g * LG + n -- so that the interval arithmetic and
     // the stores run for 64 pairs at once
+    // ... and what is stored is the RAW pair {x . h, |x|^2}: the interval arithmetic needs four constants of the pair's QUERY, a 16-byte
+    // gather per pair here (one more L1-miss line per pair, 6 % of the kernel's requests) but ONE load per visit in select_tau_kernel,
+    // which turns a visit's raw pairs into intervals in place before it ranks them
     float my_s = 0.f, my_a2 = 0.f;
     uint64_t my_slot = 0;
-    uint32_t my_b = 0, nst = 0;
+    uint32_t nst = 0;
     bool my_on = false;
     auto flush = [&]() {
-        if (my_on) __builtin_nontemporal_store(approx_interval<KINDA>(my_s, my_a2, qmeta[my_b], Kc), iv + my_slot);
+        if (my_on) __builtin_nontemporal_store(((uint64_t)__float_as_uint(my_a2) << 32) | __float_as_uint(my_s), iv + my_slot);
         my_on = false;
         nst = 0;
     };
     auto load_q = [&](uint32_t b, uint4 *hq) {
+#ifdef ZH_APX_EXP_Q_L1   // timing experiment (results invalid): eight queries only -> the query loads hit the vector L1
+        b &= 7u;
+#endif
         const uint4 *qp = Qh + (size_t)b * (D / 8) + l;
 #pragma unroll
         for (int i = 0; i < NH; i++) hq[i] = qp[i * LG];
@@ -284,7 +290,11 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
                 v[2 * j + 1] = make_float4(__uint_as_float(sx[1]), __uint_as_float(sy[1]), __uint_as_float(sz[1]), __uint_as_float(sw[1]));
             }
         } else {
+#ifdef ZH_APX_EXP_ROWS_L2   // timing experiment (results invalid): every row from a 3-MB region -> L2 hits instead of HBM reads
+            const float4 *r4 = X4 + (size_t)(row & 1023) * (D / 4) + l;
+#else
             const float4 *r4 = X4 + (size_t)row * (D / 4) + l;
+#endif
 #pragma unroll
             for (int j = 0; j < NR; j++) v[j] = ld16<true>(r4 + LG * j);
         }
@@ -312,8 +322,8 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
         }
         return group_sum<LG>((ax + ay) + (az + aw));
     };
-    auto stash = [&](float s, float a2, uint32_t b, uint64_t slot, bool valid) {
-        if (l == nst) { my_s = s; my_a2 = a2; my_b = b; my_slot = slot; my_on = valid; }
+    auto stash = [&](float s, float a2, uint32_t, uint64_t slot, bool valid) {
+        if (l == nst) { my_s = s; my_a2 = a2; my_slot = slot; my_on = valid; }
         if (++nst == (uint32_t)LG) flush();
     };
     if (P <= ZH_APX_CAP) {
@@ -498,10 +508,10 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
     }
     float my_s = 0.f;
     uint64_t my_slot = 0;
-    uint32_t my_b = 0, my_row = 0, nst = 0;
+    uint32_t my_row = 0, nst = 0;
     bool my_on = false;
-    auto flush = [&]() {
-        if (my_on) __builtin_nontemporal_store(approx_interval<KINDA>(my_s, a2_lds[wid][my_row], qmeta[my_b], Kc), iv + my_slot);
+    auto flush = [&]() {  // the raw pair {x . h, |x|^2}: select_tau_kernel makes the interval (see scan_approx_kernel)
+        if (my_on) __builtin_nontemporal_store(((uint64_t)__float_as_uint(a2_lds[wid][my_row]) << 32) | __float_as_uint(my_s), iv + my_slot);
         my_on = false;
         nst = 0;
     };
@@ -514,8 +524,8 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
         az = __builtin_fmaf(v1.z, (float)h[6], az); aw = __builtin_fmaf(v1.w, (float)h[7], aw);
         return group_sum<LG>((ax + ay) + (az + aw));
     };
-    auto stash = [&](float s, uint32_t row, uint32_t b, uint64_t slot, bool valid) {
-        if (l == nst) { my_s = s; my_row = row; my_b = b; my_slot = slot; my_on = valid; }
+    auto stash = [&](float s, uint32_t row, uint32_t, uint64_t slot, bool valid) {
+        if (l == nst) { my_s = s; my_row = row; my_slot = slot; my_on = valid; }
         if (++nst == (uint32_t)LG) flush();
     };
     auto pack = [](uint32_t rl, uint32_t b, uint64_t slot) { return slot | ((uint64_t)b << 36) | ((uint64_t)rl << 60); };
@@ -687,8 +697,9 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
 
 // pass 1: per visit that takes top_k of a longer leaf, tau = the take-th smallest hi (top_k rows of the visit have keys at or
 // below it); the smallest tau of a query's visits bounds the query's top_k-th key as well (those rows are candidates)
+template <int KINDA>
 __global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t chunk,
-                                                          uint32_t k_top, ZhApprox ap) {
+                                                          uint32_t k_top, float Kc, ZhApprox ap) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_u[8];
     const uint32_t tid = threadIdx.x;
@@ -696,6 +707,15 @@ __global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restri
     const uint32_t cnt = (uint32_t)(n_visits - base < chunk ? n_visits - base : chunk);
     for (uint32_t c = 0; c < cnt; c++) {  // block-uniform
         const ZhVisit v = visits[base + c];
+        if (v.take) {  // the scan's raw pairs {x . h, |x|^2} of this visit -> intervals, in place (one load of the query's constants per visit)
+            const float4 qm = ap.qmeta[v.b];
+            uint64_t *__restrict__ raw = ap.iv + v.row_off;
+            for (uint32_t i = tid; i < v.len; i += 256) {
+                const uint64_t w = raw[i];
+                raw[i] = approx_interval<KINDA>(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)), qm, Kc);
+            }
+            __syncthreads();
+        }
         uint32_t tau = 0xFFFFFFFFu;
         if (v.take && v.take < v.len) {
             if (v.take < k_top) {  // membership matters (see the header of this file): the exact path
@@ -1006,13 +1026,19 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
 }
 
 hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, const uint32_t *dLeafIds, ZhApprox ap,
-                                     hipStream_t s) {
+                                     int metric, int mode, uint32_t d, hipStream_t s) {
     if (!n_visits) return hipSuccess;
     if (n_visits > 0x7FFFFFFFull) return hipErrorInvalidValue;
     uint64_t chunk = (n_visits + 16383) / 16384;
     if (chunk > 256) chunk = 256;
     const uint64_t blocks = (n_visits + chunk - 1) / chunk;
-    hipLaunchKernelGGL(select_tau_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, ap);
+    const float Kc = zh_approx_bound(metric, d);
+    if (metric != ZH_COSINE)
+        hipLaunchKernelGGL(select_tau_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, Kc, ap);
+    else if (mode == ZH_COSINE_PARITY)
+        hipLaunchKernelGGL(select_tau_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, Kc, ap);
+    else
+        hipLaunchKernelGGL(select_tau_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, Kc, ap);
     hipLaunchKernelGGL(select_emit_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, dLeafIds, ap);
     return hipGetLastError();
 }

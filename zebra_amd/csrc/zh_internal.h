@@ -219,7 +219,8 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
 struct ZhApprox {
     const void *Qh;          // the fp16 copy of the batch's queries (2 * d bytes each, qhalf_kernel's layout)
     const float4 *qmeta;     // per query {1 / sigma, |q|^2, upper estimate of |q|, upper estimate of |q - h / sigma|}
-    uint64_t *iv;            // per (row, query) pair, in the pair's key slot: sortable lo | sortable hi << 32
+    uint64_t *iv;            // per (row, query) pair, in the pair's key slot: from the scan {x . h, |x|^2} (f32 bits); select_tau_kernel
+                             // turns a visit's entries into sortable lo | sortable hi << 32 in place
     uint32_t *list_lo, *list_hi, *list_id;  // per query: capq slots
     uint32_t *qcount;
     uint32_t capq;
@@ -241,7 +242,7 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
                                  const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
                                  int mode, hipStream_t s);
 hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, const uint32_t *dLeafIds, ZhApprox ap,
-                                     hipStream_t s);
+                                     int metric, int mode, uint32_t d, hipStream_t s);
 // the exact visits, then per query: duplicates out, tau, the survivors' canonical keys, top_k
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
                                     uint32_t k, const uint32_t *dLeafIds, int metric, int mode, uint64_t id_base, ZhApprox ap,
