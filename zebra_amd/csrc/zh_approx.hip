@@ -32,10 +32,14 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // groups per wave by dimension (0: not supported -> exact scan): every lane loads NH = d * G / 512 dwordx4 of halves per pair
+#ifndef ZH_APX_G768
+#define ZH_APX_G768 2   // A/B: 4 = four 16-lane groups at d = 768 (48 row registers per lane)
+#endif
 uint32_t zh_approx_groups(uint32_t d) {
     switch (d) {
     case 128: case 256: case 384: return 4;
-    case 512: case 768: case 1024: return 2;
+    case 768: return ZH_APX_G768;
+    case 512: case 1024: return 2;
     default: return 0;
     }
 }
@@ -650,7 +654,7 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
     case 256: return launch_scan_approx_d<256, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     case 384: return launch_scan_approx_d<384, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     case 512: return launch_scan_approx_d<512, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
-    case 768: return launch_scan_approx_d<768, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
+    case 768: return launch_scan_approx_d<768, ZH_APX_G768>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     case 1024: return launch_scan_approx_d<1024, 2>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
     default: return hipErrorInvalidValue;
     }
