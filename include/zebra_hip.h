@@ -420,7 +420,14 @@ ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
  * (query, tree) the visited leaves' rows are judged on their scores with a rigorous rounding bound -- which `take` rows a leaf
  * hands over (lsh.rs:300-330), and which of those can still be among the k nearest -- and only the survivors, plus every visit the
  * bound cannot decide, are scored with the reference's arithmetic; ids, keys and counts stay bit-identical.  Modes 1 and 2 always
- * sweep.  (max_node_size <= 8 and no leaf longer than 64 rows, top_k <= 64, forests built by this library.) */
+ * sweep.  (max_node_size <= 8 and no leaf longer than 64 rows, top_k <= 64, forests built by this library.)
+ * The table scan of mode 0 reads HALF-WIDTH (fp16) copies of the queries where that pays (L2 / L2^2 / cosine keys, dim 384 / 512 /
+ * 768 / 1024, top_k <= 256, five or more scored (row, query) pairs per stored row): 2 * dim instead of 4 * dim bytes per pair, an
+ * INTERVAL per pair that contains the reference's key (the fp16 rounding measured per query, every f32 rounding bounded), the
+ * candidates picked on the intervals and only the rows they cannot rule out scored with the reference's arithmetic -- ids, keys
+ * and counts stay bit-identical.  A list that runs over is redone by the f32 scan on the device, in stream order (no host round
+ * trip: safe for callers that consume results in stream order).  Mode 2 keeps the f32 scan; 4 = the half-width scan wherever it
+ * is implemented (dim 128 ... 1024), whatever the cost model says.  zh_stats_t::approx_* report it. */
 ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
 /* How a batch that needs EVERY sign of the forest (small leaves: the reference's default max_node_size 5) gets them:
  * 1 = one dot product per (query, plane), 2 * b * planes * dim flop on the matrix cores; 2 = from row scores: a plane is built from
