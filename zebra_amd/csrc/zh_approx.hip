@@ -35,9 +35,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef ZH_APX_G768
 #define ZH_APX_G768 2   // A/B: 4 = four 16-lane groups at d = 768 (48 row registers per lane)
 #endif
+#ifndef ZH_APX_G128
+#define ZH_APX_G128 8   // A/B: 4 = 16-lane groups at d = 128
+#endif
 uint32_t zh_approx_groups(uint32_t d) {
     switch (d) {
-    case 128: case 256: case 384: return 4;
+    case 128: return ZH_APX_G128;
+    case 256: case 384: return 4;
     case 768: return ZH_APX_G768;
     case 512: case 1024: return 2;
     default: return 0;
@@ -115,19 +119,20 @@ __global__ __launch_bounds__(64) void qhalf_kernel(const float *__restrict__ Q, 
 hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s) {
     if (!B) return hipSuccess;
     const uint32_t G = zh_approx_groups(d);
-    if (G == 4) hipLaunchKernelGGL(qhalf_kernel<4>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    if (G == 8) hipLaunchKernelGGL(qhalf_kernel<8>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    else if (G == 4) hipLaunchKernelGGL(qhalf_kernel<4>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 2) hipLaunchKernelGGL(qhalf_kernel<2>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-// sum over the LG lanes of a group (LG = 16, 32 or 64): the first steps of the canonical butterfly
+// sum over the LG lanes of a group (LG = 8, 16, 32 or 64): the first steps of the canonical butterfly
 template <int LG>
 __device__ __forceinline__ float group_sum(float s) {
     s = s + dpp_mov<0xB1>(s);
     s = s + dpp_mov<0x4E>(s);
     s = s + dpp_mov<0x141>(s);
-    s = s + dpp_mov<0x140>(s);
+    if (LG >= 16) s = s + dpp_mov<0x140>(s);
     if (LG >= 32) s = xor16<OpAdd>(s);
     if (LG >= 64) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
@@ -461,16 +466,18 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
 // ---- d = 128 (SIFT-style shards, cfg5): a row or a query is ONE 16-lane group's worth (8 elements per lane), and a stored row is
 // wanted by only 3-6 queries of a window -- four groups on the same row (the kernel above) would idle half the wave.  Here the
 // wave's 16 consecutive rows (8 KB, contiguous in memory: eight coalesced 1-KiB loads) wait in LDS and every group takes ANY pair
-// of the wave's list: per step four pairs, each with its own row (two conflict-free ds_read_b128) and its own query (one
-// dwordx4 of halves per lane), eight v_fma_mix_f32, four DPP adds.  Same intervals, same stages behind it.
-template <int KINDA>
+// of the wave's list: per step G pairs, each with its own row (ds_read_b128 from the wave's LDS copy) and its own query (dwordx4
+// loads of halves), v_fma_mix_f32, a short DPP reduce.  G = 8 (8-lane groups, 16 elements per lane: two query loads, four row reads,
+// sixteen fma, three DPP adds per EIGHT pairs) halves the per-pair share of everything that is not arithmetic -- record, addresses,
+// reduce, stash -- which is what this kernel's time is (21 VALU per pair at G = 4 for 2 of arithmetic).  Same intervals, same stages behind it.
+template <int G, int KINDA>
 __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__restrict__ X, const uint4 *__restrict__ Qh,
                                                               const float4 *__restrict__ qmeta, const uint2 *__restrict__ rowLeaf,
                                                               uint32_t T, uint32_t RW, const uint32_t *__restrict__ visitBits,
                                                               const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
                                                               uint32_t GRP, uint64_t row_begin, uint64_t row_end, float Kc,
                                                               uint64_t *__restrict__ iv) {
-    constexpr int LG = 16, G = 4;
+    constexpr int LG = 64 / G, NH = G / 4, NR = 2 * NH;  // G = 4: 16-lane groups, 8 elements per lane; G = 8: 8-lane groups, 16 per lane
     // pair records packed into 8 bytes (interval slot: 36 bits | query: 24 bits | row of the wave: 4 bits) and a list of 240: 40 KB of
     // LDS per block with the rows, four blocks per CU
     constexpr uint32_t CAP = 240;
@@ -501,12 +508,11 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {  // group g: rows g, g + 4, g + 8, g + 12
-        const uint32_t row = g + 4u * rr;
-        const float4 v0 = row_lds[wid][row * 32 + l], v1 = row_lds[wid][row * 32 + 16 + l];
+    for (int rr = 0; rr < 16 / G; rr++) {  // group g: rows g, g + G, ...
+        const uint32_t row = g + (uint32_t)G * rr;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        sq4(v0, c);
-        sq4(v1, c);
+#pragma unroll
+        for (int j = 0; j < NR; j++) sq4(row_lds[wid][row * 32 + LG * j + l], c);
         const float a2 = group_sum<LG>((c.x + c.y) + (c.z + c.w));
         if (l == 0) a2_lds[wid][row] = a2;
     }
@@ -519,13 +525,24 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
         my_on = false;
         nst = 0;
     };
-    auto dot8 = [&](const float4 &v0, const float4 &v1, const uint4 &hq) {
-        f16x8 h;
-        __builtin_memcpy(&h, &hq, 16);
-        float ax = __builtin_fmaf(v0.x, (float)h[0], 0.f), ay = __builtin_fmaf(v0.y, (float)h[1], 0.f);
-        float az = __builtin_fmaf(v0.z, (float)h[2], 0.f), aw = __builtin_fmaf(v0.w, (float)h[3], 0.f);
-        ax = __builtin_fmaf(v1.x, (float)h[4], ax); ay = __builtin_fmaf(v1.y, (float)h[5], ay);
-        az = __builtin_fmaf(v1.z, (float)h[6], az); aw = __builtin_fmaf(v1.w, (float)h[7], aw);
+    struct Ops { float4 v[NR]; uint4 hq[NH]; };  // a pair's operands in a lane: its slice of the row (from LDS) and of the query's halves
+    auto fetch = [&](uint32_t row, uint32_t b, Ops &o) {
+#pragma unroll
+        for (int i = 0; i < NH; i++) o.hq[i] = Qh[(size_t)b * 16 + i * LG + l];
+#pragma unroll
+        for (int j = 0; j < NR; j++) o.v[j] = row_lds[wid][row * 32 + LG * j + l];
+    };
+    auto dot8 = [&](const Ops &o) {
+        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            f16x8 h;
+            __builtin_memcpy(&h, &o.hq[i], 16);
+            ax = __builtin_fmaf(o.v[2 * i].x, (float)h[0], ax); ay = __builtin_fmaf(o.v[2 * i].y, (float)h[1], ay);
+            az = __builtin_fmaf(o.v[2 * i].z, (float)h[2], az); aw = __builtin_fmaf(o.v[2 * i].w, (float)h[3], aw);
+            ax = __builtin_fmaf(o.v[2 * i + 1].x, (float)h[4], ax); ay = __builtin_fmaf(o.v[2 * i + 1].y, (float)h[5], ay);
+            az = __builtin_fmaf(o.v[2 * i + 1].z, (float)h[6], az); aw = __builtin_fmaf(o.v[2 * i + 1].w, (float)h[7], aw);
+        }
         return group_sum<LG>((ax + ay) + (az + aw));
     };
     auto stash = [&](float s, uint32_t row, uint32_t, uint64_t slot, bool valid) {
@@ -553,20 +570,20 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // four pairs per step, the next step's records, queries and rows requested before the current step is computed
+        // G pairs per step, the next step's records, queries and rows requested before the current step is computed
         auto r_row = [](uint64_t r) { return (uint32_t)(r >> 60); };
         auto r_b = [](uint64_t r) { return (uint32_t)(r >> 36) & 0xFFFFFFu; };
         uint64_t rec = list[g < P ? g : P - 1];
-        uint4 hq = Qh[(size_t)r_b(rec) * 16 + l];
-        float4 v0 = row_lds[wid][r_row(rec) * 32 + l], v1 = row_lds[wid][r_row(rec) * 32 + 16 + l];
+        Ops cur;
+        fetch(r_row(rec), r_b(rec), cur);
         for (uint32_t p = 0; p < P; p += G) {
             const uint32_t pn = p + G + g;
             const uint64_t recn = list[pn < P ? pn : P - 1];
-            const uint4 hqn = Qh[(size_t)r_b(recn) * 16 + l];
-            const float4 v0n = row_lds[wid][r_row(recn) * 32 + l], v1n = row_lds[wid][r_row(recn) * 32 + 16 + l];
-            const float s = dot8(v0, v1, hq);
+            Ops nxt;
+            fetch(r_row(recn), r_b(recn), nxt);
+            const float s = dot8(cur);
             stash(s, r_row(rec), r_b(rec), rec & 0xFFFFFFFFFull, p + g < P);
-            rec = recn; hq = hqn; v0 = v0n; v1 = v1n;
+            rec = recn; cur = nxt;
         }
     } else {
         // more pairs than the list holds (hot leaves): entry after entry, a leaf's visits four at a time
@@ -580,13 +597,13 @@ __global__ __launch_bounds__(256) void scan_approx128_kernel(const float *__rest
                 const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], ll);
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], ll);
                 const uint32_t rl = ((uint32_t)ll + 64u * j) / T;
-                const float4 v0 = row_lds[wid][rl * 32 + l], v1 = row_lds[wid][rl * 32 + 16 + l];
                 for (uint32_t s0 = 0; s0 < c; s0 += G) {
                     const uint32_t sidx = s0 + g < c ? s0 + g : c - 1;
                     const ZhGroup *gp = groups + gb + sidx / GRP;
                     const uint32_t b = gp->b[sidx % GRP];
-                    const uint4 hq = Qh[(size_t)b * 16 + l];
-                    const float s = dot8(v0, v1, hq);
+                    Ops o;
+                    fetch(rl, b, o);
+                    const float s = dot8(o);
                     stash(s, rl, b, gp->key_off[sidx % GRP] + w, s0 + g < c);
                 }
             }
@@ -630,8 +647,6 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
     if (!n_rows) return hipSuccess;
     switch (d) {
     case 128: {
-        static const bool generic = getenv("ZH_APX128_GENERIC") != nullptr;  // A/B: the four-groups-on-one-row kernel at d = 128
-        if (generic) return launch_scan_approx_d<128, 4>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, metric, mode, s);
         const uint32_t RW = zh_scan_rows_per_wave(T);
         uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
         rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
@@ -642,7 +657,7 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
             const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
             if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 #define ZH_APX_LAUNCH(KA) \
-            hipLaunchKernelGGL((scan_approx128_kernel<KA>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, (const uint4 *)ap.Qh, ap.qmeta, dRowLeaf, T, RW, \
+            hipLaunchKernelGGL((scan_approx128_kernel<ZH_APX_G128, KA>), dim3((uint32_t)blocks), dim3(256), 0, s, dX, (const uint4 *)ap.Qh, ap.qmeta, dRowLeaf, T, RW, \
                                dVisitBits, dNodeVisit, dGroups, group, r, r_end, Kc, ap.iv)
             if (kinda == 0) ZH_APX_LAUNCH(0);
             else if (kinda == 1) ZH_APX_LAUNCH(1);
