@@ -151,6 +151,12 @@ def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch):
         st = check(ix, f, Q, k, m, om, omode, caps)
         assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 1 and (st["approx_last_overflow"] & bit), (caps, st)
         seen += 1
+    # the 8192-slot lists an index gets after an overflow (final_interval_kernel's larger variant), all four keys
+    monkeypatch.setenv("ZH_APX_CAPS", "8192,0,0")
+    for mm, omm, omo in all_metrics(za):
+        ix.stats(reset=True)
+        st = check(ix, f, Q, k, mm, omm, omo, "8192 slots")
+        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
     monkeypatch.delenv("ZH_APX_CAPS")
     ix.stats(reset=True)
     st = check(ix, f, Q, k, m, om, omode)  # mode 4 keeps trying after strikes
