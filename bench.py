@@ -149,7 +149,7 @@ def parse():
                          "own streams and run beside the current window's walk / sweep)")
     ap.add_argument("--window", type=int, default=None,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
-    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx"], default="auto",
+    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx", "approx-valu"], default="auto",
                     help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
@@ -518,6 +518,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         kname = "sweep128_kernel<%d, ...>" % kind  # the half-wave kernel of the 512-byte rows
     if half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
+        if st.get("approx_scan", 0) == 2:
+            kname = "scan_mfma_kernel<%d>" % d  # the same scan on the matrix cores, from the index's fp16 copy of the stored rows
     s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
               "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
@@ -563,8 +565,10 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # tree that wants it: those bytes are not bytes this kernel moves.
         stored = st["swept_rows_accum"] / n_launch
         qb = 2.0 * d if half else 4.0 * d  # bytes of one query as the scan reads it: fp16 copy (round 4) or f32
-        l2_bytes = qb * rows_per_launch + 4.0 * d * stored
-        by_design = stored * (4.0 * d + 8.0 * T) + 8.0 * rows_per_launch + qb * B / launches_per_batch
+        mfma = half and st.get("approx_scan", 0) == 2  # ... on the matrix cores, from the index's fp16 copy of the stored rows
+        rb = 2.0 * d + 8.0 if mfma else 4.0 * d        # bytes of one stored row as the scan reads it (fp16 copy + {|x|^2, 1 / scale})
+        l2_bytes = qb * rows_per_launch + rb * stored
+        by_design = stored * (rb + 8.0 * T) + 8.0 * rows_per_launch + qb * B / launches_per_batch
         l2_GBps = l2_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
         roof = {"bound": "l2", "achieved": l2_GBps, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_GBps / L2_GATHER_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": l2_bytes,
@@ -578,11 +582,15 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                 "frac_of_measured_l2_gather": [l2_GBps / L2_GATHER_MEASURED_GBS[0], l2_GBps / L2_GATHER_MEASURED_GBS[1]],
                 "measured_l2_gather_note": "the bare register gather of the same shape from a 6-MB / 3-MB table with nothing else running "
                                            "(profiles/micro/gather512.hip): the measured ceiling, above the guide's 16.8-18.8 TB/s quoted as `peak`",
-                "query_bytes_per_pair": qb,
+                "query_bytes_per_pair": qb, "row_bytes_per_stored_row": rb,
                 "s8d_equivalent_GBps": s8d_GBps, "s8d_bytes_per_launch": bytes_alg,
                 "s8d_note": "SURVEY s8(d) numerator / launch time: comparable with the leaf-major sweep, NOT a roofline fraction (a stored row "
                             "is read once for every tree that wants it)",
-                "sweep_mode": ("table scan with HALF-WIDTH queries: stored rows (f32) streamed once per batch window, each scored against the fp16 "
+                "sweep_mode": ("table scan with HALF-WIDTH operands on the matrix cores: the index's fp16 copy of the stored rows (2*d bytes per row, "
+                               "in the MFMA operand's order) streamed once per batch window, 16 rows x 16 (row, query) pairs per v_mfma_f32_16x16x32_f16 "
+                               "tile, each pair's query halves (2*d bytes) from L2 -> an interval per pair; the intervals pick the candidates and only "
+                               "the survivors get the reference's key from the f32 rows (zh_approx.hip)") if mfma else
+                              ("table scan with HALF-WIDTH queries: stored rows (f32) streamed once per batch window, each scored against the fp16 "
                                "copy of every query that visits one of its leaves (2*d bytes per pair from L2) -> an interval per pair; the intervals "
                                "pick the candidates and only the survivors get the reference's key (zh_approx.hip)") if half else
                               ("table scan: stored rows streamed once per batch window, each scored against every query that visits one of "

@@ -156,7 +156,8 @@ typedef struct zh_stats_t {
                                          * visits to score exactly, 8 a leaf longer than 64 rows, 16 a query's lists together hold more than the final sort */
     uint64_t approx_scan;           /* 1: the most recent batch's table scan read HALF-WIDTH (fp16) copies of the queries: every (row, query)
                                      * pair got an interval that contains the reference's key, the intervals picked the candidates, and only
-                                     * the rows they could not rule out were scored with the reference's arithmetic (zh_set_sweep_mode) */
+                                     * the rows they could not rule out were scored with the reference's arithmetic (zh_set_sweep_mode);
+                                     * 2: the same with the products on the matrix cores, from the index's fp16 copy of the stored rows */
     uint64_t approx_exact_visits;   /* ... leaf visits that take fewer than top_k rows: scored and ranked exactly */
     uint64_t approx_survivors;      /* ... rows (over all queries) that got the reference's key for the final top_k */
     uint64_t approx_list_entries;   /* ... candidates handed to the per-query stage (before de-duplication) */
@@ -421,13 +422,16 @@ ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
  * hands over (lsh.rs:300-330), and which of those can still be among the k nearest -- and only the survivors, plus every visit the
  * bound cannot decide, are scored with the reference's arithmetic; ids, keys and counts stay bit-identical.  Modes 1 and 2 always
  * sweep.  (max_node_size <= 8 and no leaf longer than 64 rows, top_k <= 64, forests built by this library.)
- * The table scan of mode 0 reads HALF-WIDTH (fp16) copies of the queries where that pays (L2 / L2^2 / cosine keys, dim 384 / 512 /
- * 768 / 1024, top_k <= 256, five or more scored (row, query) pairs per stored row): 2 * dim instead of 4 * dim bytes per pair, an
- * INTERVAL per pair that contains the reference's key (the fp16 rounding measured per query, every f32 rounding bounded), the
- * candidates picked on the intervals and only the rows they cannot rule out scored with the reference's arithmetic -- ids, keys
- * and counts stay bit-identical.  A list that runs over is redone by the f32 scan on the device, in stream order (no host round
- * trip: safe for callers that consume results in stream order).  Mode 2 keeps the f32 scan; 4 = the half-width scan wherever it
- * is implemented (dim 128 ... 1024), whatever the cost model says.  zh_stats_t::approx_* report it. */
+ * The table scan of mode 0 reads HALF-WIDTH (fp16) copies of the queries where that pays (L2 / L2^2 / cosine keys, dim 256 / 384 /
+ * 512 / 768 / 1024, top_k <= 256, two or more scored (row, query) pairs per stored row): 2 * dim instead of 4 * dim bytes per pair, an
+ * INTERVAL per pair that contains the reference's key (the fp16 roundings measured, every f32 rounding bounded), the candidates
+ * picked on the intervals and only the rows they cannot rule out scored with the reference's arithmetic -- ids, keys and counts
+ * stay bit-identical.  With up to 16 trees the products run on the matrix cores from an fp16 copy of the STORED ROWS that the
+ * index makes on first use and extends as rows are appended: + 2 * dim + 8 bytes per stored row of device memory (+50 % of the row
+ * table; skipped, and the f32 rows read by a VALU kernel instead, when less than that plus a sixteenth of the device is free).
+ * A list that runs over is redone by the f32 scan on the device, in stream order (no host round trip: safe for callers that
+ * consume results in stream order).  Mode 2 keeps the f32 scan; 4 = the half-width scan wherever it is implemented (dim 128 ...
+ * 1024), whatever the cost model says; 5 = as 4 with the VALU kernel only (no copy of the rows).  zh_stats_t::approx_* report it. */
 ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
 /* How a batch that needs EVERY sign of the forest (small leaves: the reference's default max_node_size 5) gets them:
  * 1 = one dot product per (query, plane), 2 * b * planes * dim flop on the matrix cores; 2 = from row scores: a plane is built from

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Instruction mix and wait counters of the table scan (cfg3, --serial-windows: one window on the GPU at a time), one rocprofv3
 # --pmc pass per group:   gpurun -- bash profiles/pmc_scan_mix.sh      -> gpurun_out/pmc_scan_mix.txt
-# ARGS="<bench.py workload args>" (default: cfg3, 6 steps); KERNEL=<substring of the kernel name> (default: the scan the bench line runs, scan_approx_kernel since round 4; ZH_NO_APPROX=1
+# ARGS="<bench.py workload args>" (default: cfg3, 6 steps); KERNEL=<substring of the kernel name> (default: the scan the bench line runs, scan_mfma_kernel since round 4; ARGS="--sweep-mode approx-valu" KERNEL=scan_approx_kernel for the VALU kernel, ZH_NO_APPROX=1
 # KERNEL=scan_sweep_kernel for the f32 scan)
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-export KERNEL=${KERNEL:-scan_approx_kernel}
+export KERNEL=${KERNEL:-scan_mfma_kernel}
 OUT=gpurun_out/pmc_mix; rm -rf $OUT; mkdir -p $OUT
 args="bench.py ${ARGS:---steps 6 --warmup 2} --cpu-seconds 0 --no-recall --no-other-configs --profile-run --serial-windows"
 i=0

@@ -51,7 +51,7 @@ def launch_classes(cfg_dir):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         k = kname(r["Kernel_Name"])
-        if not any(t in k for t in ("scan_approx", "scan_sweep", "sweep_kernel", "sweep128", "prefilter_kernel", "walk_blocked")):
+        if not any(t in k for t in ("scan_approx", "scan_mfma", "scan_sweep", "sweep_kernel", "sweep128", "prefilter_kernel", "walk_blocked")):
             continue
         grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
         a[k][str(grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

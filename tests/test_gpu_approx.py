@@ -50,25 +50,33 @@ CASES = [
 ]
 
 
+def scan_code(mode, d, T=8):
+    """zh_stats_t::approx_scan of a half-width batch: 2 where the matrix-core kernel runs (scan_mfma_kernel: up to 16 trees; mode 5 keeps the
+    VALU kernel)"""
+    return 2 if mode == "approx" and d in (256, 384, 512, 768, 1024) and T <= 16 else 1
+
+
+@pytest.mark.parametrize("mode", ["approx", "approx-valu"])
 @pytest.mark.parametrize("n,d,M,T,k,B,kind,expect", CASES)
-def test_half_width_scan_equals_oracle(za, n, d, M, T, k, B, kind, expect):
+def test_half_width_scan_equals_oracle(za, n, d, M, T, k, B, kind, expect, mode):
     X = zo.synth_rows(n, d, kind=kind)
     Q = zo.synth_queries(B, d, n, kind=kind)
     f = zo.Forest.build(X, M, T)
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
     ix.add(X)
-    ix.set_sweep_mode("approx")
+    ix.set_sweep_mode(mode)
     ix.set_hash_mode("dense")
     for m, om, omode in all_metrics(za):
         st = check(ix, f, Q, k, m, om, omode)
-        assert st["approx_scan"] == (1 if expect else 0), (om, omode, st)
+        assert st["approx_scan"] == (scan_code(mode, d, T) if expect else 0), (om, omode, st)
         assert st["approx_fallbacks_accum"] == 0, st
         if expect:
             assert st["approx_survivors"] >= min(k, 1) and st["approx_list_entries"] > 0
     ix.close()
 
 
-def test_exact_visits_are_exercised(za):
+@pytest.mark.parametrize("mode", ["approx", "approx-valu"])
+def test_exact_visits_are_exercised(za, mode):
     """leaves shorter than top_k send the walk to backup subtrees with n < top_k (lsh.rs:340-345): those visits must hand over
     exactly their `take` nearest rows -- the exact path of the half-width scan"""
     n, d, M, T, k, B = 6000, 768, 120, 8, 32, 24
@@ -77,12 +85,12 @@ def test_exact_visits_are_exercised(za):
     f = zo.Forest.build(X, M, T)
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
     ix.add(X)
-    ix.set_sweep_mode("approx")
+    ix.set_sweep_mode(mode)
     ix.set_hash_mode("dense")
     seen = 0
     for m, om, omode in all_metrics(za):
         st = check(ix, f, Q, k, m, om, omode)
-        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
+        assert st["approx_scan"] == scan_code(mode, d) and st["approx_fallbacks_accum"] == 0
         seen += st["approx_exact_visits"]
     assert seen > 0
     ix.close()
@@ -106,7 +114,8 @@ def _adversarial_rows(n, d, rng):
     return X
 
 
-def test_adversarial_rows_and_queries(za):
+@pytest.mark.parametrize("mode", ["approx", "approx-valu"])
+def test_adversarial_rows_and_queries(za, mode):
     rng = np.random.default_rng(7)
     n, d, M, T, k, B = 4000, 768, 1024, 6, 50, 40
     X = _adversarial_rows(n, d, rng)
@@ -114,7 +123,7 @@ def test_adversarial_rows_and_queries(za):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
     ix.append(X)
     ix.set_forest(f.arrays())        # (the oracle's forest: a NaN sample row makes a NaN plane, whose payload bits need not agree)
-    ix.set_sweep_mode("approx")
+    ix.set_sweep_mode(mode)          # (the matrix-core kernel rounds the ROWS too: the huge / tiny / non-finite rows get scales out of range)
     Q = zo.synth_queries(B, d, n)
     Q[0] = X[0]                      # a stored row itself: distance 0, its duplicates tie
     Q[1] = X[410]                    # an integer row
@@ -126,11 +135,12 @@ def test_adversarial_rows_and_queries(za):
     # (no NaN / inf QUERY: every key would be a NaN, whose sign bit differs between the host's and the GPU's arithmetic)
     for m, om, omode in all_metrics(za):
         st = check(ix, f, Q, k, m, om, omode, "adversarial")
-        assert st["approx_scan"] == 1
+        assert st["approx_scan"] == scan_code(mode, d)
     ix.close()
 
 
-def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch):
+@pytest.mark.parametrize("mode", ["approx", "approx-valu"])
+def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch, mode):
     """a candidate list, the survivors, the table of exact visits or their key scratch running over raises a flag on the device
     and the f32 scan + select + final enqueued behind redo the batch in stream order: same results, counted in the stats"""
     n, d, M, T, k, B = 8000, 768, 120, 8, 32, 24
@@ -139,29 +149,58 @@ def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch):
     f = zo.Forest.build(X, M, T)
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
     ix.add(X)
-    ix.set_sweep_mode("approx")
+    ix.set_sweep_mode(mode)
+    code = scan_code(mode, d, T)
     ix.set_hash_mode("dense")
     m, om, omode = za.L2Distance(), zo.L2, 0
     st = check(ix, f, Q, k, m, om, omode)
-    assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0 and st["approx_exact_visits"] > 0
+    assert st["approx_scan"] == code and st["approx_fallbacks_accum"] == 0 and st["approx_exact_visits"] > 0
     seen = 0
     for caps, bit in (("64,0,0", 1), ("0,1,0", 4), ("0,0,8", 8)):
         monkeypatch.setenv("ZH_APX_CAPS", caps)
         ix.stats(reset=True)
         st = check(ix, f, Q, k, m, om, omode, caps)
-        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 1 and (st["approx_last_overflow"] & bit), (caps, st)
+        assert st["approx_scan"] == code and st["approx_fallbacks_accum"] == 1 and (st["approx_last_overflow"] & bit), (caps, st)
         seen += 1
     # the 8192-slot lists an index gets after an overflow (final_interval_kernel's larger variant), all four keys
     monkeypatch.setenv("ZH_APX_CAPS", "8192,0,0")
     for mm, omm, omo in all_metrics(za):
         ix.stats(reset=True)
         st = check(ix, f, Q, k, mm, omm, omo, "8192 slots")
-        assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
+        assert st["approx_scan"] == code and st["approx_fallbacks_accum"] == 0
     monkeypatch.delenv("ZH_APX_CAPS")
     ix.stats(reset=True)
     st = check(ix, f, Q, k, m, om, omode)  # mode 4 keeps trying after strikes
-    assert st["approx_scan"] == 1 and st["approx_fallbacks_accum"] == 0
+    assert st["approx_scan"] == code and st["approx_fallbacks_accum"] == 0
     assert seen == 3
+    ix.close()
+
+
+def test_matrix_core_scan_follows_the_stored_rows(za):
+    """the matrix-core scan keeps an fp16 copy of the stored rows, a scale per row and the largest relative rounding error of any row
+    (row_half_kernel): all three must follow
+    rows that are appended (only the new rows are measured) and rows that are replaced (clear + refill to the same count)"""
+    n, d, M, T, k, B = 6000, 512, 256, 6, 10, 32
+    X = zo.synth_rows(2 * n, d)
+    X[n:] *= np.float32(2.0 ** 12)  # the appended half on another scale
+    m, om, omode = za.L2Distance(), zo.L2, 0
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X[:n])
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    Q = zo.synth_queries(B, d, n)
+    st = check(ix, zo.Forest.build(X[:n], M, T), Q, k, m, om, omode, "first half")
+    assert st["approx_scan"] == 2
+    ix.append(X[n:])
+    ix.build()
+    Q2 = np.concatenate([Q[:B // 2], zo.synth_queries(B // 2, d, n) * np.float32(2.0 ** 12)])
+    st = check(ix, zo.Forest.build(X, M, T), Q2, k, m, om, omode, "both halves")
+    assert st["approx_scan"] == 2
+    ix.clear()
+    Y = zo.synth_rows(2 * n, d, seed=5) * np.float32(2.0 ** -30)
+    ix.add(Y)
+    st = check(ix, zo.Forest.build(Y, M, T), zo.synth_queries(B, d, 2 * n, seed_rows=5) * np.float32(2.0 ** -30), k, m, om, omode, "refilled")
+    assert st["approx_scan"] == 2
     ix.close()
 
 
@@ -179,7 +218,7 @@ def test_windows_through_contexts_and_default_mode(za):
     for _ in range(5):
         ix.search_batch(Qs[0], k, m)
     st = check(ix, f, Qs[0], k, m, om, omode, "default mode")
-    assert st["table_scan"] == 1 and st["approx_scan"] == 1, st
+    assert st["table_scan"] == 1 and st["approx_scan"] == 2, st  # (15 trees: the matrix-core kernel)
     dev = torch.device("cuda", 0)
     dq = [torch.from_numpy(q).to(dev) for q in Qs]
     out = [dict(ids=torch.empty((B, k), dtype=torch.int64, device=dev), keys=torch.empty((B, k), dtype=torch.int64, device=dev),
@@ -193,7 +232,7 @@ def test_windows_through_contexts_and_default_mode(za):
     s.synchronize()  # stream order is enough: nothing is redone from the host
     host = [(o["ids"].cpu().numpy().view(np.uint64), o["keys"].cpu().numpy().view(np.uint64), o["counts"].cpu().numpy().view(np.uint32)) for o in out]
     ctx.wait()
-    assert ix.stats()["approx_scan"] == 1 and ix.stats()["window_batches"] == 3
+    assert ix.stats()["approx_scan"] == 2 and ix.stats()["window_batches"] == 3
     for q, (ids, keys, counts) in zip(Qs, host):
         oi, ok, oc = f.search_batch(q, k, om, omode)
         assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()

@@ -137,7 +137,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     // ... with half-width queries (zh_approx.hip): intervals from the scan, the reference's keys for the few rows they cannot
     // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
-    bool approx = false;
+    bool approx = false, approx_mfma = false;
     uint32_t *h_ap = nullptr;
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     uint32_t score_Bp = 0;    // ... for this many (padded) queries per stored row
@@ -210,6 +210,13 @@ struct zh_index {
     // default leaf size), so a forest that changes between searches (insert, search, insert, ...) keeps the pointer walk / the
     // leaf-major sweep: the views are built once the forest has served a few batches unchanged.
     std::atomic<uint32_t> batches_since_change{0};
+    // the MFMA table scan's view of the stored rows (zh_launch_row_half): their fp16 copy in the A operand's order (2 * d bytes per row), per
+    // row {|x|^2, 1 / scale}, and the largest relative rounding error of any row; for rows [0, scale_rows) of generation scale_gen,
+    // extended when rows are appended; a failed allocation is remembered until the rows change (the VALU kernel serves the index)
+    DevBuf row_half, row_meta, row_rho_dev;
+    bool row_half_failed = false;
+    uint64_t scale_rows = 0, scale_gen = 0;
+    float row_rho = 0.f;
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
@@ -218,7 +225,7 @@ struct zh_index {
 
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
-    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies
+    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies, 5 = 4 with the VALU kernel only (no fp16 copy of the rows)
     // a batch whose half-width scan ran over was redone by the f32 scan: both scans paid.  Data whose keys are dense around the cut (the
     // parity cosine key on iid rows in 20k-row leaves: thousands of rows per query inside the bound) would do so batch after batch:
     // after the first such batch -- or one whose lists came close -- the per-query lists get 8192 slots instead of 4096 (a final
@@ -413,7 +420,7 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (ix->sweep_stream) hipStreamSynchronize(ix->sweep_stream);
     free_forest(ix);
     ix->X.release();
-    ix->row_hn2.release(); ix->row_norm.release();
+    ix->row_hn2.release(); ix->row_norm.release(); ix->row_half.release(); ix->row_meta.release(); ix->row_rho_dev.release();
     ix->dctx.release_all();
     DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
@@ -438,6 +445,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->rows_gen++; ix->dead_gen++;
     ix->norm_rows = 0; ix->norm_gen = 0;
     ix->row_hn2.release(); ix->row_norm.release();
+    ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
     ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
     return ZH_OK;
@@ -1184,9 +1192,9 @@ extern "C" int zh_set_hash_mode(zh_index *ix, int mode) {
 }
 extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    if (mode < 0 || mode > 4)
+    if (mode < 0 || mode > 5)
         return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan with f32 queries, 3 = as 0: prefilter where row scores exist, "
-                               "4 = table scan with half-width queries wherever it applies)", mode);
+                               "4 = table scan with half-width queries wherever it applies, 5 = as 4 without the fp16 copy of the rows: the VALU kernel)", mode);
     ix->sweep_mode = mode;
     return ZH_OK;
 }
@@ -1324,16 +1332,59 @@ static int build_row_leaf(zh_index *ix) {
     return ZH_OK;
 }
 
+// The fp16 copy of the stored rows for the MFMA table scan (under blk_mu): rows appended since the last call only.  false: no room for it.
+static int ensure_row_half(zh_index *ix, bool *ok) {
+    *ok = false;
+    if (ix->row_half_failed && ix->scale_gen == ix->rows_gen && ix->scale_rows == ix->n_rows) return ZH_OK;
+    if (!ix->row_half_failed && ix->scale_gen == ix->rows_gen && ix->scale_rows == ix->n_rows) { *ok = true; return ZH_OK; }
+    const uint64_t d = ix->opt.dim, tiles = (ix->n_rows + 15) / 16;
+    ix->row_half_failed = false;
+    // room for it?  (a copy that grows is allocated anew before the old one is freed; a sixteenth of the device stays free for the batches' scratch)
+    size_t mem_free = 0, mem_total = 0;
+    const uint64_t want = std::max<uint64_t>(tiles, 1) * 16 * (d * 2 + sizeof(float2));
+    const bool room = want <= ix->row_half.cap + ix->row_meta.cap ||
+                      (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
+    if (!room || ix->row_half.ensure(std::max<uint64_t>(tiles, 1) * 16 * d * 2, true, ix->stream) != ZH_OK ||
+        ix->row_meta.ensure(std::max<uint64_t>(tiles, 1) * 16 * sizeof(float2), true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(4) != ZH_OK) {
+        ix->row_half.release(); ix->row_meta.release();
+        ix->row_half_failed = true;
+        ix->scale_rows = ix->n_rows; ix->scale_gen = ix->rows_gen;
+        return ZH_OK;
+    }
+    uint64_t from = ix->scale_rows;
+    if (ix->scale_gen != ix->rows_gen || from > ix->n_rows) {
+        from = 0;
+        HIPCHK(hipMemsetAsync(ix->row_rho_dev.p, 0, 4, ix->stream));
+    }
+    HIPCHK(zh_launch_row_half(ix->X.as<float>(), from, ix->n_rows - from, (uint32_t)d, ix->row_half.p, ix->row_meta.as<float2>(),
+                              ix->row_rho_dev.as<uint32_t>(), ix->stream));
+    float rho = 0.f;
+    HIPCHK(hipMemcpyAsync(&rho, ix->row_rho_dev.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->row_rho = rho;
+    ix->scale_rows = ix->n_rows; ix->scale_gen = ix->rows_gen;
+    *ok = true;
+    return ZH_OK;
+}
+
 // Leaf by leaf or the whole table once?  The leaf-major sweep gathers group_rows rows from HBM (5.9-6.1 TB/s of 3-KB rows,
 // 5.5 TB/s of 512-byte ones); the table scan streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and
 // fetches one query from L2 per scored (row, query) pair -- measured 0.075 + 0.00022 d ns per pair chip-wide (4.1 G pairs/s
 // at d = 768 = what the L2s deliver; 10 G pairs/s at d = 128 with the paired kernel, where the leaf-major sweep still wins at the BASELINE shapes), slower once the window's queries no
 // longer fit beside the stream in the 8 x 4 MB of L2.  zh_set_sweep_mode / ZH_SWEEP_MODE=leaf|scan force one of them.
 static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric);
+// The half-width scan on the matrix cores (scan_mfma_kernel) where it has a kernel and the index can keep an fp16 copy of its rows
+// (+50 % of the row table; ensure_row_half): mode 5 / ZH_NO_MFMA=1 keep the VALU kernel, which reads the f32 rows.
+static bool mfma_wanted(const zh_index *ix) {
+    static const bool off = getenv("ZH_NO_MFMA") != nullptr;
+    return !off && ix->sweep_mode != 5 && zh_scan_mfma_supported(ix->opt.dim, ix->n_trees) &&
+           !(ix->row_half_failed && ix->scale_gen == ix->rows_gen && ix->scale_rows == ix->n_rows);
+}
 static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B, size_t k) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
-    const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    if (mode == 5) mode = 4;
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
     if (mode == 2 || mode == 4) return true;
     if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
@@ -1341,12 +1392,14 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
     const double t_leaf = (double)tot.group_rows * row_b / (d >= 256 ? 6.0e12 : 5.5e12);
     // with half-width queries (zh_approx.hip) a pair pulls 2 d bytes through the vector L1 instead of 4 d: measured 0.157 ns per pair at
     // d = 768 (cfg3, window 2, profiles/r04_*), and twice the queries fit beside the stream in L2
-    const bool half = use_approx(ix, tot, B, k, metric);
+    const bool half = use_approx(ix, tot, B, k, metric), mfma = half && mfma_wanted(ix);
     const double q_bytes = (double)B * row_b * (half ? 0.5 : 1.0);
-    const double pair_s = half ? 0.05e-9 + 0.00014e-9 * d
+    // (on the matrix cores: 3.4-3.5 ms per 3.33M rows + 28.6M pairs at d = 768, window 2 -- the L2s' rate for 2 d bytes per pair; the rows are fp16 too)
+    const double pair_s = mfma ? 0.02e-9 + 0.00011e-9 * d
+                        : half ? 0.05e-9 + 0.00014e-9 * d
                                : (d == 128 ? 0.10e-9 : 0.075e-9 + 0.00022e-9 * d);  // (d = 128: the paired kernel, two pairs per step)
     const double t_pairs = (double)tot.rows * pair_s * (q_bytes > 8e6 ? 1.25 : 1.0);
-    const double t_scan = std::max((double)ix->n_rows * (row_b + 8.0 * T) / 6.0e12, t_pairs) + 20e-6;
+    const double t_scan = std::max((double)ix->n_rows * (row_b * (mfma ? 0.5 : 1.0) + 8.0 * T) / 6.0e12, t_pairs) + 20e-6;
     return t_scan < 0.92 * t_leaf;
 }
 
@@ -1356,13 +1409,18 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
 static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
     static const bool off = getenv("ZH_NO_APPROX") != nullptr;
-    const int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    if (mode == 5) mode = 4;
     if (off || mode == 2 || mode == 1) return false;
     if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0 || B >= (1u << 24)) return false;  // (24 bits of a packed pair record)
     if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
     // by itself only where it pays: per pair it moves half the bytes, but a window of ONE cfg3 batch (4.3 pairs per stored row) gains 4 % on
     // the scan (3.28 against 3.42 ms per launch) and pays more than that for the interval stages: from ~5 pairs per stored row on
-    if (mode != 4 && (ix->approx_strikes.load() >= 2 || !zh_approx_pays(ix->opt.dim) || tot.rows < 5 * ix->n_rows)) return false;
+    // (the matrix-core kernel reads half the row bytes as well and multiplies for nothing: measured from d = 256 and ~2 pairs per stored row on)
+    const bool mfma = mfma_wanted(ix);
+    if (mode != 4 && (ix->approx_strikes.load() >= 2 || !(mfma ? ix->opt.dim >= 256 : zh_approx_pays(ix->opt.dim)) ||
+                      tot.rows < (mfma ? 2 : 5) * ix->n_rows))
+        return false;
     return true;
 }
 
@@ -1782,6 +1840,14 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     c->approx = c->scan && use_approx(ix, tot, B, k, c->metric);
     ZhApprox ap{};
+    // the scan on the matrix cores, from an fp16 copy of the stored rows (+50 % of the row table, made on first use); no room for it, or mode 5:
+    // the VALU kernel on the f32 rows
+    bool mfma = c->approx && mfma_wanted(ix);
+    if (mfma) {
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if ((rc = ensure_row_half(ix, &mfma))) return rc;
+    }
+    c->approx_mfma = mfma;
     if (c->approx) {
         // per query: what final_interval_kernel's sort holds (48 KB per query of HBM).  A visit hands on the rows its intervals cannot
         // rule out: a few more than `take` -- or dozens more where the keys are dense around the cut: the parity cosine key on iid
@@ -1803,10 +1869,12 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         ap.ex_visits = c->wApEx.as<uint2>(); ap.ex_cap = ex_cap;
         ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
+        ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;
+        ap.row_rho = mfma ? ix->row_rho : 0.f;
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
         HIPCHK(hipMemsetAsync(ap.qtau, 0xFF, B * 4, s));
         HIPCHK(hipMemsetAsync(c->wApCtl.p, 0, ZH_APX_CTL_WORDS * 4, s));
-        HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), s));
+        HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), mfma, s));
     }
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
@@ -1913,7 +1981,7 @@ int ctx_wait(zh_search_ctx *c) {
                                    : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8);
     st.table_scan = c->scan && !pf ? 1 : 0;
     const bool apx = c->approx && !pf;
-    st.approx_scan = apx ? 1 : 0;
+    st.approx_scan = apx ? (c->approx_mfma ? 2 : 1) : 0;
     st.approx_exact_visits = apx ? c->h_ap[0] : 0;
     st.approx_survivors = apx ? c->h_ap[3] : 0;
     st.approx_list_entries = apx ? c->h_ap[4] : 0;

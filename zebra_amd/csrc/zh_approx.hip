@@ -62,10 +62,13 @@ bool zh_approx_pays(uint32_t d) { return d >= 384; }
 // two roundings for V itself: |V - d*| <= (c0 + 54) u (|x| + |q|)^2 + 2 |x| dq; (c0 + 100) leaves room for V +- E and E themselves.
 // Cosine, in the scale of the clipped distance 1 - cos: the canonical sums give the reference's value within 2 c0 u of the real
 // one; s / (sigma nx nq) within dq / |q| + 73 u; + 4 u for the kernel's own roundings -> (2 c0 + 80) u + dq / |q|.
-float zh_approx_bound(int metric, uint32_t d) {
-    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0;
-    if (metric == ZH_COSINE) return (float)(1.01 * (2.0 * c0 + 80.0) * u);
-    return (float)(1.01 * (c0 + 100.0) * u);
+// mfma (scan_mfma_kernel): s is the sum of four MFMA accumulators, ops = 33 d / 128 + 2 operations of at most 2 u each on its longest chain
+// instead of 33 of u: |s / sigma - x.q| gains (2 ops - 33) u |x||q| -- in V's scale 2 |x||q| <= (|x| + |q|)^2 / 2, i.e. + ops u; in the cosine's + 2 ops u.
+// The rounding of the ROW (|x - xh / sigma_x| <= rho |x|) is approx_interval's `rho` term.
+float zh_approx_bound(int metric, uint32_t d, bool mfma) {
+    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0, ops = mfma ? 33.0 * (d / 128) + 2.0 : 0.0;
+    if (metric == ZH_COSINE) return (float)(1.01 * (2.0 * c0 + 80.0 + 2.0 * ops) * u);
+    return (float)(1.01 * (c0 + 100.0 + ops) * u);
 }
 
 // ---- the fp16 copy of a batch's queries ----
@@ -116,10 +119,11 @@ __global__ __launch_bounds__(64) void qhalf_kernel(const float *__restrict__ Q, 
     }
 }
 
-hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s) {
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, bool mfma, hipStream_t s) {
     if (!B) return hipSuccess;
-    const uint32_t G = zh_approx_groups(d);
-    if (G == 8) hipLaunchKernelGGL(qhalf_kernel<8>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    const uint32_t G = mfma ? 16 : zh_approx_groups(d);  // (the MFMA scan's k-groups are four lanes wide)
+    if (G == 16) hipLaunchKernelGGL(qhalf_kernel<16>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    else if (G == 8) hipLaunchKernelGGL(qhalf_kernel<8>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 4) hipLaunchKernelGGL(qhalf_kernel<4>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 2) hipLaunchKernelGGL(qhalf_kernel<2>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else return hipErrorInvalidValue;
@@ -143,20 +147,22 @@ __device__ __forceinline__ float group_sum(float s) {
 
 // the interval of one (row, query) pair from its sums: sortable lo | sortable hi << 32; (0, all ones) = nothing certain
 template <int KINDA>
-__device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc) {
+__device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc, float rho) {
     uint32_t lo_s = 0u, hi_s = 0xFFFFFFFFu;
     const float sh = s * qm.x;
     if (KINDA == 0) {
         const float nx = sqrtf(a2) * (1.0f + 1e-5f), nn = nx + qm.z, sum = a2 + qm.y;
         const float V = sum - 2.0f * sh;
-        const float E = Kc * nn * nn + 2.02f * nx * qm.w;
+        // |s / sigma - x.q| <= |x| dq + |x - x'| (|q| + dq), |x - x'| <= rho |x| (rho = 0: the scan multiplied the f32 row)
+        const float E = Kc * nn * nn + 2.02f * nx * (qm.w + rho * (qm.z + qm.w));
         if ((V - V == 0.f) && (E - E == 0.f) && nn > 1e-12f && sum < 1e37f) { lo_s = f32_sortable(V - E); hi_s = f32_sortable(V + E); }
     } else {
         const float nx = sqrtf(a2), nq = sqrtf(qm.y);
         if (nx > 1e-12f && nq > 1e-12f && (sh - sh == 0.f) && (nx - nx == 0.f) && (nq - nq == 0.f)) {
             float r = 1.0f - sh / (nx * nq);
             r = r > 0.f ? r : 0.f;
-            const float e = Kc + 1.01f * qm.w / nq;
+            const float dqr = qm.w / nq;
+            const float e = Kc + 1.01f * (dqr + rho * (1.0f + dqr));
             float v = r;
             bool ok = true;
             if (KINDA == 2) {  // ZH_COSINE_PARITY keys compare as the bits of 1 - distance: as pf_value<2>
@@ -457,6 +463,261 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     flush();
 }
 
+// ---- the table scan on the matrix cores (round 4, second half; zh_set_sweep_mode 5 -- measurement, not the default) ----
+// The VALU scan above spends 36 vector instructions per pair (profiles/r04_pmc_scan_mix.txt): a 32-lane fma column, its reduce, its
+// record and its stash.  Here a wave's 16 stored rows are the A operand of v_mfma_f32_16x16x32_f16 (converted ONCE per window to
+// fp16, power-of-two scaled per row, held in registers for all of the wave's pairs) and SIXTEEN pairs of the wave's list are the 16
+// columns of B; D / 32 MFMAs produce the 16 x 16 products of which the 16 wanted ones (column c wants row rec.x) are picked from the
+// accumulators: no reduce, no per-pair arithmetic at all.  15 of 16 products are waste; the matrix pipe has forty times the rate this
+// needs (16 cycles per MFMA and SIMD, D / 32 of them per 16 pairs).
+// RESULT (profiles/r04_ab_scan_mfma.txt, r04_pmc_scan_mfma.txt): 40 % of the VALU kernel's vector instructions, a fifth of its scalar
+// ones -- and the same time per launch (4.55-4.75 against 4.4-4.55 ms at cfg3).  Both kernels run at the rate the L2s answer a CU's
+// line requests (0.19-0.22 lines per clock and CU; 15.6-16 TB/s of L2 requests against the 16.8-18.8 TB/s the guide measures for
+// L2-served gathers): a pair's 2 d bytes of query must come from L2 whatever multiplies them.  Rounding the ROWS as well widens the
+// intervals (the literal cosine key scores twice the rows exactly), so the VALU kernel stays the default.
+// k order: both operands use the SAME map (step s, k-group h, element j -> stored element 32 s + 4 h + (j & 3) + 16 (j >> 2)), which is
+// all a dot product needs: a lane's eight row elements are two 16-byte loads of the f32 row, its eight query halves ONE 16-byte
+// load of qhalf_kernel<16>'s layout.
+// What changes for the intervals: the row is rounded too.  |x - xh / sigma_x| <= rho |x| with rho MEASURED over the stored rows
+// (row_scale_kernel: the largest relative rounding error of any usable row, ~0.3 * 2^-11 on generic data, never above 2^-11), and the
+// accumulation happens inside the MFMA in an order the ISA does not specify: four accumulators, each the target of D / 128 MFMAs of
+// 32 products -- any order, any rounding of at most 2 u per operation gives |acc - sum| <= (33 D / 128 + 2) 2 u sum |xh_i h_i|
+// (zh_approx_bound's `ops`).  Rows whose scale is out of range (or not finite) hand every pair the interval (-inf, +inf).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// The fp16 copy of the stored rows, written once (rows appended later: their own slots), in the A operand's own order: per tile of 16
+// rows and MFMA step s one KiB = lane (c, h)'s eight halves {row 16 tile + c, elements 32 s + 4 h + t and 32 s + 16 + 4 h + t}, so that a
+// scan wave's whole operand is D / 32 fully coalesced 1-KiB loads -- half the HBM bytes of the f32 rows, an eighth of the tag look-ups of
+// loading them fragment-shaped, nothing to convert in the scan.  rowMeta[row] = {f32 |x|^2, 1 / sigma_x (NaN: scale out of range or a
+// non-finite element: nothing is certain about this row)}; *rhoMax = the largest |x - xh / sigma_x| / |x| (f32 bits; atomicMax).
+__global__ __launch_bounds__(256) void row_half_kernel(const float *__restrict__ X, uint64_t row0, uint64_t n_rows, uint32_t d,
+                                                       _Float16 *__restrict__ Xh, float2 *__restrict__ rowMeta, uint32_t *__restrict__ rhoMax) {
+    const uint32_t lane = threadIdx.x & 63, NS = d / 32;
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    float rho_w = 0.f;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_rows; i += nw) {
+        const uint64_t row = row0 + i;
+        const float *x = X + (size_t)row * d;
+        float m = 0.f, a2 = 0.f;
+        bool bad = false;
+        for (uint32_t e = lane; e < d; e += 64) {
+            const float v = x[e];
+            bad |= !(v - v == 0.f);
+            m = fmaxf(m, fabsf(v));
+            a2 = __builtin_fmaf(v, v, a2);
+        }
+        m = wave_butterfly<OpMax>(m);
+        a2 = wave_sum_canonical(a2);  // (d / 64 + 6 <= 32 roundings: what zh_approx_bound assumes of |x|^2)
+        bad = __ballot(bad) != 0;
+        bool usable = false;
+        float sigma = 1.f, inv = __uint_as_float(0x7FC00000u);
+        if (!bad) {
+            int ex = 14;  // (a zero row: sigma = 1)
+            if (m > 0.f) (void)frexpf(m, &ex);
+            if (ex >= -100 && ex <= 100) { usable = true; sigma = ldexpf(1.f, 14 - ex); inv = ldexpf(1.f, ex - 14); }
+        }
+        // the rounding error in the row's scaled units (max in [2^13, 2^14)): nothing under- or overflows that matters at the 1.001
+        float s2 = 0.f, d2 = 0.f;
+        _Float16 *tile = Xh + ((size_t)(row >> 4) * NS * 64 + (row & 15)) * 8;
+        for (uint32_t e = lane; e < d; e += 64) {
+            const float v = x[e] * sigma;
+            const _Float16 hv = usable ? (_Float16)v : (_Float16)0.f;
+            const float df = v - (float)hv;
+            s2 = __builtin_fmaf(v, v, s2);
+            d2 = __builtin_fmaf(df, df, d2);
+            const uint32_t st = e >> 5, w = e & 31, hh = (w & 15) >> 2, j = (w & 3) + ((w >> 4) << 2);
+            tile[((size_t)st * 64 + hh * 16) * 8 + j] = hv;
+        }
+        s2 = wave_sum_canonical(s2);
+        d2 = wave_sum_canonical(d2);
+        if (usable && s2 > 0.f) rho_w = fmaxf(rho_w, sqrtf(d2) * 1.001f / (sqrtf(s2) * 0.9999f));
+        if (lane == 0) rowMeta[row] = make_float2(a2, inv);
+    }
+    if (lane == 0 && rho_w > 0.f) atomicMax(rhoMax, __float_as_uint(rho_w));
+}
+
+hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
+                              hipStream_t s) {
+    if (!n_rows) return hipSuccess;
+    const uint64_t blocks = std::min<uint64_t>((n_rows + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(row_half_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, row0, n_rows, d, (_Float16 *)dXh, dRowMeta, dRhoMax);
+    return hipGetLastError();
+}
+
+#ifndef ZH_MFMA_CL
+#define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
+#endif
+template <int D>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
+                                                         const uint4 *__restrict__ Qh, const uint2 *__restrict__ rowLeaf, uint32_t T,
+                                                         uint32_t RW, const uint32_t *__restrict__ visitBits,
+                                                         const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
+                                                         uint32_t GRP, uint64_t row_begin, uint64_t row_end, uint64_t *__restrict__ iv) {
+    constexpr int NS = D / 32;   // MFMA steps of a tile
+    constexpr int NL = D / 64;   // 128-byte lines of a query = two steps each
+    constexpr int CL = ZH_MFMA_CL ? ZH_MFMA_CL : (NL % 4 == 0 ? 2 : 3);  // lines per chunk: 2 CL load instructions, 2 CL KB of the wave's LDS
+    constexpr int NCH = NL / CL;
+    static_assert(D % 128 == 0 && NL % CL == 0 && NCH % 2 == 0, "four accumulators; the chunk registers alternate with a static parity");
+    __shared__ uint4 pair_list[4][ZH_APX_CAP];  // {row of the wave's RW, query, interval slot lo, hi}
+    __shared__ uint4 stage[4][CL * 128];        // a chunk of the tile's query halves: [line][column / 8][column % 8][16-byte piece, swizzled]
+    __shared__ float2 row_meta[4][16];          // {|x|^2, 1 / sigma_x (NaN: nothing is certain about this row)}
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r0 = row_begin + wave * RW;
+    if (r0 >= row_end) return;
+    const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
+    const uint32_t n_ent = nr * T;
+    const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
+    uint32_t eGb[ZH_SCAN_NE], eWithin[ZH_SCAN_NE], eC[ZH_SCAN_NE], off[ZH_SCAN_NE], eB0[ZH_SCAN_NE];
+    uint64_t eK0[ZH_SCAN_NE];
+    const uint32_t P = scan_phase1(lane, n_ent, ent, visitBits, nodeVisit, eGb, eWithin, eC, off, eB0, eK0);
+    if (P == 0) return;
+    uint4 *list = pair_list[wid];
+    const bool listed = P <= ZH_APX_CAP;
+#pragma unroll
+    for (int j = 0; j < ZH_SCAN_NE; j++) {
+        const uint32_t e = lane + 64u * j, c = eC[j];
+        if (c && listed) {
+            const uint32_t rl = e / T, gb = eGb[j];
+            {
+                const uint64_t slot = eK0[j] + eWithin[j];
+                list[off[j]] = make_uint4(rl, eB0[j], (uint32_t)slot, (uint32_t)(slot >> 32));
+            }
+            for (uint32_t sidx = 1; sidx < c; sidx++) {
+                const ZhGroup *gp = groups + gb + sidx / GRP;
+                const uint64_t slot = gp->key_off[sidx % GRP] + eWithin[j];
+                list[off[j] + sidx] = make_uint4(rl, gp->b[sidx % GRP], (uint32_t)slot, (uint32_t)(slot >> 32));
+            }
+        }
+    }
+    // ---- the wave's 16 rows: their fp16 copy, already in the A operand's order (row_half_kernel): D / 32 coalesced 1-KiB loads ----
+    f16x8 A[NS];
+    {
+        const u32x4v *tp = Xh + (size_t)(r0 >> 4) * (NS * 64) + lane;
+#pragma unroll
+        for (int st = 0; st < NS; st++) A[st] = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(tp + 64 * st));
+        if (lane < 16) row_meta[wid][lane] = rowMeta[r0 + (lane < nr ? lane : 0u)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float2 *rmeta = row_meta[wid];
+    // The query halves of a tile come in FULL 128-byte lines -- lane (g, p) = (lane >> 3, lane & 7) loads 16 bytes of column g's (then
+    // column 8 + g's) query, eight lanes a line: eight tag look-ups per load instruction.  Loaded as the MFMA wants them (lane (c, h):
+    // 16 bytes of column c, every lane of a quarter-wave another query) the same bytes cost 64 look-ups per instruction and the texture
+    // path, not L2, set the pace: 6.9 ms per launch (profiles/r04_pmc_scan_mfma.txt, v1).  The lines pass
+    // through the wave's own LDS chunk (written as loaded, pieces XOR-swizzled by column so that the fragment reads -- ds_read_b128, lane
+    // (c, h) piece 4 (s & 1) + h of column c -- meet no bank twice within their 16-lane groups).
+    u32x4v *stg = reinterpret_cast<u32x4v *>(stage[wid]);  // (native vectors: HIP's uint4 struct copies global -> private -> LDS stayed memcpys in scratch memory)
+    const u32x4v *__restrict__ Qv = reinterpret_cast<const u32x4v *>(Qh);
+    const uint32_t g8 = lane >> 3, pc = lane & 7;
+    const uint32_t swA = (g8 >> 1) & 7u, swB = (4u + (g8 >> 1)) & 7u;          // columns g8 and 8 + g8
+    const uint32_t rd0 = (c16 >> 3) * 64u + (c16 & 7u) * 8u + ((h ^ (c16 >> 1)) & 7u);   // even steps: piece h
+    const uint32_t rd1 = (c16 >> 3) * 64u + (c16 & 7u) * 8u + (((4u + h) ^ (c16 >> 1)) & 7u);
+    auto issue = [&](uint32_t bA, uint32_t bB, int chunk, u32x4v *dst) {
+        const u32x4v *qa = Qv + (size_t)bA * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swA);
+        const u32x4v *qb = Qv + (size_t)bB * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swB);
+#pragma unroll
+        for (int i = 0; i < CL; i++) { dst[2 * i] = qa[8 * i]; dst[2 * i + 1] = qb[8 * i]; }
+    };
+    auto to_lds = [&](const u32x4v *src) {
+#pragma unroll
+        for (int i = 0; i < 2 * CL; i++) stg[64 * i + lane] = src[i];
+    };
+    auto mfma_chunk = [&](int chunk, f32x4v *acc) {
+#pragma unroll
+        for (int i = 0; i < 2 * CL; i++) {  // step 2 CL chunk + i: line i / 2 of the chunk
+            const u32x4v v = stg[128 * (i / 2) + ((i & 1) ? rd1 : rd0)];
+            const int st = chunk * 2 * CL + i;
+            acc[st & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[st], __builtin_bit_cast(f16x8, v), acc[st & 3], 0, 0, 0);
+        }
+    };
+    auto emit = [&](const f32x4v *acc, uint32_t rl, uint64_t slot, bool valid) {  // column c16 wants row rl: lane (c16, rl >> 2), register rl & 3
+        const f32x4v t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (valid && (rl >> 2) == h) {
+            const uint32_t i = rl & 3u;
+            const float sv = i == 0 ? t[0] : (i == 1 ? t[1] : (i == 2 ? t[2] : t[3]));
+            const float2 rm = rmeta[rl];
+            __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + slot);
+        }
+    };
+    if (listed) {
+        // the wave's pairs sixteen at a time, whichever rows they belong to; the next chunk of query lines is requested before the
+        // current one is multiplied, across tile boundaries
+        const uint32_t nt = (P + 15) / 16;
+        auto col_b = [&](uint32_t t, uint32_t col) { const uint32_t pi = 16 * t + col; return list[pi < P ? pi : P - 1].y; };
+        uint32_t bA = col_b(0, g8), bB = col_b(0, 8 + g8);
+        u32x4v ra[2 * CL], rb[2 * CL];
+        issue(bA, bB, 0, ra);
+        for (uint32_t t = 0; t < nt; t++) {
+            f32x4v acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const uint32_t pe = 16 * t + c16;
+            const uint4 rec = list[pe < P ? pe : P - 1];
+#pragma unroll
+            for (int c = 0; c < NCH; c += 2) {
+                issue(bA, bB, c + 1, rb);
+                to_lds(ra);
+                mfma_chunk(c, acc);
+                if (c + 2 < NCH) issue(bA, bB, c + 2, ra);
+                else {
+                    bA = col_b(t + 1, g8); bB = col_b(t + 1, 8 + g8);
+                    issue(bA, bB, 0, ra);
+                }
+                to_lds(rb);
+                mfma_chunk(c + 1, acc);
+            }
+            emit(acc, rec.x, ((uint64_t)rec.w << 32) | rec.z, pe < P);
+        }
+    } else {
+        // more pairs than the list holds (hot leaves): entry after entry, a leaf's visits sixteen at a time, records from the group array
+#pragma unroll
+        for (int j = 0; j < ZH_SCAN_NE; j++) {
+            unsigned long long m = __ballot(eC[j] != 0);
+            while (m) {
+                const int ll = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)eC[j], ll);
+                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)eGb[j], ll);
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)eWithin[j], ll);
+                const uint32_t rl = ((uint32_t)ll + 64u * j) / T;
+                for (uint32_t s0 = 0; s0 < c; s0 += 16) {
+                    auto visit_b = [&](uint32_t col) { const uint32_t si = s0 + col < c ? s0 + col : c - 1; return groups[gb + si / GRP].b[si % GRP]; };
+                    const uint32_t bA = visit_b(g8), bB = visit_b(8 + g8);
+                    const uint32_t sidx = s0 + c16 < c ? s0 + c16 : c - 1;
+                    const ZhGroup *gp = groups + gb + sidx / GRP;
+                    f32x4v acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    u32x4v rq[2 * CL];
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++) {
+                        issue(bA, bB, cc, rq);
+                        to_lds(rq);
+                        mfma_chunk(cc, acc);
+                        __builtin_amdgcn_sched_barrier(0);  // (the rare path must not set the kernel's register count: all chunks' loads hoisted)
+                    }
+                    emit(acc, rl, gp->key_off[sidx % GRP] + w, s0 + c16 < c);
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+static hipError_t launch_scan_mfma_d(const float *dX, uint64_t n_rows, const ZhApprox &ap, const uint2 *dRowLeaf, uint32_t T,
+                                     const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, hipStream_t s) {
+    const uint32_t RW = zh_scan_rows_per_wave(T);
+    uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
+    rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
+    for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
+        const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
+        const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((scan_mfma_kernel<D>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)ap.row_half, ap.row_meta, (const uint4 *)ap.Qh, dRowLeaf, T, RW,
+                           dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv);
+    }
+    return hipGetLastError();
+}
+
 // (Measured and not kept, round 4: phase 1 as a kernel of its own -- scan_pairs_kernel wrote every 16-row unit's pair records (8 bytes
 // each, compacted through one atomic per unit) and a "listed" scan kernel started from them with independent loads only.  cfg3, window
 // 2: the pairs kernel ~4 ms per batch, the listed scan 6.5 against 4.7 ms per launch beside it, 100 k against 142 k QPS.  Phase 1 is
@@ -619,7 +880,7 @@ static hipError_t launch_scan_approx_d(const float *dX, uint64_t n_rows, const Z
     const uint32_t RW = zh_scan_rows_per_wave(T);
     uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
     rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
-    const float Kc = zh_approx_bound(metric, D);
+    const float Kc = zh_approx_bound(metric, D, false);
     const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
     for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
@@ -636,6 +897,8 @@ static hipError_t launch_scan_approx_d(const float *dX, uint64_t n_rows, const Z
     return hipGetLastError();
 }
 
+// (16 rows per wave = one tile of the fp16 row copy: up to 16 trees)
+bool zh_scan_mfma_supported(uint32_t d, uint32_t T) { return (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024) && zh_scan_rows_per_wave(T) == 16; }
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric) {
     if (metric != ZH_L2 && metric != ZH_L2SQ && metric != ZH_COSINE) return false;
     return zh_approx_groups(d) != 0 && zh_scan_rows_per_wave(T) != 0;
@@ -645,12 +908,20 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
                                  const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
                                  int mode, hipStream_t s) {
     if (!n_rows) return hipSuccess;
+    if (ap.mfma) switch (d) {
+    case 256: return launch_scan_mfma_d<256>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, s);
+    case 384: return launch_scan_mfma_d<384>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, s);
+    case 512: return launch_scan_mfma_d<512>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, s);
+    case 768: return launch_scan_mfma_d<768>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, s);
+    case 1024: return launch_scan_mfma_d<1024>(dX, n_rows, ap, dRowLeaf, T, dVisitBits, dNodeVisit, dGroups, group, s);
+    default: return hipErrorInvalidValue;
+    }
     switch (d) {
     case 128: {
         const uint32_t RW = zh_scan_rows_per_wave(T);
         uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
         rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
-        const float Kc = zh_approx_bound(metric, 128);
+        const float Kc = zh_approx_bound(metric, 128, false);
         const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
         for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
             const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
@@ -731,7 +1002,7 @@ __global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restri
             uint64_t *__restrict__ raw = ap.iv + v.row_off;
             for (uint32_t i = tid; i < v.len; i += 256) {
                 const uint64_t w = raw[i];
-                raw[i] = approx_interval<KINDA>(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)), qm, Kc);
+                raw[i] = approx_interval<KINDA>(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)), qm, Kc, ap.row_rho);
             }
             __syncthreads();
         }
@@ -1051,7 +1322,7 @@ hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, 
     uint64_t chunk = (n_visits + 16383) / 16384;
     if (chunk > 256) chunk = 256;
     const uint64_t blocks = (n_visits + chunk - 1) / chunk;
-    const float Kc = zh_approx_bound(metric, d);
+    const float Kc = zh_approx_bound(metric, d, ap.mfma != 0);
     if (metric != ZH_COSINE)
         hipLaunchKernelGGL(select_tau_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, Kc, ap);
     else if (mode == ZH_COSINE_PARITY)

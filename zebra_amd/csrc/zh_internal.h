@@ -232,12 +232,22 @@ struct ZhApprox {
     uint32_t *ex_cids;
     uint32_t ex_rows_cap;
     uint32_t *ctl;
+    // the scan on the matrix cores (scan_mfma_kernel): the stored rows are rounded to fp16 as well
+    const void *row_half;    // the fp16 copy of the stored rows, tiles of 16 rows in the A operand's order (row_half_kernel)
+    const float2 *row_meta;  // per stored row {|x|^2, 1 / sigma_x (NaN: nothing certain about the row)}
+    float row_rho;           // |x - xh / sigma_x| <= row_rho |x| for every usable stored row (0 with f32 rows)
+    uint32_t mfma;
 };
 uint32_t zh_approx_groups(uint32_t d);
 bool zh_approx_pays(uint32_t d);
-float zh_approx_bound(int metric, uint32_t d);
+float zh_approx_bound(int metric, uint32_t d, bool mfma);
+bool zh_scan_mfma_supported(uint32_t d, uint32_t T);
+// the fp16 copy of rows [row0, row0 + n_rows) in scan_mfma_kernel's operand order (2 * d bytes per row, tiles of 16 rows), per row {|x|^2,
+// 1 / sigma_x}; *dRhoMax = the largest relative rounding error of a row (f32 bits, atomicMax)
+hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
+                              hipStream_t s);
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
-hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, hipStream_t s);
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, bool mfma, hipStream_t s);
 hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
                                  const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
                                  int mode, hipStream_t s);
