@@ -149,7 +149,7 @@ def parse():
                          "own streams and run beside the current window's walk / sweep)")
     ap.add_argument("--window", type=int, default=None,
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
-    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx", "approx-valu"], default="auto",
+    ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx", "approx-valu", "leaf-half"], default="auto",
                     help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
@@ -516,7 +516,12 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     kname = ("scan_sweep_kernel<%d, %d>" if scan else "sweep_kernel<%d, %d, ...>") % (d, kind)  # <D, KIND (0 = L2, 1 = cosine), ...>
     if not scan and d == 128:
         kname = "sweep128_kernel<%d, ...>" % kind  # the half-wave kernel of the 512-byte rows
-    if half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
+    leaf_half = half and st.get("approx_scan", 0) == 3  # d = 128, leaf by leaf from the fp16 copy of the rows (sweep128h_kernel)
+    if leaf_half:
+        kname = "sweep128h_kernel<4>"
+        bytes_alg = 2.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 2.0 * d * B / launches_per_batch
+        bytes_nosharing = (2.0 * d + 12.0) * rows_per_launch
+    elif half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
         if st.get("approx_scan", 0) == 2:
             kname = "scan_mfma_kernel<%d>" % d  # the same scan on the matrix cores, from the index's fp16 copy of the stored rows

@@ -176,6 +176,75 @@ def test_lists_that_run_over_are_redone_on_the_device(za, monkeypatch, mode):
     ix.close()
 
 
+LEAF_CASES = [
+    # n, M, T, k, batch, kind
+    (20000, 2000, 6, 10, 64, 1),     # SIFT-style integer rows: the fp16 copy is exact
+    (9000, 300, 10, 10, 96, 1),
+    (12000, 1500, 5, 100, 40, 0),    # float rows: rounded under the table's common scale
+    (3001, 3002, 5, 10, 300, 0),     # ONE leaf per tree, visited by every query: many groups on the same rows
+    (7000, 24, 6, 10, 9, 0),         # leaves ~ top_k: tiles that span many groups, backup visits (the exact path)
+    (5000, 700, 16, 100, 33, 2),
+]
+
+
+@pytest.mark.parametrize("n,M,T,k,B,kind", LEAF_CASES)
+def test_leaf_major_half_width_sweep_equals_oracle(za, n, M, T, k, B, kind):
+    """d = 128, leaf by leaf at half width on the matrix cores (sweep128h_kernel, zh_set_sweep_mode 6): an fp16 copy of the rows under one
+    scale, the queries of up to four groups as the A operand, 16 stored rows as B; same intervals, same stages behind it"""
+    d = 128
+    X = zo.synth_rows(n, d, kind=kind)
+    Q = zo.synth_queries(B, d, n, kind=kind)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("leaf-half")
+    ix.set_hash_mode("dense")
+    for m, om, omode in all_metrics(za):
+        st = check(ix, f, Q, k, m, om, omode)
+        assert st["approx_scan"] == 3 and st["table_scan"] == 0, (om, omode, st)
+        assert st["approx_fallbacks_accum"] == 0, st
+    ix.close()
+
+
+def test_leaf_major_half_width_adversarial_rows_appends_and_overflow(za, monkeypatch):
+    """rows that do not survive the table's common scale (tiny, huge, non-finite: stored as NaNs -> the exact path), ties, appended rows on a
+    larger scale (the copy is re-made), and lists that run over (redone by the f32 leaf-major sweep on the device)"""
+    rng = np.random.default_rng(11)
+    n, d, M, T, k, B = 6000, 128, 800, 6, 20, 48
+    X = zo.synth_rows(2 * n, d, kind=0)
+    X[100:164] = X[:64]
+    X[200:264] = np.nextafter(X[:64], np.float32(np.inf))
+    X[400:700] = np.round(X[400:700] * 2.0)
+    X[700:710] = 0.0
+    X[710:720] *= np.float32(1e-12)
+    X[730, 3] = np.nan
+    X[731, 5] = np.inf
+    X[n:] *= np.float32(64.0)           # the appended half: a larger scale
+    m, om, omode = za.L2Distance(), zo.L2, 0
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X[:n])
+    f = zo.Forest.build(X[:n], M, T)
+    ix.set_forest(f.arrays())
+    ix.set_sweep_mode("leaf-half")
+    Q = zo.synth_queries(B, d, n)
+    Q[0] = X[0]; Q[1] = X[410]; Q[2] = 0.0
+    for mm, omm, omo in all_metrics(za):
+        st = check(ix, f, Q, k, mm, omm, omo, "adversarial")
+        assert st["approx_scan"] == 3
+    ix.append(X[n:])
+    f2 = zo.Forest.build(X, M, T)
+    ix.set_forest(f2.arrays())
+    Q2 = np.concatenate([Q[:B // 2], zo.synth_queries(B // 2, d, n) * np.float32(64.0)])
+    st = check(ix, f2, Q2, k, m, om, omode, "appended")
+    assert st["approx_scan"] == 3
+    monkeypatch.setenv("ZH_APX_CAPS", "64,0,0")
+    ix.stats(reset=True)
+    st = check(ix, f2, Q2, k, m, om, omode, "lists run over")
+    assert st["approx_scan"] == 3 and st["approx_fallbacks_accum"] == 1
+    monkeypatch.delenv("ZH_APX_CAPS")
+    ix.close()
+
+
 def test_matrix_core_scan_follows_the_stored_rows(za):
     """the matrix-core scan keeps an fp16 copy of the stored rows, a scale per row and the largest relative rounding error of any row
     (row_half_kernel): all three must follow

@@ -42,7 +42,7 @@ def test_fuzz_config(seed):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
     ix.set_dense_levels(int(rng.choice([-1, -1, 0, 1, 3, 64])))
-    ix.set_sweep_mode(str(rng.choice(["auto", "leaf", "scan", "approx", "approx-valu"])))  # (scan / approx fall back where they have no kernel: odd d, other metrics)
+    ix.set_sweep_mode(str(rng.choice(["auto", "leaf", "scan", "approx", "approx-valu", "leaf-half"])))  # (scan / approx fall back where they have no kernel: odd d, other metrics)
     f = zo.Forest.build(X, M, T, seed=seed)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
     mets = _metrics(za, rng)
@@ -208,7 +208,8 @@ def test_fuzz_half_width_scan(seed):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
-    ix.set_sweep_mode("approx-valu" if seed % 3 == 2 else "approx")  # (every third case: the VALU kernel on the f32 rows instead of the matrix cores)
+    ix.set_sweep_mode("approx-valu" if seed % 3 == 2 else ("leaf-half" if d == 128 and seed % 3 == 1 else "approx"))  # (every third case: the VALU kernel on the
+    # f32 rows instead of the matrix cores; d = 128, every third: leaf by leaf at half width)
     ix.set_hash_mode("dense")
     used = 0
     for m, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),

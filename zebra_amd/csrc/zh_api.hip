@@ -137,7 +137,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     // ... with half-width queries (zh_approx.hip): intervals from the scan, the reference's keys for the few rows they cannot
     // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
-    bool approx = false, approx_mfma = false;
+    bool approx = false, approx_mfma = false, approx_leaf = false;  // (approx_leaf: the d = 128 leaf-major sweep at half width, sweep128h_kernel)
     uint32_t *h_ap = nullptr;
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
     uint32_t score_Bp = 0;    // ... for this many (padded) queries per stored row
@@ -215,6 +215,12 @@ struct zh_index {
     // extended when rows are appended; a failed allocation is remembered until the rows change (the VALU kernel serves the index)
     DevBuf row_half, row_meta, row_rho_dev;
     bool row_half_failed = false;
+    // d = 128, leaf by leaf at half width (sweep128h_kernel): a row-major fp16 copy under ONE power-of-two scale (2^(14 - h128_ex)), same life cycle
+    DevBuf row_half128;
+    uint64_t h128_rows = 0, h128_gen = 0;
+    int h128_ex = 0;
+    float h128_rho = 0.f;
+    bool h128_failed = false;
     uint64_t scale_rows = 0, scale_gen = 0;
     float row_rho = 0.f;
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
@@ -420,7 +426,7 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (ix->sweep_stream) hipStreamSynchronize(ix->sweep_stream);
     free_forest(ix);
     ix->X.release();
-    ix->row_hn2.release(); ix->row_norm.release(); ix->row_half.release(); ix->row_meta.release(); ix->row_rho_dev.release();
+    ix->row_hn2.release(); ix->row_norm.release(); ix->row_half.release(); ix->row_meta.release(); ix->row_rho_dev.release(); ix->row_half128.release();
     ix->dctx.release_all();
     DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
@@ -446,6 +452,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->norm_rows = 0; ix->norm_gen = 0;
     ix->row_hn2.release(); ix->row_norm.release();
     ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
+    ix->h128_rows = 0; ix->h128_gen = 0; ix->h128_rho = 0.f; ix->row_half128.release(); ix->h128_failed = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
     ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
     return ZH_OK;
@@ -1192,9 +1199,10 @@ extern "C" int zh_set_hash_mode(zh_index *ix, int mode) {
 }
 extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
     if (!ix) return fail(ZH_EINVAL, "null index");
-    if (mode < 0 || mode > 5)
+    if (mode < 0 || mode > 6)
         return fail(ZH_EINVAL, "sweep mode %d (0 = choose per batch, 1 = leaf by leaf, 2 = table scan with f32 queries, 3 = as 0: prefilter where row scores exist, "
-                               "4 = table scan with half-width queries wherever it applies, 5 = as 4 without the fp16 copy of the rows: the VALU kernel)", mode);
+                               "4 = table scan with half-width queries wherever it applies, 5 = as 4 without the fp16 copy of the rows: the VALU kernel, "
+                               "6 = leaf by leaf at half width where that kernel exists (dim 128))", mode);
     ix->sweep_mode = mode;
     return ZH_OK;
 }
@@ -1367,6 +1375,51 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
     return ZH_OK;
 }
 
+// The row-major fp16 copy of a d = 128 table under one scale (under blk_mu).  Appended rows that fit the scale are added; a larger element
+// than the scale allows re-makes the copy.
+static int ensure_row_half128(zh_index *ix, bool *ok) {
+    *ok = false;
+    const bool current = ix->h128_gen == ix->rows_gen && ix->h128_rows == ix->n_rows;
+    if (current) { *ok = !ix->h128_failed; return ZH_OK; }
+    ix->h128_failed = false;
+    size_t mem_free = 0, mem_total = 0;
+    const uint64_t want = std::max<uint64_t>(ix->n_rows, 1) * 256;
+    const bool room = want <= ix->row_half128.cap || (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
+    if (!room || ix->row_half128.ensure(want, true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(8) != ZH_OK) {
+        ix->row_half128.release();
+        ix->h128_failed = true;
+        ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
+        return ZH_OK;
+    }
+    uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows) ? ix->h128_rows : 0;
+    uint32_t *dmax = ix->row_rho_dev.as<uint32_t>() + 1;
+    for (int pass = 0; pass < 2; pass++) {
+        uint32_t mbits = 0;
+        HIPCHK(hipMemsetAsync(dmax, 0, 4, ix->stream));
+        HIPCHK(zh_launch_absmax(ix->X.as<float>() + from * 128, (ix->n_rows - from) * 128, dmax, ix->stream));
+        HIPCHK(hipMemcpyAsync(&mbits, dmax, 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        float m;
+        memcpy(&m, &mbits, 4);
+        int ex = 14;
+        if (m > 0.f) (void)frexpf(m, &ex);
+        ex = std::min(std::max(ex, -100), 100);
+        if (from == 0) { ix->h128_ex = ex; break; }
+        if (ex <= ix->h128_ex) break;
+        from = 0;  // the appended rows do not fit the scale: the whole copy again, under theirs
+    }
+    if (from == 0) HIPCHK(hipMemsetAsync(ix->row_rho_dev.p, 0, 4, ix->stream));
+    HIPCHK(zh_launch_row_half128(ix->X.as<float>(), from, ix->n_rows - from, ldexpf(1.f, 14 - ix->h128_ex), ix->row_half128.p,
+                                 ix->row_rho_dev.as<uint32_t>(), ix->stream));
+    float rho = 0.f;
+    HIPCHK(hipMemcpyAsync(&rho, ix->row_rho_dev.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->h128_rho = rho;
+    ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
+    *ok = true;
+    return ZH_OK;
+}
+
 // Leaf by leaf or the whole table once?  The leaf-major sweep gathers group_rows rows from HBM (5.9-6.1 TB/s of 3-KB rows,
 // 5.5 TB/s of 512-byte ones); the table scan streams every stored row once (plus 8 bytes per tree of row -> leaf entries) and
 // fetches one query from L2 per scored (row, query) pair -- measured 0.075 + 0.00022 d ns per pair chip-wide (4.1 G pairs/s
@@ -1385,6 +1438,7 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
     int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
     if (mode == 5) mode = 4;
+    if (mode == 6) mode = 1;
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
     if (mode == 2 || mode == 4) return true;
     if (!ix->row_leaf_valid && ix->batches_since_change.load() < 3) return false;  // (the row -> leaf table is built for a forest that stays)
@@ -1411,7 +1465,7 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
     static const bool off = getenv("ZH_NO_APPROX") != nullptr;
     int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
     if (mode == 5) mode = 4;
-    if (off || mode == 2 || mode == 1) return false;
+    if (off || mode == 2 || mode == 1 || mode == 6) return false;
     if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0 || B >= (1u << 24)) return false;  // (24 bits of a packed pair record)
     if (tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
     // by itself only where it pays: per pair it moves half the bytes, but a window of ONE cfg3 batch (4.3 pairs per stored row) gains 4 % on
@@ -1421,6 +1475,20 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
     if (mode != 4 && (ix->approx_strikes.load() >= 2 || !(mfma ? ix->opt.dim >= 256 : zh_approx_pays(ix->opt.dim)) ||
                       tot.rows < (mfma ? 2 : 5) * ix->n_rows))
         return false;
+    return true;
+}
+
+// The leaf-major sweep of a d = 128 table at half width (sweep128h_kernel)?  Where the f32 sweep is what HBM gives random 512-byte rows: long
+// leaves, many scored rows; the same list limits as the half-width scan.  zh_set_sweep_mode(6) asks for it wherever it is implemented,
+// (1) keeps the f32 sweep; ZH_NO_LEAF_HALF=1 switches it off.
+static bool use_approx_leaf(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric) {
+    static const bool off = getenv("ZH_NO_LEAF_HALF") != nullptr || getenv("ZH_NO_APPROX") != nullptr;
+    static const bool env_sweep = getenv("ZH_SWEEP_MODE") != nullptr;
+    if (off || ix->opt.dim != 128 || !zh_sweep_has_predicate(128, metric)) return false;
+    if (ix->sweep_mode != 6 && (env_sweep || (ix->sweep_mode != 0 && ix->sweep_mode != 3))) return false;
+    if (k > 256 || B == 0 || B >= (1u << 24) || tot.takes > 2048ull * B || tot.visits > 8ull * B * ix->n_trees) return false;
+    if (ix->h128_failed && ix->h128_gen == ix->rows_gen && ix->h128_rows == ix->n_rows) return false;
+    if (ix->sweep_mode != 6 && (ix->approx_strikes.load() >= 2 || tot.group_rows < (4u << 20))) return false;
     return true;
 }
 
@@ -1597,7 +1665,7 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
     c->nwin = nwin; c->bwin = bwin;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
-    c->approx = false;
+    c->approx = false; c->approx_leaf = false; c->approx_mfma = false;
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
@@ -1839,10 +1907,17 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     c->approx = c->scan && use_approx(ix, tot, B, k, c->metric);
+    c->approx_leaf = false;
+    if (!c->scan && !no_wave_table && use_approx_leaf(ix, tot, B, k, c->metric)) {
+        bool ok = false;
+        std::lock_guard<std::mutex> lk(ix->blk_mu);
+        if ((rc = ensure_row_half128(ix, &ok))) return rc;
+        c->approx = c->approx_leaf = ok;
+    }
     ZhApprox ap{};
     // the scan on the matrix cores, from an fp16 copy of the stored rows (+50 % of the row table, made on first use); no room for it, or mode 5:
     // the VALU kernel on the f32 rows
-    bool mfma = c->approx && mfma_wanted(ix);
+    bool mfma = c->approx && !c->approx_leaf && mfma_wanted(ix);
     if (mfma) {
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if ((rc = ensure_row_half(ix, &mfma))) return rc;
@@ -1871,10 +1946,11 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
         ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;
         ap.row_rho = mfma ? ix->row_rho : 0.f;
+        if (c->approx_leaf) { ap.mfma = 2u; ap.row_rho = ap.rho_norm = ix->h128_rho; }
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
         HIPCHK(hipMemsetAsync(ap.qtau, 0xFF, B * 4, s));
         HIPCHK(hipMemsetAsync(c->wApCtl.p, 0, ZH_APX_CTL_WORDS * 4, s));
-        HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), mfma, s));
+        HIPCHK(zh_launch_qhalf(c->dQ, (uint32_t)B, d, c->wQh.p, c->wQmeta.as<float4>(), c->approx_leaf ? 2 : (mfma ? 1 : 0), s));
     }
     HIPCHK(hipEventRecord(c->ev[2], s));
     // the HBM-bound sweep may run on a different ("heavy") stream shared by all contexts, so that sweeps of
@@ -1882,7 +1958,10 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     hipStream_t hs = heavy ? heavy : s;
     if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
-    if (c->approx)
+    if (c->approx_leaf)
+        HIPCHK(zh_launch_sweep128h(ix->row_half128.p, c->wQh.p, ldexpf(1.f, ix->h128_ex - 14), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(),
+                                   tot.groups, c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->wKeys.as<uint64_t>(), hs));
+    else if (c->approx)
         HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
                                      c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group, c->metric, c->mode, hs));
     else if (c->scan)
@@ -1907,9 +1986,13 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         // redo the batch in stream order -- kernels that return at once otherwise.  On the context's own stream: the shared sweep
         // stream must not wait for this batch's light kernels.
         run_if = ap.ctl + 1;
-        HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
-                                    c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group,
-                                    c->metric, c->mode, c->wKeys.as<uint64_t>(), run_if, s));
+        if (c->approx_leaf)
+            HIPCHK(zh_launch_sweep(ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups,
+                                   c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->metric, c->mode, c->wKeys.as<uint64_t>(), f.group, s, run_if));
+        else
+            HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
+                                        c->wVisitBits.as<uint32_t>(), c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group,
+                                        c->metric, c->mode, c->wKeys.as<uint64_t>(), run_if, s));
     }
     HIPCHK(zh_launch_select(c->wVisits.as<ZhVisit>(), tot.visits, f.leaf_ids, c->wKeys.as<uint64_t>(),
                             c->wCandKeys.as<uint64_t>(), c->wCandIds.as<uint32_t>(), ix->max_leaf_len, run_if, s));
@@ -1981,7 +2064,7 @@ int ctx_wait(zh_search_ctx *c) {
                                    : tot.group_rows * ((uint64_t)4 * ix->opt.dim + 4) + tot.rows * 8);
     st.table_scan = c->scan && !pf ? 1 : 0;
     const bool apx = c->approx && !pf;
-    st.approx_scan = apx ? (c->approx_mfma ? 2 : 1) : 0;
+    st.approx_scan = apx ? (c->approx_leaf ? 3 : (c->approx_mfma ? 2 : 1)) : 0;
     st.approx_exact_visits = apx ? c->h_ap[0] : 0;
     st.approx_survivors = apx ? c->h_ap[3] : 0;
     st.approx_list_entries = apx ? c->h_ap[4] : 0;

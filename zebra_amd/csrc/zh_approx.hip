@@ -65,8 +65,8 @@ bool zh_approx_pays(uint32_t d) { return d >= 384; }
 // mfma (scan_mfma_kernel): s is the sum of four MFMA accumulators, ops = 33 d / 128 + 2 operations of at most 2 u each on its longest chain
 // instead of 33 of u: |s / sigma - x.q| gains (2 ops - 33) u |x||q| -- in V's scale 2 |x||q| <= (|x| + |q|)^2 / 2, i.e. + ops u; in the cosine's + 2 ops u.
 // The rounding of the ROW (|x - xh / sigma_x| <= rho |x|) is approx_interval's `rho` term.
-float zh_approx_bound(int metric, uint32_t d, bool mfma) {
-    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0, ops = mfma ? 33.0 * (d / 128) + 2.0 : 0.0;
+float zh_approx_bound(int metric, uint32_t d, int mfma) {  // 0 the VALU scans, 1 scan_mfma_kernel, 2 sweep128h_kernel (|x|^2 from 16 v_dot2 of the rounded row: + 40)
+    const double u = 5.9604644775390625e-8, c0 = (d + 255) / 256 + 8.0, ops = mfma ? 33.0 * (d / 128) + 2.0 + (mfma == 2 ? 40.0 : 0.0) : 0.0;
     if (metric == ZH_COSINE) return (float)(1.01 * (2.0 * c0 + 80.0 + 2.0 * ops) * u);
     return (float)(1.01 * (c0 + 100.0 + ops) * u);
 }
@@ -119,10 +119,12 @@ __global__ __launch_bounds__(64) void qhalf_kernel(const float *__restrict__ Q, 
     }
 }
 
-hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, bool mfma, hipStream_t s) {
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, int layout, hipStream_t s) {
     if (!B) return hipSuccess;
-    const uint32_t G = mfma ? 16 : zh_approx_groups(d);  // (the MFMA scan's k-groups are four lanes wide)
-    if (G == 16) hipLaunchKernelGGL(qhalf_kernel<16>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    // layout 0: the VALU scan's groups; 1: the MFMA scan's k-groups (four lanes wide); 2: natural order (LG = 1; sweep128h_kernel)
+    const uint32_t G = layout == 2 ? 64 : (layout == 1 ? 16 : zh_approx_groups(d));
+    if (G == 64) hipLaunchKernelGGL(qhalf_kernel<64>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
+    else if (G == 16) hipLaunchKernelGGL(qhalf_kernel<16>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 8) hipLaunchKernelGGL(qhalf_kernel<8>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 4) hipLaunchKernelGGL(qhalf_kernel<4>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
     else if (G == 2) hipLaunchKernelGGL(qhalf_kernel<2>, dim3(B), dim3(64), 0, s, dQ, B, d, (_Float16 *)dQh, dQmeta);
@@ -147,14 +149,15 @@ __device__ __forceinline__ float group_sum(float s) {
 
 // the interval of one (row, query) pair from its sums: sortable lo | sortable hi << 32; (0, all ones) = nothing certain
 template <int KINDA>
-__device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc, float rho) {
+__device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc, float rho, float rho_n) {
     uint32_t lo_s = 0u, hi_s = 0xFFFFFFFFu;
     const float sh = s * qm.x;
     if (KINDA == 0) {
-        const float nx = sqrtf(a2) * (1.0f + 1e-5f), nn = nx + qm.z, sum = a2 + qm.y;
+        // rho_n != 0: a2 is the ROUNDED row's |x'|^2 (sweep128h_kernel): |x| <= |x'| (1 + 2 rho_n), ||x'|^2 - |x|^2| <= 2.2 rho_n |x'|^2
+        const float nx = sqrtf(a2) * (1.0f + 1e-5f) * (1.0f + 2.0f * rho_n), nn = nx + qm.z, sum = a2 + qm.y;
         const float V = sum - 2.0f * sh;
         // |s / sigma - x.q| <= |x| dq + |x - x'| (|q| + dq), |x - x'| <= rho |x| (rho = 0: the scan multiplied the f32 row)
-        const float E = Kc * nn * nn + 2.02f * nx * (qm.w + rho * (qm.z + qm.w));
+        const float E = Kc * nn * nn + 2.02f * nx * (qm.w + rho * (qm.z + qm.w)) + 2.2f * rho_n * nx * nx;
         if ((V - V == 0.f) && (E - E == 0.f) && nn > 1e-12f && sum < 1e37f) { lo_s = f32_sortable(V - E); hi_s = f32_sortable(V + E); }
     } else {
         const float nx = sqrtf(a2), nq = sqrtf(qm.y);
@@ -162,7 +165,7 @@ __device__ __forceinline__ uint64_t approx_interval(float s, float a2, const flo
             float r = 1.0f - sh / (nx * nq);
             r = r > 0.f ? r : 0.f;
             const float dqr = qm.w / nq;
-            const float e = Kc + 1.01f * (dqr + rho * (1.0f + dqr));
+            const float e = Kc + 1.01f * (dqr + rho * (1.0f + dqr) + rho_n);
             float v = r;
             bool ok = true;
             if (KINDA == 2) {  // ZH_COSINE_PARITY keys compare as the bits of 1 - distance: as pf_value<2>
@@ -718,6 +721,207 @@ static hipError_t launch_scan_mfma_d(const float *dX, uint64_t n_rows, const ZhA
     return hipGetLastError();
 }
 
+// ---- d = 128, leaf by leaf, at half width: the sweep of SIFT-style shards (cfg5) on the matrix cores ----
+// The leaf-major sweep of 512-byte rows runs at what HBM gives random rows (0.82-0.88 of the measured gather ceiling, round 3), and a random
+// 256-byte row costs HBM half of a 512-byte one (profiles/micro/gather512.hip: 6.6 TB/s for both): the lever is the ROW's bytes.  The index
+// keeps an fp16 copy of its rows (row-major, ONE power-of-two scale for the table: integer-valued SIFT rows are exact; a row that does not
+// survive the common scale within 2^-10 of its norm -- or holds a non-finite element -- is stored as NaNs and lands on the exact path), the
+// batch's queries get qhalf_kernel's fp16 copy in natural order, and a wave takes its 64 flat rows as four MFMA tiles: the queries of up to
+// four groups are the 16 rows of A (group g of the set in rows 4 g .. 4 g + 3), 16 stored rows the columns of B, 4 MFMAs (K = 128) give
+// every (query, row) product of the tile, and lane (c, h) -- stored row c, group h of the set -- stores its group's results where the f32
+// sweep stores keys: the raw {x^ . h^ / sigma_X, |x^|^2 / sigma_X^2} that select_tau_kernel turns into intervals.  Rows are loaded whole
+// (four 256-byte rows per instruction), pass through the wave's LDS tile (XOR-swizzled 16-byte pieces) and come back as B fragments.
+// |x|^2 comes from the ROUNDED row: approx_interval's rho_n term.
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ X, uint64_t n, uint32_t *__restrict__ out) {
+    float m = 0.f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(X[i]);
+        if (v - v == 0.f) m = fmaxf(m, v);  // (finite elements only)
+    }
+    m = wave_butterfly<OpMax>(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void row_half128_kernel(const float *__restrict__ X, uint64_t row0, uint64_t n_rows, float sigma,
+                                                          _Float16 *__restrict__ Xh, uint32_t *__restrict__ rhoMax) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    float rho_w = 0.f;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_rows; i += nw) {
+        const uint64_t row = row0 + i;
+        const float2 x = reinterpret_cast<const float2 *>(X + (size_t)row * 128)[lane];
+        const float v0 = x.x * sigma, v1 = x.y * sigma;
+        bool bad = !(v0 - v0 == 0.f) || !(v1 - v1 == 0.f) || fabsf(v0) > 60000.f || fabsf(v1) > 60000.f;
+        const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+        const float d0 = v0 - (float)h0, d1 = v1 - (float)h1;
+        const float s2 = wave_sum_canonical(__builtin_fmaf(v0, v0, v1 * v1));
+        const float d2 = wave_sum_canonical(__builtin_fmaf(d0, d0, d1 * d1));
+        const float m = wave_butterfly<OpMax>(fmaxf(fabsf(x.x), fabsf(x.y)));
+        bad = __ballot(bad) != 0 || !(s2 - s2 == 0.f) || (s2 == 0.f && m > 0.f);
+        const float rho = s2 > 0.f ? sqrtf(d2) * 1.001f / (sqrtf(s2) * 0.9999f) : 0.f;
+        bad = bad || !(rho <= 9.765625e-4f);
+        if (!bad) rho_w = fmaxf(rho_w, rho);
+        const _Float16 nanh = (_Float16)__uint_as_float(0x7FC00000u);
+        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+        reinterpret_cast<f16x2v *>(Xh + (size_t)row * 128)[lane] = bad ? f16x2v{nanh, nanh} : f16x2v{h0, h1};
+    }
+    if (lane == 0 && rho_w > 0.f) atomicMax(rhoMax, __float_as_uint(rho_w));
+}
+
+hipError_t zh_launch_absmax(const float *dX, uint64_t n, uint32_t *dOut, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(absmax_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s, dX, n, dOut);
+    return hipGetLastError();
+}
+hipError_t zh_launch_row_half128(const float *dX, uint64_t row0, uint64_t n_rows, float sigma, void *dXh, uint32_t *dRhoMax, hipStream_t s) {
+    if (!n_rows) return hipSuccess;
+    hipLaunchKernelGGL(row_half128_kernel, dim3((uint32_t)std::min<uint64_t>((n_rows + 3) / 4, 256 * 32)), dim3(256), 0, s, dX, row0, n_rows, sigma,
+                       (_Float16 *)dXh, dRhoMax);
+    return hipGetLastError();
+}
+
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8_self(const f16x8 v, float c) {
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(v, v, 2, 3), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 4, 5), __builtin_shufflevector(v, v, 4, 5), c, false);
+    return __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), __builtin_shufflevector(v, v, 6, 7), c, false);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
+                                                         const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                                                         uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                                                         const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                                                         uint64_t *__restrict__ iv) {
+    __shared__ u32x4v rows_lds[4][16 * 16];  // per wave: ONE tile = 16 rows x 16 pieces of 16 bytes, piece p of row R at R * 16 + (p ^ R)
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    uint64_t r0 = row_begin + wave * (64 * CH);
+    if (r0 >= R_grouped) return;
+    uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+    uint32_t my_g, my_id, my_within, my_off, my_len;
+    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
+    u32x4v *tl = rows_lds[wid];
+    f16x8 Aq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t a_g0 = 0xFFFFFFFFu;  // the groups whose queries A holds: a_g0 .. a_g0 + 3 (wave-uniform)
+    // a tile's rows, whole: instruction i = the tile's rows 4 i .. 4 i + 3, lane (h, c16) the 16-byte piece c16 of row 4 i + h.  ONE register
+    // set: once a tile is written to LDS its registers take the next tile's loads (across chunk boundaries, where the next chunk's rows
+    // are known), which travel while this tile is multiplied.
+    u32x4v R[4];
+    auto issue_tile = [&](uint32_t ids, uint32_t n, uint32_t t) {  // flat rows 16 t .. 16 t + 15 of a chunk of n rows whose ids the lanes hold
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t fr = 16u * t + 4u * i + h;
+            const uint32_t id = (uint32_t)__shfl((int)ids, (int)(fr < n ? fr : n - 1));
+            R[i] = __builtin_nontemporal_load(Xh + (size_t)id * 16 + c16);
+        }
+    };
+    issue_tile(my_id, cnt, 0);
+    for (int c = 0; c < CH; c++) {
+        // the next chunk: does it lie entirely in the group this chunk's last row belongs to?  (wave-uniform; as sweep128_kernel)
+        const uint64_t r0n = r0 + 64;
+        const bool have_next = c + 1 < CH && r0n < R_grouped;
+        const uint32_t cntn = have_next ? (uint32_t)(R_grouped - r0n < 64 ? R_grouped - r0n : 64) : 0;
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)my_within, (int)cnt - 1) + 1;
+        const uint32_t loff = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)cnt - 1);
+        const uint32_t llen = (uint32_t)__builtin_amdgcn_readlane((int)my_len, (int)cnt - 1);
+        const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)cnt - 1);
+        const bool fast = have_next && cnt == 64 && (uint64_t)lw + cntn <= llen;
+        uint32_t nxt_id = 0;
+        if (fast) {
+            const uint32_t wn = lw + (lane < cntn ? lane : cntn - 1);
+            nxt_id = leaf_ids ? leaf_ids[(size_t)loff + wn] : loff + wn;
+        }
+        const uint32_t ntile = (cnt + 15) / 16;
+#pragma unroll 1
+        for (uint32_t t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + h;
+                tl[rr * 16 + (c16 ^ rr)] = R[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (t + 1 < ntile) issue_tile(my_id, cnt, t + 1);
+            else if (fast) issue_tile(nxt_id, cntn, 0);
+            f16x8 Bf[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t fr = 16 * t + c16;                       // this lane's column: flat row fr of the chunk
+            const uint32_t last = 16 * t + 15 < cnt ? 16 * t + 15 : cnt - 1;
+            const uint32_t g_first = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)(16 * t));
+            const uint32_t g_last = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)last);
+            const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
+            const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
+            float a2 = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; st++) a2 = dot8_self(Bf[st], a2);
+            a2 = xor16<OpAdd>(a2);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(a2), false, false);
+                a2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            for (uint32_t gp = g_first; gp <= g_last; gp += 4) {
+                if (gp != a_g0) {  // (wave-uniform) the queries of groups gp .. gp + 3: A's row m = slot m & 3 of group gp + (m >> 2)
+                    a_g0 = gp;
+                    const uint32_t grp = gp + (c16 >> 2);
+                    const bool on = grp < n_groups && (c16 & 3u) < groups[grp < n_groups ? grp : 0].gsize;
+                    const uint32_t b = on ? groups[grp].b[c16 & 3u] : 0u;
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                        Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+                f32x4v acc[4];
+#pragma unroll
+                for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4v dsum = (acc[0] + acc[1]) + (acc[2] + acc[3]);  // [i] = query slot i of group gp + h against stored row c16 of the tile
+                if (fr < cnt && rg == gp + h) {
+                    const ZhGroup *G = groups + rg;
+                    const uint32_t gs = G->gsize;
+                    const uint32_t a2b = __float_as_uint(a2 * inv * inv);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((uint32_t)i < gs)
+                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv), iv + G->key_off[i] + rw);
+                }
+            }
+        }
+        if (!have_next) break;
+        r0 = r0n; cnt = cntn;
+        if (fast) {
+            my_g = lg; my_off = loff; my_len = llen;
+            my_within = lw + (lane < cntn ? lane : cntn - 1);
+            my_id = nxt_id;
+        } else {
+            resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
+            issue_tile(my_id, cnt, 0);
+        }
+    }
+}
+
+hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s) {
+    if (R_grouped == 0 || n_groups == 0) return hipSuccess;
+    constexpr int CH = 4;
+    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+    for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
+        const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
+        const uint64_t w = (r_end - r + 64 * CH - 1) / (64 * CH), blocks = (w + 3) / 4;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                           dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
+    }
+    return hipGetLastError();
+}
+
 // (Measured and not kept, round 4: phase 1 as a kernel of its own -- scan_pairs_kernel wrote every 16-row unit's pair records (8 bytes
 // each, compacted through one atomic per unit) and a "listed" scan kernel started from them with independent loads only.  cfg3, window
 // 2: the pairs kernel ~4 ms per batch, the listed scan 6.5 against 4.7 ms per launch beside it, 100 k against 142 k QPS.  Phase 1 is
@@ -880,7 +1084,7 @@ static hipError_t launch_scan_approx_d(const float *dX, uint64_t n_rows, const Z
     const uint32_t RW = zh_scan_rows_per_wave(T);
     uint64_t rows_per_launch = zh_sweep_rows_per_launch(D);
     rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
-    const float Kc = zh_approx_bound(metric, D, false);
+    const float Kc = zh_approx_bound(metric, D, 0);
     const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
     for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
@@ -921,7 +1125,7 @@ hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, Z
         const uint32_t RW = zh_scan_rows_per_wave(T);
         uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
         rows_per_launch = rows_per_launch / (4 * RW) * (4 * RW);
-        const float Kc = zh_approx_bound(metric, 128, false);
+        const float Kc = zh_approx_bound(metric, 128, 0);
         const int kinda = metric == ZH_COSINE ? (mode == ZH_COSINE_PARITY ? 2 : 1) : 0;
         for (uint64_t r = 0; r < n_rows; r += rows_per_launch) {
             const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
@@ -1002,7 +1206,7 @@ __global__ __launch_bounds__(256) void select_tau_kernel(const ZhVisit *__restri
             uint64_t *__restrict__ raw = ap.iv + v.row_off;
             for (uint32_t i = tid; i < v.len; i += 256) {
                 const uint64_t w = raw[i];
-                raw[i] = approx_interval<KINDA>(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)), qm, Kc, ap.row_rho);
+                raw[i] = approx_interval<KINDA>(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)), qm, Kc, ap.row_rho, ap.rho_norm);
             }
             __syncthreads();
         }
@@ -1322,7 +1526,7 @@ hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, 
     uint64_t chunk = (n_visits + 16383) / 16384;
     if (chunk > 256) chunk = 256;
     const uint64_t blocks = (n_visits + chunk - 1) / chunk;
-    const float Kc = zh_approx_bound(metric, d, ap.mfma != 0);
+    const float Kc = zh_approx_bound(metric, d, (int)ap.mfma);
     if (metric != ZH_COSINE)
         hipLaunchKernelGGL(select_tau_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, s, dVisits, n_visits, (uint32_t)chunk, k, Kc, ap);
     else if (mode == ZH_COSINE_PARITY)

@@ -417,3 +417,31 @@ __device__ __forceinline__ uint32_t f32_sortable(float x) {
     const uint32_t u = __float_as_uint(x);
     return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
+
+// ---- the leaf-major sweeps' view of a batch: flat rows = the rows of group 0, then group 1, ... (moved out of zh_search.hip) ----
+// lane i of a sweep wave -> (group, stored row, position in the group) of flat row r0 + i.  With the wave-start table the
+// search is confined to the <= 64 groups the wave's 64 rows can span (every group has at least one row), and skipped when
+// the whole wave lies in one group (the common case with leaves of thousands of rows).
+__device__ __forceinline__ void resolve_flat_rows(uint64_t r0, uint32_t cnt, uint32_t lane, const ZhGroup *__restrict__ groups,
+                                                  const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                                  const uint32_t *__restrict__ waveGroup, const uint32_t *__restrict__ leaf_ids,
+                                                  uint32_t &my_g, uint32_t &my_id, uint32_t &my_within,
+                                                  uint32_t *my_leaf_off = nullptr, uint32_t *my_len = nullptr) {
+    const uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
+    uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
+    if (waveGroup) {
+        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)waveGroup[r0 >> 6]);
+        hi = lo + 64 < n_groups ? lo + 64 : n_groups;
+        if (lo + 1 >= n_groups || groupRowOff[lo + 1] > r0 + cnt - 1) hi = lo + 1;  // wave-uniform: one group
+    }
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (groupRowOff[mid] <= r) lo = mid; else hi = mid;
+    }
+    my_g = (uint32_t)lo;
+    my_within = (uint32_t)(r - groupRowOff[lo]);
+    const uint32_t lo_off = groups[lo].leaf_off;
+    if (my_leaf_off) *my_leaf_off = lo_off;
+    if (my_len) *my_len = groups[lo].len;
+    my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
+}

@@ -172,7 +172,8 @@ hipError_t zh_launch_walk_emit(ZhForestDev f, const float *dQ, uint32_t B, uint3
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dWaveGroup,
                            const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int mode, uint64_t *dKeys,
-                           uint32_t group, hipStream_t s);
+                           uint32_t group, hipStream_t s, const uint32_t *dRunIf = nullptr);
+bool zh_sweep_has_predicate(uint32_t d, int metric);
 // waveGroup[w] = group of flat row 64 w, for every wave start of [0, R_grouped)
 hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups, uint32_t *dWaveGroup,
                                  hipStream_t s);
@@ -236,18 +237,24 @@ struct ZhApprox {
     const void *row_half;    // the fp16 copy of the stored rows, tiles of 16 rows in the A operand's order (row_half_kernel)
     const float2 *row_meta;  // per stored row {|x|^2, 1 / sigma_x (NaN: nothing certain about the row)}
     float row_rho;           // |x - xh / sigma_x| <= row_rho |x| for every usable stored row (0 with f32 rows)
-    uint32_t mfma;
+    float rho_norm;          // = row_rho where |x|^2 itself comes from the rounded row (sweep128h_kernel), else 0
+    uint32_t mfma;           // zh_approx_bound's kind: 0 VALU scans, 1 scan_mfma_kernel, 2 sweep128h_kernel
 };
 uint32_t zh_approx_groups(uint32_t d);
 bool zh_approx_pays(uint32_t d);
-float zh_approx_bound(int metric, uint32_t d, bool mfma);
+float zh_approx_bound(int metric, uint32_t d, int mfma);
 bool zh_scan_mfma_supported(uint32_t d, uint32_t T);
 // the fp16 copy of rows [row0, row0 + n_rows) in scan_mfma_kernel's operand order (2 * d bytes per row, tiles of 16 rows), per row {|x|^2,
 // 1 / sigma_x}; *dRhoMax = the largest relative rounding error of a row (f32 bits, atomicMax)
 hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
                               hipStream_t s);
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
-hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, bool mfma, hipStream_t s);
+hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, int layout, hipStream_t s);
+// d = 128, leaf by leaf at half width (sweep128h_kernel): the table's common scale from its largest finite element, the row-major fp16 copy, the sweep
+hipError_t zh_launch_absmax(const float *dX, uint64_t n, uint32_t *dOut, hipStream_t s);
+hipError_t zh_launch_row_half128(const float *dX, uint64_t row0, uint64_t n_rows, float sigma, void *dXh, uint32_t *dRhoMax, hipStream_t s);
+hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s);
 hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
                                  const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
                                  int mode, hipStream_t s);

@@ -1120,32 +1120,6 @@ hipError_t zh_launch_wave_groups(const ZhGroup *dGroups, const uint64_t *dGroupR
     return hipGetLastError();
 }
 
-// lane i of a sweep wave -> (group, stored row, position in the group) of flat row r0 + i.  With the wave-start table the
-// search is confined to the <= 64 groups the wave's 64 rows can span (every group has at least one row), and skipped when
-// the whole wave lies in one group (the common case with leaves of thousands of rows).
-__device__ __forceinline__ void resolve_flat_rows(uint64_t r0, uint32_t cnt, uint32_t lane, const ZhGroup *__restrict__ groups,
-                                                  const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
-                                                  const uint32_t *__restrict__ waveGroup, const uint32_t *__restrict__ leaf_ids,
-                                                  uint32_t &my_g, uint32_t &my_id, uint32_t &my_within,
-                                                  uint32_t *my_leaf_off = nullptr, uint32_t *my_len = nullptr) {
-    const uint64_t r = r0 + (lane < cnt ? lane : cnt - 1);
-    uint64_t lo = 0, hi = n_groups;  // last group with row offset <= r
-    if (waveGroup) {
-        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)waveGroup[r0 >> 6]);
-        hi = lo + 64 < n_groups ? lo + 64 : n_groups;
-        if (lo + 1 >= n_groups || groupRowOff[lo + 1] > r0 + cnt - 1) hi = lo + 1;  // wave-uniform: one group
-    }
-    while (hi - lo > 1) {
-        uint64_t mid = (lo + hi) >> 1;
-        if (groupRowOff[mid] <= r) lo = mid; else hi = mid;
-    }
-    my_g = (uint32_t)lo;
-    my_within = (uint32_t)(r - groupRowOff[lo]);
-    const uint32_t lo_off = groups[lo].leaf_off;
-    if (my_leaf_off) *my_leaf_off = lo_off;
-    if (my_len) *my_len = groups[lo].len;
-    my_id = leaf_ids ? leaf_ids[(size_t)lo_off + my_within] : lo_off + my_within;
-}
 
 // one row against the (up to G) queries of its group.  s0[m] (and s1[m] for Bray-Curtis) are per
 // member; for cosine s1[0] carries a2, the stored row's norm, shared by the members
@@ -1309,8 +1283,9 @@ __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__
                                                         const uint32_t *__restrict__ waveGroup,
                                                         const uint32_t *__restrict__ leaf_ids, uint64_t row_begin,
                                                         uint64_t R_grouped, int metric, int param,
-                                                        uint64_t *__restrict__ keys) {
+                                                        uint64_t *__restrict__ keys, const uint32_t *__restrict__ run_if) {
     static_assert(KIND == K_L2 || KIND == K_COS, "the half-wave sweep covers the two simsimd-path kinds");
+    if (run_if && *run_if == 0) return;  // (the redo behind a half-width sweep whose lists did not run over: zh_approx.hip)
     const uint32_t lane = threadIdx.x & 63, hl = lane & 31;
     const bool up = lane >= 32;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1425,6 +1400,7 @@ struct SweepArgs {
     const ZhGroup *dGroups; const uint64_t *dGroupRowOff; uint64_t n_groups;
     const uint32_t *dWaveGroup;  // wave-start table (zh_launch_wave_groups) or nullptr: full binary search per lane
     const uint32_t *dLeafIds; uint64_t R_grouped; int metric, param; uint64_t *dKeys; uint32_t group; hipStream_t s;
+    const uint32_t *dRunIf;  // a predicate on the device (d = 128 half-wave kernel only): the launch returns at once when it is zero
 };
 
 template <int D, int KIND, int G>
@@ -1450,7 +1426,7 @@ static hipError_t launch_sweep_g(const SweepArgs &a) {
                 static const int ch128 = [] { const char *e = getenv("ZH_SWEEP128_CHUNKS"); return e ? atoi(e) : 4; }();
 #define ZH_S128(RG_, CH_) do { const uint64_t w_ = (r_end - r + 64 * CH_ - 1) / (64 * CH_);                                          \
                                hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true, CH_>), dim3((uint32_t)((w_ + 3) / 4)), blk, 0, a.s, a.dX, a.dQ, a.dQQ, \
-                                                  a.dGroups, a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys); } while (0)
+                                                  a.dGroups, a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys, a.dRunIf); } while (0)
                 if (ch128 == 1) ZH_S128(8, 1);
                 else if (ch128 == 8) ZH_S128(8, 8);
                 else if (v128 == 4) ZH_S128(4, 4);
@@ -1508,6 +1484,13 @@ static hipError_t launch_sweep_kind(const SweepArgs &a) {
 #undef ZH_SWEEP_CASE
 }
 
+// the leaf-major sweep that takes a device-side predicate: the d = 128 half-wave kernel of the two simsimd-path kinds (not under ZH_SWEEP128=0)
+bool zh_sweep_has_predicate(uint32_t d, int metric) {
+    static const int v128 = [] { const char *e = getenv("ZH_SWEEP128"); return e ? atoi(e) : 8; }();
+    const int kind = zh_kind_of(metric);
+    return d == 128 && v128 > 0 && (kind == K_L2 || kind == K_COS);
+}
+
 uint32_t zh_group_size(uint32_t dim) {
     static const int forced = [] { const char *e = getenv("ZH_GROUP"); return e ? atoi(e) : 0; }();
     if (forced == 2 || forced == 4) return (uint32_t)forced;
@@ -1517,10 +1500,11 @@ uint32_t zh_group_size(uint32_t dim) {
 hipError_t zh_launch_sweep(const float *dX, uint32_t d, const float *dQ, const float *dQQ, const ZhGroup *dGroups,
                            const uint64_t *dGroupRowOff, uint64_t n_groups, const uint32_t *dWaveGroup,
                            const uint32_t *dLeafIds, uint64_t R_grouped, int metric, int param, uint64_t *dKeys,
-                           uint32_t group, hipStream_t s) {
+                           uint32_t group, hipStream_t s, const uint32_t *dRunIf) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
+    if (dRunIf && !zh_sweep_has_predicate(d, metric)) return hipErrorInvalidValue;
     const SweepArgs a{dX, d, dQ, dQQ, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, metric, param, dKeys,
-                      group == 4 ? 4u : 2u, s};
+                      group == 4 ? 4u : 2u, s, dRunIf};
 #define ZH_KIND_CASE(K) case K: return launch_sweep_kind<K>(a)
     switch (zh_kind_of(metric)) {
         ZH_KIND_CASE(K_COS);

@@ -278,8 +278,8 @@ class LSHIndex:
 
     def set_sweep_mode(self, mode):
         """0 = chosen per batch (default: a batch hashed from row scores is prefiltered, not swept), 1 = leaf by leaf, 2 = table
-        scan with f32 queries, 3 = as 0, 4 = table scan with half-width queries wherever it applies, 5 = as 4 with the VALU kernel only, no fp16 copy of the rows (zh_set_sweep_mode)"""
-        check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2, "prefilter": 3, "approx": 4, "approx-valu": 5}.get(mode, mode)))
+        scan with f32 queries, 3 = as 0, 4 = table scan with half-width queries wherever it applies, 5 = as 4 with the VALU kernel only, no fp16 copy of the rows, 6 = leaf by leaf at half width where implemented: dim 128 (zh_set_sweep_mode)"""
+        check(lib().zh_set_sweep_mode(self._h, {"auto": 0, "leaf": 1, "scan": 2, "prefilter": 3, "approx": 4, "approx-valu": 5, "leaf-half": 6}.get(mode, mode)))
 
     def set_hash_mode(self, mode):
         """0 = chosen per batch (default), 1 = one dot product per plane, 2 = from row scores (zh_set_hash_mode)"""
