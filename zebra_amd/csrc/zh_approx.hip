@@ -788,8 +788,15 @@ __device__ __forceinline__ float dot8_self(const f16x8 v, float c) {
     return __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), __builtin_shufflevector(v, v, 6, 7), c, false);
 }
 
+#ifndef ZH_S128H_WAVES
+#define ZH_S128H_WAVES 0   // A/B: force this many waves per SIMD (registers spill past 4)
+#endif
 template <int CH>
-__global__ __launch_bounds__(256) void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
+__global__ __launch_bounds__(256)
+#if ZH_S128H_WAVES
+__attribute__((amdgpu_waves_per_eu(ZH_S128H_WAVES, ZH_S128H_WAVES)))
+#endif
+void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
                                                          const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
                                                          uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
                                                          const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
