@@ -80,7 +80,7 @@ WORKLOADS = {
 # what the N = 1 run measures besides `value`: (key, workload, shards it is one of, steps[, window])
 # cfg3_window_of_one: the bench line's workload with every batch its own internal batch -- the latency / throughput trade of --window
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
-OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg2", "cfg2", 1, 40), ("cfg4_one_of_8_shards", "cfg4", 8, 12),
+OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg4_one_of_8_shards", "cfg4", 8, 12), ("cfg2", "cfg2", 1, 40),
                  ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6)]
 
 
