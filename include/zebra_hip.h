@@ -157,7 +157,8 @@ typedef struct zh_stats_t {
     uint64_t approx_scan;           /* 1: the most recent batch's table scan read HALF-WIDTH (fp16) copies of the queries: every (row, query)
                                      * pair got an interval that contains the reference's key, the intervals picked the candidates, and only
                                      * the rows they could not rule out were scored with the reference's arithmetic (zh_set_sweep_mode);
-                                     * 2: the same with the products on the matrix cores, from the index's fp16 copy of the stored rows */
+                                     * 2: the same with the products on the matrix cores, from the index's fp16 copy of the stored rows;
+                                     * 3: 128-d rows leaf by leaf from their fp16 copy (table_scan = 0) */
     uint64_t approx_exact_visits;   /* ... leaf visits that take fewer than top_k rows: scored and ranked exactly */
     uint64_t approx_survivors;      /* ... rows (over all queries) that got the reference's key for the final top_k */
     uint64_t approx_list_entries;   /* ... candidates handed to the per-query stage (before de-duplication) */
@@ -431,7 +432,11 @@ ZH_API int zh_set_dense_levels(zh_index *idx, int levels);
  * table; skipped, and the f32 rows read by a VALU kernel instead, when less than that plus a sixteenth of the device is free).
  * A list that runs over is redone by the f32 scan on the device, in stream order (no host round trip: safe for callers that
  * consume results in stream order).  Mode 2 keeps the f32 scan; 4 = the half-width scan wherever it is implemented (dim 128 ...
- * 1024), whatever the cost model says; 5 = as 4 with the VALU kernel only (no copy of the rows).  zh_stats_t::approx_* report it. */
+ * 1024), whatever the cost model says; 5 = as 4 with the VALU kernel only (no copy of the rows).
+ * 128-d tables (SIFT-style shards) whose batches score 4M rows or more leaf by leaf get the same treatment on the leaf-major sweep: a row-major
+ * fp16 copy of the rows under ONE power-of-two scale (+ 256 bytes per stored row; exact for integer-valued rows; rows the scale does not serve
+ * are scored exactly), 16-row tiles on the matrix cores, the same intervals and exact passes behind; 6 = that sweep wherever it is
+ * implemented, 1 keeps the f32 sweep.  zh_stats_t::approx_* report it. */
 ZH_API int zh_set_sweep_mode(zh_index *idx, int mode);
 /* How a batch that needs EVERY sign of the forest (small leaves: the reference's default max_node_size 5) gets them:
  * 1 = one dot product per (query, plane), 2 * b * planes * dim flop on the matrix cores; 2 = from row scores: a plane is built from
