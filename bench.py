@@ -822,6 +822,12 @@ def pmc_traffic(args, name, S, roof):
         if ent.get("l2_hit_rate") is not None:
             roof["l2_hit_rate"] = ent["l2_hit_rate"]
             roof["l2_request_bytes_per_launch"] = ent.get("l2_request_bytes_per_launch")
+            if roof["bound"] == "l2" and ent.get("l2_request_bytes_per_launch") and roof.get("launch_ms"):
+                # ALL of the kernel's L2 requests (TCC_REQ x 128 B: operands + row -> leaf entries, visit records, stores), over this run's launch
+                # time, against the same peak: how close the scan is to what the L2s answer, where `frac` counts the algorithmic operand bytes only
+                g = ent["l2_request_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
+                roof["l2_requests_GBps"] = g
+                roof["l2_requests_frac_of_peak"] = g / roof["peak"]
         roof["traffic_source"] = {"file": os.path.relpath(cands[-1], ROOT), "collected_at_commit": meta.get("commit"),
                                   "collected_at_kernel_sources_sha": meta.get("kernel_sources_sha"),
                                   "kernel_sources_sha_now": kernel_sources_sha(),
