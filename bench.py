@@ -904,7 +904,8 @@ def main():
                                                                "rows_per_launch", "rows_loaded_per_launch", "window_batches", "sweep_mode", "hbm_bytes_by_design_per_launch",
                                                                "hbm_frac", "s8d_equivalent_GBps", "measured_gather_ceiling_GBps", "frac_of_measured_gather_ceiling",
                                                                "measured_l2_gather_ceiling_GBps", "frac_of_measured_l2_gather", "query_bytes_per_pair",
-                                                               "traffic", "traffic_over_hbm_by_design", "traffic_over_algorithmic", "traffic_source", "l2_hit_rate",
+                                                               "traffic", "traffic_over_hbm_by_design", "traffic_over_algorithmic", "traffic_source", "l2_hit_rate", "l2_request_bytes_per_launch",
+                                                               "l2_requests_GBps", "l2_requests_frac_of_peak", "row_bytes_per_stored_row",
                                                                "visits_per_launch", "sector_GBps", "exact_rows_per_launch", "exact_visits_per_launch", "prefilter_fallbacks", "note")
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
