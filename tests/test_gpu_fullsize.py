@@ -222,6 +222,52 @@ def test_cfg5_full_shard_125m_128d_sift_l2_top10_batch4096():
            n_total=1_000_000_000)
 
 
+def _every_sweep_agrees(za, n, d, metric_name, k, B, M, T, modes, kind=0, rows0=0, n_total=None):
+    """one full-size index, the SAME batch under every sweep kind that serves it: ids, keys and counts of ALL queries must be equal bit for
+    bit (the default kind is compared with the oracle in the tests above; this ties every other kernel to it at full size)"""
+    n_total = n_total or n
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=rows0, reserve_rows=n)
+    ix.append_synthetic(n, first_row=rows0, kind=kind)
+    ix.build()
+    Q = zo.synth_queries(B, d, n_total, kind=kind)
+    m = _metrics(za)[metric_name][0]
+    ref, seen = None, {}
+    for mode, code in modes:
+        ix.set_sweep_mode(mode)
+        got = ix.search_batch(Q, k, m)
+        st = ix.stats()
+        assert st["approx_scan"] == code, (mode, st["approx_scan"], st["table_scan"])
+        seen[mode] = st["rows_swept"]
+        if ref is None:
+            ref = got
+        else:
+            assert all((a == b).all() for a, b in zip(ref, got)), mode
+    ix.close()
+    return seen
+
+
+def test_cfg3_full_size_every_scan_kernel_agrees():
+    """10M x 768, L2 top-100, batch 1024: the matrix-core scan (fp16 rows and queries), the VALU half-width scan (f32 rows), the f32 scan and the
+    leaf-major sweep return the same 1024 x 100 ids and keys"""
+    import zebra_amd as za
+    seen = _every_sweep_agrees(za, 10_000_000, 768, "l2", 100, 1024, 4096, 15, [("approx", 2), ("approx-valu", 1), ("scan", 0), ("leaf", 0)])
+    assert seen["approx"] == seen["scan"] == 10_000_000  # (the table read once per batch)
+
+
+def test_cfg4_shard_full_size_every_scan_kernel_agrees():
+    """one of 8 cfg4 shards, 12.5M x 768, the reference's literal cosine key (the hard case of the intervals: twice the exact rows with rounded rows)"""
+    import zebra_amd as za
+    _every_sweep_agrees(za, 12_500_000, 768, "cos_parity", 10, 1024, 4096, 15, [("approx", 2), ("approx-valu", 1), ("scan", 0)],
+                        rows0=25_000_000, n_total=100_000_000)
+
+
+def test_cfg5_shard_full_size_every_sweep_agrees():
+    """one of 8 cfg5 shards, 125M x 128 SIFT-style: leaf by leaf at half width (the default there), the f32 leaf-major sweep, the d = 128 half-width table scan"""
+    import zebra_amd as za
+    _every_sweep_agrees(za, 125_000_000, 128, "l2", 10, 4096, 8192, 15, [("auto", 3), ("leaf", 0), ("approx", 1)], kind=1,
+                        rows0=250_000_000, n_total=1_000_000_000)
+
+
 def test_reference_default_options_at_batch_size_more_than_2_24_visits():
     """lsh.rs:134-135 defaults (max_node_size 5, 15 trees) on 1M rows with a batch of 256: the walk wanders over a good
     part of every tree -- 17.5M leaf visits in one batch, more than 2^24, past the inline visits and the
