@@ -621,7 +621,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         out["half_width_scan"] = {"batches": st["approx_batches_accum"], "redone_by_the_f32_scan": st["approx_fallbacks_accum"],
                                   "last_overflow_bits": st["approx_last_overflow"], "list_entries_per_query": st["approx_list_entries"] / max(st["batch"], 1),
                                   "survivors_scored_exactly_per_query": st["approx_survivors"] / max(st["batch"], 1),
-                                  "visits_ranked_exactly": st["approx_exact_visits"]}
+                                  "visits_ranked_exactly": st["approx_exact_visits"],
+                                  # device memory the index holds for the fp16 copy of its stored rows (0: the VALU kernel on the f32 rows)
+                                  "fp16_row_copy_bytes": st.get("row_copy_bytes", 0)}
     if lat_store["ms"]:
         ls = sorted(lat_store["ms"])
         out["latency_ms"] = {"p50_window_submit_to_host": ls[len(ls) // 2], "max_window_submit_to_host": ls[-1], "windows": len(ls),

@@ -168,6 +168,8 @@ typedef struct zh_stats_t {
                                      * visits, 8 their key scratch */
     uint64_t combined_batches_accum; /* zh_search_batch: internal batches that served MORE than one concurrent caller (since reset) */
     uint64_t combined_calls_accum;   /* ... and the calls they served */
+    uint64_t row_copy_bytes;         /* device memory the index holds for fp16 copies of its stored rows (the half-width sweeps: zh_set_sweep_mode);
+                                     * 0 until a batch has used one, and with modes 1 / 2 / 5 */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -258,14 +258,17 @@ def test_matrix_core_scan_follows_the_stored_rows(za):
     ix.set_sweep_mode("approx")
     ix.set_hash_mode("dense")
     Q = zo.synth_queries(B, d, n)
+    assert ix.stats()["row_copy_bytes"] == 0
     st = check(ix, zo.Forest.build(X[:n], M, T), Q, k, m, om, omode, "first half")
-    assert st["approx_scan"] == 2
+    assert st["approx_scan"] == 2 and st["row_copy_bytes"] >= n * (2 * d + 8)
     ix.append(X[n:])
     ix.build()
     Q2 = np.concatenate([Q[:B // 2], zo.synth_queries(B // 2, d, n) * np.float32(2.0 ** 12)])
     st = check(ix, zo.Forest.build(X, M, T), Q2, k, m, om, omode, "both halves")
     assert st["approx_scan"] == 2
+    assert ix.stats()["row_copy_bytes"] >= 2 * n * (2 * d + 8)
     ix.clear()
+    assert ix.stats()["row_copy_bytes"] == 0
     Y = zo.synth_rows(2 * n, d, seed=5) * np.float32(2.0 ** -30)
     ix.add(Y)
     st = check(ix, zo.Forest.build(Y, M, T), zo.synth_queries(B, d, 2 * n, seed_rows=5) * np.float32(2.0 ** -30), k, m, om, omode, "refilled")

@@ -55,7 +55,8 @@ class Stats(C.Structure):
                 ("prefilter_fallbacks_accum", C.c_uint64), ("prefilter_last_overflow", C.c_uint64),
                 ("approx_scan", C.c_uint64), ("approx_exact_visits", C.c_uint64), ("approx_survivors", C.c_uint64),
                 ("approx_list_entries", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
-                ("approx_last_overflow", C.c_uint64), ("combined_batches_accum", C.c_uint64), ("combined_calls_accum", C.c_uint64)]
+                ("approx_last_overflow", C.c_uint64), ("combined_batches_accum", C.c_uint64), ("combined_calls_accum", C.c_uint64),
+                ("row_copy_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

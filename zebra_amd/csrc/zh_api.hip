@@ -1208,8 +1208,12 @@ extern "C" int zh_set_sweep_mode(zh_index *ix, int mode) {
 }
 extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
     if (!ix || !out) return fail(ZH_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(ix->stats_mu);
-    *out = ix->stats;
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        *out = ix->stats;
+    }
+    std::lock_guard<std::mutex> lk(ix->blk_mu);  // (the copies are made and dropped under it)
+    out->row_copy_bytes = ix->row_half.cap + ix->row_meta.cap + ix->row_half128.cap;
     return ZH_OK;
 }
 extern "C" int zh_stats_reset(zh_index *ix) {
