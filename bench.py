@@ -48,6 +48,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # (row, query) pair from L2).  The upper end is the peak, so that frac never flatters.
 GATHER_CEILING_GBS = [6410.0, 6560.0]  # random 512-byte .. 3-KiB rows gathered from HBM into registers, two boxes (profiles/micro/r03_gather512.csv)
 L2_GATHER_PEAK_GBS = 18800.0
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate -- the `peak` of an L2-bound kernel (the 16.8-18.8 TB/s of
+                       # the guide's LDS-gather table is a LOWER bound of one gather shape, not the L2's rate)
 L2_GATHER_RANGE_GBS = [16800.0, 18800.0]
 # what the bare gather of the scan's access shape reaches from an L2-sized table on this chip with nothing else going on
 # (profiles/micro/gather512.hip, r03_gather512.csv: 6-MB table 22.7 TB/s, 3-MB table 31.3 TB/s): the MEASURED ceiling, above the guide's figure
@@ -93,34 +95,81 @@ def rank_env(base, rank, world, port):
     return e
 
 
-def launch_ranks(n, argv):
-    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU; this parent never touches
-    a GPU and never execs), relay rank 0's JSON line, return the worst exit code.  Fewer than N devices: an error line, rc 3."""
-    import socket
+def count_devices():
+    """GPUs visible to a rank, counted in a short-lived CHILD interpreter: whatever the count costs (on ROCm builds without amdsmi
+    torch falls back to hipGetDeviceCount, which initialises HIP), the launcher itself never touches a GPU -- the ranks are started
+    from a process that has not initialised the runtime."""
     import subprocess
-    import torch  # (device_count does not initialise the GPU)
-    found = torch.cuda.device_count()
+    try:
+        p = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(p.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001 -- no torch / no answer: the ranks will say what is wrong
+        return 0
+
+
+def launch_ranks(n, argv, timeout_s=None, poll_s=0.2, count=count_devices, script=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU; this parent never touches
+    a GPU and never execs), relay rank 0's stdout, SUPERVISE the ranks: on the first non-zero exit (or after `timeout_s`) the
+    survivors are terminated, then killed, and that exit code (124 for the timeout) is returned -- a rank that dies at start-up
+    cannot leave the others waiting in a rendezvous or a collective.  The ranks meet through a FILE store (ZH_BENCH_RDZV_FILE:
+    no port is picked here, so none can be taken between a bind and its reuse); MASTER_PORT is only there for code that reads it.
+    Fewer than N devices: an error line, rc 3."""
+    import subprocess
+    import tempfile
+    import threading
+    found = count()
     if found < n:
         print(json.dumps({"error": "needs %d devices, found %d" % (n, found), "n_gpus": n}))
         return 3
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
+    timeout_s = timeout_s or float(os.environ.get("ZH_BENCH_LAUNCH_TIMEOUT_S", "3300"))
+    rdzv = tempfile.mkdtemp(prefix="zh_bench_rdzv_")
+    base = dict(os.environ)
+    base["ZH_BENCH_RDZV_FILE"] = os.path.join(rdzv, "store")
     procs = []
     for r in range(n):
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=rank_env(os.environ, r, n, port),
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(base, r, n, 29400),
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    out = []
+    rd = threading.Thread(target=lambda: out.extend(procs[0].stdout), daemon=True)  # (a full pipe must not block rank 0)
+    rd.start()
+    t0, why, code = time.monotonic(), None, 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why, code = "ranks failed (rank, exit code): %s" % bad, abs(bad[0][1])
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() - t0 > timeout_s:
+            why, code = "timeout after %.0f s" % timeout_s, 124
+            break
+        time.sleep(poll_s)
+    if why:  # end the survivors: a rank waiting for a dead peer would sit out its own (long) timeouts
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10:
+            time.sleep(poll_s)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    try:
+        import shutil
+        shutil.rmtree(rdzv, ignore_errors=True)
+    except Exception:  # noqa: BLE001
+        pass
+    text = "".join(out)
+    sys.stdout.write(text)
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
-        if not any(l.startswith("{") for l in out.splitlines()):
-            print(json.dumps({"error": "ranks failed: %s" % bad, "n_gpus": n}))
-    return max((abs(rc) for rc in rcs), default=0)
+    if why:
+        print("bench.py: %s" % why, file=sys.stderr)
+        print(json.dumps({"error": why, "n_gpus": n}))  # the LAST line says the run failed, whatever rank 0 printed before
+        return code or 1
+    return 0
 
 
 def parse():
@@ -212,7 +261,11 @@ class Env:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             # control plane only (unique id, barriers, max-over-ranks of the elapsed time): gloo on the CPU.  The data
             # path's one collective is the ncclAllGather inside libzebra_hip.so.
-            dist.init_process_group("gloo")
+            rdzv = os.environ.get("ZH_BENCH_RDZV_FILE")  # set by launch_ranks: a file store, no port to race for
+            if rdzv:
+                dist.init_process_group("gloo", init_method="file://" + rdzv, rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("gloo")
             self.dist = dist
 
     def barrier(self):
@@ -310,6 +363,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             sl["ctx"].finish_window([r["ids"].data_ptr() for r in rs], [r["keys"].data_ptr() for r in rs],
                                     [r["counts"].data_ptr() for r in rs], heavy)
             sl["held"] = True
+            if "t_begin" in sl:  # behind the window's last kernel, on its own stream: the results are complete on the DEVICE here
+                sl["ev_r"].record(sl["stream"])
 
         def retire(sl):
             """zh_search_wait FIRST, then the D2H copies: the header says a batch's outputs are complete only when wait has returned
@@ -372,12 +427,12 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     # right before begin() is called (the stream is idle then: the slot's previous window completed long ago, so the event's
     # timestamp is the submission time), one behind the D2H copies of the window's last batch.  Only the single-GPU loop: the
     # sharded loop's results complete on a stream the library owns.
-    lat_store = {"on": False, "ms": []}
+    lat_store = {"on": False, "ms": [], "ready_ms": []}
     lat = None
 
     def _mark_begin(sl):
         if "ev_b" not in sl:
-            sl["ev_b"], sl["ev_e"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sl["ev_b"], sl["ev_e"], sl["ev_r"] = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         sl["ev_b"].record(sl["stream"])
         sl["t_begin"] = True  # (the end event goes behind the D2H copies, in retire)
 
@@ -386,6 +441,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
     def _window_latency(sl):
         sl["ev_e"].synchronize()
+        lat_store["ready_ms"].append(sl["ev_b"].elapsed_time(sl["ev_r"]))
         return sl["ev_b"].elapsed_time(sl["ev_e"])
 
     def run(first, n):
@@ -575,18 +631,18 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         l2_bytes = qb * rows_per_launch + rb * stored
         by_design = stored * (rb + 8.0 * T) + 8.0 * rows_per_launch + qb * B / launches_per_batch
         l2_GBps = l2_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
-        roof = {"bound": "l2", "achieved": l2_GBps, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_GBps / L2_GATHER_PEAK_GBS,
+        roof = {"bound": "l2", "achieved": l2_GBps, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": l2_GBps / L2_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": l2_bytes,
-                "peak_source": "MI355X_MICROARCH.md 'Indexed rows: gather into LDS', rows served from the XCD's L2: 66-73 GB/s per CU = "
-                               "16.8-18.8 TB/s chip-wide (upper end used)",
-                "peak_range_GBps": L2_GATHER_RANGE_GBS,
+                "peak_source": "MI355X_MICROARCH.md 'L2 (per XCD)': ~34.5 TB/s aggregate",
+                "guide_l2_gather_GBps": L2_GATHER_RANGE_GBS,  # 'Indexed rows: gather into LDS', rows served from the XCD's L2 (a lower bound of one shape)
+                "frac_of_guide_l2_gather": l2_GBps / L2_GATHER_PEAK_GBS,
                 "hbm_bytes_by_design_per_launch": by_design,
                 "hbm_frac": by_design / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms else 0.0,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
                 "measured_l2_gather_ceiling_GBps": L2_GATHER_MEASURED_GBS,
                 "frac_of_measured_l2_gather": [l2_GBps / L2_GATHER_MEASURED_GBS[0], l2_GBps / L2_GATHER_MEASURED_GBS[1]],
                 "measured_l2_gather_note": "the bare register gather of the same shape from a 6-MB / 3-MB table with nothing else running "
-                                           "(profiles/micro/gather512.hip): the measured ceiling, above the guide's 16.8-18.8 TB/s quoted as `peak`",
+                                           "(profiles/micro/gather512.hip): the measured ceiling of this access shape, between the guide's gather figure and its L2 peak",
                 "query_bytes_per_pair": qb, "row_bytes_per_stored_row": rb,
                 "s8d_equivalent_GBps": s8d_GBps, "s8d_bytes_per_launch": bytes_alg,
                 "s8d_note": "SURVEY s8(d) numerator / launch time: comparable with the leaf-major sweep, NOT a roofline fraction (a stored row "
@@ -626,10 +682,16 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                   "fp16_row_copy_bytes": st.get("row_copy_bytes", 0)}
     if lat_store["ms"]:
         ls = sorted(lat_store["ms"])
-        out["latency_ms"] = {"p50_window_submit_to_host": ls[len(ls) // 2], "max_window_submit_to_host": ls[-1], "windows": len(ls),
-                             "batches_per_window": WIN, "windows_in_flight": NS,
-                             "note": "hipEvent span on the window's own stream, recorded before begin() (stream idle = submission time) and behind "
-                                     "the D2H copy of the window's last batch; no batch of a window completes before the whole window"}
+        lr = sorted(lat_store["ready_ms"])
+        out["latency_ms"] = {"p50_window_submit_to_results": lr[len(lr) // 2], "max_window_submit_to_results": lr[-1],
+                             "p50_window_submit_to_host_incl_slot_reuse": ls[len(ls) // 2], "max_window_submit_to_host_incl_slot_reuse": ls[-1],
+                             "windows": len(ls), "batches_per_window": WIN, "windows_in_flight": NS,
+                             "note": "hipEvent spans on the window's own stream from an event recorded before begin() (stream idle = submission time).  "
+                                     "submit_to_results: to an event right behind the window's LAST kernel (its top-k complete in device memory; the D2H "
+                                     "copy of a window is ~1 MB more) -- the window's latency.  submit_to_host_incl_slot_reuse (ADVICE r4: what round 4 "
+                                     "called submit_to_host): to an event behind the D2H copies, which this loop only queues when the slot is REUSED, "
+                                     "`windows_in_flight` windows later, after zh_search_wait -- it includes that delay and is not the window's latency.  "
+                                     "No batch of a window completes before the whole window"}
     if group is not None:
         out["ranks_seen"] = group.ranks()  # ncclCommCount of the communicator the exchange ran on
         # every rank must have run the same host loop on the same shapes, or the collectives were not the same sequence:
@@ -842,6 +904,141 @@ def pmc_traffic(args, name, S, roof):
         return
 
 
+LINE_LIMIT = 6000  # bytes; the driver keeps an 8-KB tail of stdout and parses its LAST line (r04's 25.9-KB line did not parse)
+PREFILTER_DTYPE = {
+    "scan_mfma": "f16 (stored rows AND queries, v_mfma_f32_16x16x32_f16, f32 accumulate) -> an interval per pair; every returned key is the f32 canonical one",
+    "sweep128h": "f16 (stored rows AND queries, v_mfma_f32_16x16x32_f16, f32 accumulate) -> an interval per pair; every returned key is the f32 canonical one",
+    "scan_approx": "f16 queries x f32 stored rows (v_fma_mix_f32) -> an interval per pair; every returned key is the f32 canonical one",
+}
+
+
+def _clean(o, sig=6):
+    """JSON-safe copy: non-finite floats -> None (no NaN / Infinity tokens), floats to `sig` significant digits, numpy scalars -> Python"""
+    import math
+    if isinstance(o, dict):
+        return {str(k): _clean(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v, sig) for v in o]
+    if isinstance(o, (bool, type(None), str)):
+        return o
+    if isinstance(o, (int, np.integer)):
+        return int(o)
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        if not math.isfinite(f):
+            return None
+        return float("%.*g" % (sig, f))
+    return str(o)
+
+
+def _pick(dct, keys):
+    return {k: dct[k] for k in keys if dct and k in dct and dct[k] is not None}
+
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "launch_ms", "launches_per_batch", "window_batches",
+             "rows_per_launch", "rows_loaded_per_launch", "unique_row_fraction", "hbm_frac", "hbm_bytes_by_design_per_launch", "traffic_over_hbm_by_design",
+             "traffic_over_algorithmic", "l2_hit_rate", "l2_request_bytes_per_launch", "l2_requests_GBps", "l2_requests_frac_of_peak",
+             "frac_of_guide_l2_gather", "guide_l2_gather_GBps", "frac_of_measured_l2_gather", "measured_l2_gather_ceiling_GBps",
+             "frac_of_measured_gather_ceiling", "query_bytes_per_pair", "row_bytes_per_stored_row", "l2_requests_per_pair", "sector_GBps", "visits_per_launch")
+
+
+def prefilter_dtype_of(roof):
+    kn = (roof or {}).get("kernel", "")
+    for k, v in PREFILTER_DTYPE.items():
+        if kn.startswith(k):
+            return v
+    return None
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline` + a few top-level figures, under `limit` bytes,
+    strictly JSON (no NaN / Infinity).  Everything else (other_configs' full blocks, notes, recall tables) goes to bench_detail.json and to an
+    EARLIER stdout line.  Optional parts are dropped, least important first, should the line still run over."""
+    roof = _pick(full.get("roofline") or {}, ROOF_KEYS)
+    roof.setdefault("traffic", None)
+    ts = (full.get("roofline") or {}).get("traffic_source") or {}
+    if ts:
+        roof["traffic_file"] = ts.get("file")
+        roof["counters_describe_these_kernels"] = ts.get("counters_describe_these_kernels")
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        cpu = dict(cpu)
+        cpu["sample"] = str(cpu.get("sample", ""))[:400]
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "prefilter_dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = str(cfg.get("workload", ""))[:200]
+    cfg["parallelism"] = str(cfg.get("parallelism", ""))[:120]
+    line["config"] = cfg
+    line["roofline"] = roof
+    line["cpu_baseline"] = cpu
+    line["host_buffers_qps"] = full.get("host_buffers_qps")
+    optional = []  # (key, value), most important first
+    optional.append(("stage_ms_per_batch", full.get("stage_ms_per_batch")))
+    lat = full.get("latency_ms") or {}
+    optional.append(("latency_ms", _pick(lat, ("p50_window_submit_to_results", "p50_window_submit_to_host", "p50_blocking_single_batch", "batches_per_window", "windows_in_flight")) or None))
+    k = (full.get("config") or {}).get("top_k")
+    rc = full.get("recall") or {}
+    rsum = {"clustered": _pick(rc.get("informative") or {}, (f"recall_at_{k}", "planted_neighbour_hit_rate", "queries_per_s")),
+            "iid": _pick(rc.get("bench_data_iid") or {}, (f"recall_at_{k}", "planted_neighbour_hit_rate"))}
+    if rc.get("at_this_point"):
+        rsum["at_this_point"] = _pick(rc["at_this_point"], ("max_node_size_per_shard", f"recall_at_{k}", f"recall_at_{k}_reference_key", "planted_neighbour_hit_rate"))
+    optional.append(("recall", rsum))
+    oc = {}
+    for key, v in (full.get("other_configs") or {}).items():
+        r = v.get("roofline") or {}
+        e = {"qps": v.get("queries_per_s_this_gpu"), "ms_per_batch": v.get("ms_per_batch"), "kernel": r.get("kernel"), "bound": r.get("bound"),
+             "frac": r.get("frac"), "launch_ms": r.get("launch_ms"), "traffic_ratio": r.get("traffic_over_algorithmic", r.get("traffic_over_hbm_by_design"))}
+        if v.get("host_buffers_qps") is not None:
+            e["host_buffers_qps"] = v["host_buffers_qps"]
+        r10 = v.get("recall_at_10")
+        if r10:
+            e["recall_at_10_clustered_corrected_key"] = (r10.get("clustered_rows") or {}).get("corrected_key")
+            e["recall_at_10_reference_key"] = (r10.get("iid_rows") or {}).get("reference_key")
+        if "recall_at_100" in v:
+            e["recall_at_100"] = v["recall_at_100"]
+        oc[key] = {a: b for a, b in e.items() if b is not None}
+    optional.append(("other_configs", oc or None))
+    hw = full.get("half_width_scan")
+    optional.append(("half_width_scan", _pick(hw or {}, ("redone_by_the_f32_scan", "list_entries_per_query", "survivors_scored_exactly_per_query",
+                                                          "visits_ranked_exactly", "fp16_row_copy_bytes")) or None))
+    for key in ("preflight", "ranks_seen", "emulated", "pipelined_batches_in_flight", "timed_span", "detail"):
+        optional.append((key, full.get(key)))
+    for key, v in optional:
+        if v is not None:
+            line[key] = v
+    line = _clean(line)
+    dump = lambda o: json.dumps(o, allow_nan=False, separators=(",", ":"))  # noqa: E731
+    text = dump(line)
+    for key, _ in reversed(optional):  # still too long: drop optional parts, least important first
+        if len(text) <= limit:
+            break
+        if line.pop(key, None) is not None:
+            line["dropped_for_length"] = line.get("dropped_for_length", []) + [key]
+            text = dump(line)
+    if len(text) > limit:  # (cannot happen with the fields above; never print an unparsable line)
+        line = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                          "vs_baseline", "dtype", "data")}
+        line["error"] = "bench line over %d bytes after dropping every optional part" % limit
+        text = dump(line)
+    return text
+
+
+def write_detail(full):
+    """everything the run measured, as bench_detail.json at the repo root and under gpurun_out/ (which travels back from the GPU box)"""
+    doc = json.dumps(_clean(full, sig=9), allow_nan=False)
+    where = []
+    for dname in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(dname, exist_ok=True)
+            with open(os.path.join(dname, "bench_detail.json"), "w") as f:
+                f.write(doc + "\n")
+            where.append(os.path.relpath(os.path.join(dname, "bench_detail.json"), ROOT))
+        except OSError:
+            pass
+    return doc, where
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: be one
@@ -927,7 +1124,10 @@ def main():
         out = {
             "metric": "queries/sec", "value": res["qps"], "unit": "queries/s", "n_gpus": env.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong", "vs_baseline": None,
+            # the arithmetic type of the path's RESULTS: every returned key is the canonical f32 sum (bit-equal to the oracle).  The scan that
+            # PICKS the candidates may multiply fp16 copies on the matrix cores: `prefilter_dtype` says so at top level.
+            "dtype": "f32",
             "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
             "pipelined_batches_in_flight": max(2, args.in_flight) if not args.no_pipeline else 1,
             "timed_span": "queries resident in HBM -> merged top-k in pinned host memory (D2H inside the span)",
@@ -987,7 +1187,12 @@ def main():
         env.dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
     if env.rank == 0:
-        print(json.dumps(out), flush=True)
+        out["prefilter_dtype"] = prefilter_dtype_of(out["roofline"])
+        doc, where = write_detail(out)
+        out["detail"] = ", ".join(where) + "; also the stdout line before this one"
+        # the full record first (one line, any length), the COMPACT record last: the driver parses the last line of stdout
+        print(json.dumps({"bench_detail": json.loads(doc)}, allow_nan=False), flush=True)
+        print(compact_line(out), flush=True)
 
 
 def _planted_row(seed_q, b, n_rows):
