@@ -762,12 +762,20 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     assert (last_host[1] <= k).all() and (last_host[1] > 0).all(), "empty results in the last timed batch"
     # PCIe-inclusive rate through the host-buffer entry point: reported beside, never as, `value`
     if group is None and S == 1 and not args.profile_run:
-        qh = [queries[warmup + i % max(steps, 1)].cpu().numpy() for i in range(3)]
-        ix.search_batch(qh[0], k, metric)
+        # zh_search_batch (HOST pointers, blocking: what the shim's search_batch / Database::query_vectors reaches, core.rs:290-313) with a batch of
+        # four API batches' worth of host-resident queries (4096 at cfg3): the library cuts it into windows over two contexts, copies beside the
+        # kernels (zh_api.hip, search_host_windows).  PCIe inclusive, pageable memory on both sides.
+        nb_h = max(1, min(4, n_batches))
+        qh = np.concatenate([queries[(warmup + i) % n_batches].cpu().numpy() for i in range(nb_h)])
+        ix.search_batch(qh[:B], k, metric)  # (one API batch first: the windows want the visits per pair of an earlier batch)
+        ix.search_batch(qh, k, metric)      # (warm: the second context's scratch)
+        hw0 = ix.stats()["host_window_calls_accum"]
         th = time.perf_counter()
-        for q_ in qh:
-            ix.search_batch(q_, k, metric)
-        out["host_buffers_qps"] = 3 * B / (time.perf_counter() - th)
+        for _ in range(3):
+            ix.search_batch(qh, k, metric)
+        out["host_buffers_qps"] = 3 * qh.shape[0] / (time.perf_counter() - th)
+        out["host_buffers"] = {"queries_per_call": int(qh.shape[0]), "calls": 3, "calls_run_as_windows": ix.stats()["host_window_calls_accum"] - hw0,
+                               "note": "blocking zh_search_batch calls back to back, queries and results in pageable host memory"}
         # what a latency-bound caller sees: ONE batch through the blocking device-pointer call, results on the host
         lb = []
         for i in range(5):
@@ -973,6 +981,7 @@ def compact_line(full, limit=LINE_LIMIT):
     line["roofline"] = roof
     line["cpu_baseline"] = cpu
     line["host_buffers_qps"] = full.get("host_buffers_qps")
+    line["host_buffers_queries_per_call"] = (full.get("host_buffers") or {}).get("queries_per_call")
     optional = []  # (key, value), most important first
     optional.append(("stage_ms_per_batch", full.get("stage_ms_per_batch")))
     lat = full.get("latency_ms") or {}
@@ -1109,6 +1118,7 @@ def main():
                                                               if kk in r["roofline"]},
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms"),
+                          "host_buffers_qps": r.get("host_buffers_qps"), "host_buffers": r.get("host_buffers"),
                           "half_width_scan": r.get("half_width_scan")}
             if rec10:
                 other[key]["recall_at_10"] = rec10
@@ -1138,7 +1148,7 @@ def main():
             f"recall_at_{k}": res.get(f"recall_at_{k}"), f"recall_at_{k}_reference_key": res.get(f"recall_at_{k}_reference_key"),
             "planted_neighbour_hit_rate": res.get("planted_neighbour_hit_rate"),
             "roofline": res["roofline"], "cpu_baseline": cpu[1] if cpu else None, "cpu_baseline_bitexact": cpu[0] if cpu else None,
-            "host_buffers_qps": res.get("host_buffers_qps"), "stage_ms_per_batch": res["stage_ms_per_batch"], "host_loop": res["host_loop"],
+            "host_buffers_qps": res.get("host_buffers_qps"), "host_buffers": res.get("host_buffers"), "stage_ms_per_batch": res["stage_ms_per_batch"], "host_loop": res["host_loop"],
             "stage_ms_note": "hipEvent spans on each batch's own stream; with batches in flight they overlap other batches' sweeps",
             "setup_s": res["setup_s"],
         }

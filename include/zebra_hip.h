@@ -168,6 +168,8 @@ typedef struct zh_stats_t {
                                      * visits, 8 their key scratch */
     uint64_t combined_batches_accum; /* zh_search_batch: internal batches that served MORE than one concurrent caller (since reset) */
     uint64_t combined_calls_accum;   /* ... and the calls they served */
+    uint64_t host_window_calls_accum; /* zh_search_batch calls whose (large, host-resident) batch ran as windows over two contexts, copies beside
+                                      * the kernels (since reset) */
     uint64_t row_copy_bytes;         /* device memory the index holds for fp16 copies of its stored rows (the half-width sweeps: zh_set_sweep_mode);
                                      * 0 until a batch has used one, and with modes 1 / 2 / 5 */
 } zh_stats_t;
@@ -408,6 +410,41 @@ typedef struct zh_ref_header {
 ZH_API int zh_ref_header_decode(const uint8_t *bytes, size_t len, int metric, size_t model_len, zh_ref_header *out);
 /* out == NULL: only *out_len (the size needed) is written */
 ZH_API int zh_ref_header_encode(const zh_ref_header *header, const uint8_t *model_bytes, uint8_t *out, size_t cap, size_t *out_len);
+
+/* ---- test / debug access: what the half-width scans computed for EVERY scored pair --------------------------------
+ * The half-width scans (zh_set_sweep_mode 4 / 5 / 6) give every member of every visited leaf -- every (stored row, query) pair that
+ * tree_result scores with Metric::distance (lsh.rs:310-323; distance.rs:23,41,106) -- an interval that must CONTAIN the reference's key; only
+ * then are the returned ids / keys the reference's.  These two calls let a test check that claim pair by pair on the device's own numbers
+ * (tests/test_gpu_intervals.py) instead of end to end: zh_debug_keep_raw(idx, 1) makes every later half-width batch keep a copy of the
+ * scan's raw output {x^ . h^ / sigma_x, |x|^2} (the intervals overwrite it in place); zh_debug_scan_pairs returns, for the most recent
+ * batch of `ctx` (NULL: the index's blocking context, i.e. the last zh_search_batch_device call; the context must be idle), one record per
+ * scored pair.  lo / hi are f32 values in the scale the scan ranks in, mapped to order-preserving u32 ("sortable": bits ^ (sign ? ~0 :
+ * 0x80000000)): L2 family: the canonical f32 sum of (x_i - q_i)^2; cosine, corrected key: the clipped distance 1 - cos; the reference's
+ * literal key (distance.rs:23-25): key > 0 ? key : 2 - key for key = 1 - distance.  (lo, hi) = (0, ~0): nothing is certain about the pair
+ * (it takes the exact path).  Not a product path: host-side copies of the whole batch's scratch. */
+typedef struct zh_debug_pair {
+    uint32_t row;          /* stored row (local: without id_base) */
+    uint32_t query;        /* query of the batch (of the window: batch * b + i) */
+    uint32_t lo, hi;       /* the interval, sortable f32 (valid when flags & 1) */
+    float raw_s, raw_a2;   /* the scan's raw output for the pair (valid when zh_debug_scan_info::raw_kept) */
+    uint32_t flags;        /* 1: the visit's raw pairs were turned into intervals (every visit that hands rows on); 2: a visit that takes FEWER
+                            * than top_k rows of a longer leaf -- ranked by the reference's arithmetic, its intervals only gate the query's list */
+    uint32_t visit;        /* index of the leaf visit the pair belongs to */
+} zh_debug_pair;
+typedef struct zh_debug_scan_info {
+    uint32_t approx_scan;  /* as zh_stats_t::approx_scan: 1 VALU scan, 2 matrix-core scan, 3 leaf-major at half width; 0: the batch was not half-width */
+    uint32_t queries, top_k;
+    int32_t metric, cosine_mode;
+    uint32_t raw_kept;     /* 1: raw_s / raw_a2 are valid */
+    uint32_t overflow;     /* the batch's overflow word (non-zero: it was redone by the f32 path; the intervals are still what the scan made) */
+    float bound_const;     /* zh_approx_bound for the batch ("Half-width scan: the bound") */
+    float row_rho, rho_norm; /* the measured relative rounding error of the stored rows' fp16 copy (0 with f32 rows) */
+    uint64_t pairs, visits;
+} zh_debug_scan_info;
+ZH_API int zh_debug_keep_raw(zh_index *idx, int on);
+/* out (cap records; NULL with cap 0 to size: info->pairs) in key-slot order; qmeta (may be NULL): queries x 4 floats {1 / sigma_q, f32 |q|^2,
+ * upper estimate of |q|, upper estimate of |q - h / sigma_q|} (NaN: nothing certain about the query) */
+ZH_API int zh_debug_scan_pairs(zh_index *idx, zh_search_ctx *ctx, zh_debug_scan_info *info, zh_debug_pair *out, size_t cap, float *qmeta);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 ZH_API int zh_set_profiling(zh_index *idx, int level); /* 0 off, 1 per-stage hipEvent timing, 2 + unique-row count */

@@ -56,7 +56,21 @@ class Stats(C.Structure):
                 ("approx_scan", C.c_uint64), ("approx_exact_visits", C.c_uint64), ("approx_survivors", C.c_uint64),
                 ("approx_list_entries", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
                 ("approx_last_overflow", C.c_uint64), ("combined_batches_accum", C.c_uint64), ("combined_calls_accum", C.c_uint64),
-                ("row_copy_bytes", C.c_uint64)]
+                ("host_window_calls_accum", C.c_uint64), ("row_copy_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class DebugPair(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("query", C.c_uint32), ("lo", C.c_uint32), ("hi", C.c_uint32), ("raw_s", C.c_float), ("raw_a2", C.c_float),
+                ("flags", C.c_uint32), ("visit", C.c_uint32)]
+
+
+class DebugScanInfo(C.Structure):
+    _fields_ = [("approx_scan", C.c_uint32), ("queries", C.c_uint32), ("top_k", C.c_uint32), ("metric", C.c_int32), ("cosine_mode", C.c_int32),
+                ("raw_kept", C.c_uint32), ("overflow", C.c_uint32), ("bound_const", C.c_float), ("row_rho", C.c_float), ("rho_norm", C.c_float),
+                ("pairs", C.c_uint64), ("visits", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -128,6 +142,8 @@ SYMBOLS = [
     ("zh_ref_tree_encode", _i, [_vp, _u32, _u32, _vp, _u64, _vp, _sz, _vp]),
     ("zh_ref_header_decode", _i, [_vp, _sz, _i, _sz, _vp]),
     ("zh_ref_header_encode", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("zh_debug_keep_raw", _i, [_vp, _i]),
+    ("zh_debug_scan_pairs", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     ("zh_set_profiling", _i, [_vp, _i]),
     ("zh_stats", _i, [_vp, _vp]),
     ("zh_stats_reset", _i, [_vp]),

@@ -117,7 +117,10 @@ struct zh_search_ctx {
     zh_index *ix = nullptr;
     DevBuf wQQ, wBits, wCounts, wInline, wRowBase, wCandBase, wVisitBase, wTotals, wVisits, wKeys, wCandKeys, wCandIds,
         wLeafCount, wLeafFill, wGroupBase, wGroupRowBase, wGroups, wGroupRowOff, wWaveGroup, wVisitBits, wNodeVisit, wScore, wJunkBits, wZeros, wQnorm, wQpad, wFixList, wLogPool, wLogHead, wLogCtl,
-        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl, wUnc, wQh, wQmeta, wApList, wApCount, wApEx, wApExKeys, wApCtl;
+        wPfRows, wPfCounts, wPfKeys, wPfIds, wPfAmb, wPfCtl, wUnc, wQh, wQmeta, wApList, wApCount, wApEx, wApExKeys, wApCtl, wRaw;
+    // test / debug (zh_debug_scan_pairs): the half-width batch this context ran last -- its ZhApprox, and (zh_debug_keep_raw) the scan's raw pairs
+    ZhApprox dbg_ap{};
+    bool dbg_valid = false, dbg_raw = false;
     size_t log_chunks = 0;  // capacity of wLogPool for the batch in flight
     ZhTotals *h_totals = nullptr;  // pinned
     hipEvent_t ev[6] = {};         // stage boundaries: hash | walk | sweep | select | final
@@ -155,7 +158,7 @@ struct zh_search_ctx {
         return {&wQQ, &wBits, &wCounts, &wInline, &wRowBase, &wCandBase, &wVisitBase, &wTotals, &wVisits, &wKeys,
                 &wCandKeys, &wCandIds, &wLeafCount, &wLeafFill, &wGroupBase, &wGroupRowBase, &wGroups, &wGroupRowOff, &wWaveGroup, &wVisitBits, &wNodeVisit, &wScore, &wJunkBits, &wZeros, &wQnorm, &wQpad, &wFixList,
                 &wLogPool, &wLogHead, &wLogCtl, &wQwin, &wOutWin, &wPfRows, &wPfCounts, &wPfKeys, &wPfIds, &wPfAmb, &wPfCtl, &wUnc,
-                &wQh, &wQmeta, &wApList, &wApCount, &wApEx, &wApExKeys, &wApCtl};
+                &wQh, &wQmeta, &wApList, &wApCount, &wApEx, &wApExKeys, &wApCtl, &wRaw};
     }
     void release_all() {
         for (DevBuf *b : all_bufs()) b->release();
@@ -214,14 +217,16 @@ struct zh_index {
     // row {|x|^2, 1 / scale}, and the largest relative rounding error of any row; for rows [0, scale_rows) of generation scale_gen,
     // extended when rows are appended; a failed allocation is remembered until the rows change (the VALU kernel serves the index)
     DevBuf row_half, row_meta, row_rho_dev;
-    bool row_half_failed = false;
+    // (the flags and generations below are read without a lock by the per-batch choices -- mfma_wanted, choose_scan, use_approx_leaf -- while another
+    // context may be inside ensure_row_half / ensure_row_half128 under blk_mu: atomics; the buffers themselves are only touched under blk_mu)
+    std::atomic<bool> row_half_failed{false};
     // d = 128, leaf by leaf at half width (sweep128h_kernel): a row-major fp16 copy under ONE power-of-two scale (2^(14 - h128_ex)), same life cycle
     DevBuf row_half128;
-    uint64_t h128_rows = 0, h128_gen = 0;
+    std::atomic<uint64_t> h128_rows{0}, h128_gen{0};
     int h128_ex = 0;
     float h128_rho = 0.f;
-    bool h128_failed = false;
-    uint64_t scale_rows = 0, scale_gen = 0;
+    std::atomic<bool> h128_failed{false};
+    std::atomic<uint64_t> scale_rows{0}, scale_gen{0};
     float row_rho = 0.f;
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
@@ -231,7 +236,8 @@ struct zh_index {
 
     bool broken = false;  // an incremental add failed half way: trees are stale until zh_index_build
     int dense_levels = -1;
-    int sweep_mode = 0;  // zh_set_sweep_mode: 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies, 5 = 4 with the VALU kernel only (no fp16 copy of the rows)
+    bool debug_keep_raw = false;  // zh_debug_keep_raw
+    std::atomic<int> sweep_mode{0};  // zh_set_sweep_mode (atomic: set by one thread while pipelined contexts read it per batch): 0 cost model (prefilter where the batch has row scores), 1 leaf-major, 2 table scan (exact), 3 = 0, 4 table scan with half-width queries wherever it applies, 5 = 4 with the VALU kernel only (no fp16 copy of the rows)
     // a batch whose half-width scan ran over was redone by the f32 scan: both scans paid.  Data whose keys are dense around the cut (the
     // parity cosine key on iid rows in 20k-row leaves: thousands of rows per query inside the bound) would do so batch after batch:
     // after the first such batch -- or one whose lists came close -- the per-query lists get 8192 slots instead of 4096 (a final
@@ -280,6 +286,11 @@ struct zh_index {
         zh_search_ctx ctx;
         bool init = false, busy = false;
         hipStream_t s = nullptr;
+        // a large host-resident batch is cut into windows that alternate between two contexts (search_host_windows): the second one
+        zh_search_ctx ctx2;
+        bool init2 = false;
+        hipStream_t s2 = nullptr;
+        hipEvent_t ev_d2h[2] = {nullptr, nullptr};
         DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
         void *h_stage = nullptr;  // pinned staging of a combined batch: queries in, results out (one H2D, three D2H per round)
         size_t h_stage_cap = 0;
@@ -416,6 +427,9 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     if (ix)
         for (auto &ln : ix->lanes) {
             if (ln.init) { hipSetDevice(ix->device); ln.ctx.release_all(); }
+            if (ln.init2) { hipSetDevice(ix->device); ln.ctx2.release_all(); }
+            if (ln.s2) hipStreamDestroy(ln.s2);
+            for (auto &ev : ln.ev_d2h) if (ev) hipEventDestroy(ev);
             ln.wQ.release(); ln.wOutIds.release(); ln.wOutKeys.release(); ln.wOutCounts.release();
             if (ln.s) hipStreamDestroy(ln.s);
             if (ln.h_stage) hipHostFree(ln.h_stage);
@@ -451,6 +465,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->rows_gen++; ix->dead_gen++;
     ix->norm_rows = 0; ix->norm_gen = 0;
     ix->row_hn2.release(); ix->row_norm.release();
+    std::lock_guard<std::mutex> lb(ix->blk_mu);  // (the fp16 copies' state is blk_mu's: zh_stats reads it under that lock)
     ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
     ix->h128_rows = 0; ix->h128_gen = 0; ix->h128_rho = 0.f; ix->row_half128.release(); ix->h128_failed = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
@@ -1395,7 +1410,7 @@ static int ensure_row_half128(zh_index *ix, bool *ok) {
         ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
         return ZH_OK;
     }
-    uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows) ? ix->h128_rows : 0;
+    uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows) ? ix->h128_rows.load() : 0;
     uint32_t *dmax = ix->row_rho_dev.as<uint32_t>() + 1;
     for (int pass = 0; pass < 2; pass++) {
         uint32_t mbits = 0;
@@ -1440,7 +1455,8 @@ static bool mfma_wanted(const zh_index *ix) {
 static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B, size_t k) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
     const uint32_t d = ix->opt.dim, T = ix->n_trees;
-    int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    const int sm_ = ix->sweep_mode.load();
+    int mode = sm_ == 3 ? forced : (sm_ ? sm_ : forced);
     if (mode == 5) mode = 4;
     if (mode == 6) mode = 1;
     if (mode == 1 || !zh_scan_sweep_supported(d, T, metric) || ix->row_leaf_failed || ix->scan_unsafe) return false;
@@ -1467,7 +1483,8 @@ static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, siz
 static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t k, int metric) {
     static const int forced = [] { const char *e = getenv("ZH_SWEEP_MODE"); return !e ? 0 : (e[0] == 's' ? 2 : (e[0] == 'a' ? 4 : 1)); }();
     static const bool off = getenv("ZH_NO_APPROX") != nullptr;
-    int mode = ix->sweep_mode == 3 ? forced : (ix->sweep_mode ? ix->sweep_mode : forced);
+    const int sm_ = ix->sweep_mode.load();
+    int mode = sm_ == 3 ? forced : (sm_ ? sm_ : forced);
     if (mode == 5) mode = 4;
     if (off || mode == 2 || mode == 1 || mode == 6) return false;
     if (!zh_scan_approx_supported(ix->opt.dim, ix->n_trees, metric) || k > 256 || B == 0 || B >= (1u << 24)) return false;  // (24 bits of a packed pair record)
@@ -1980,7 +1997,15 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (hs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_sw1, 0));
     HIPCHK(hipEventRecord(c->ev[3], s));
     const uint32_t *run_if = nullptr;
+    c->dbg_valid = c->approx;
+    c->dbg_raw = false;
     if (c->approx) {
+        c->dbg_ap = ap;
+        if (ix->debug_keep_raw && tot.rows) {  // tests: the scan's raw pairs, before select_tau_kernel turns them into intervals in place
+            if ((rc = c->wRaw.ensure(tot.rows * 8))) return rc;
+            HIPCHK(hipMemcpyAsync(c->wRaw.p, c->wKeys.p, tot.rows * 8, hipMemcpyDeviceToDevice, s));
+            c->dbg_raw = true;
+        }
         HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, c->metric, c->mode, d, s));
         HIPCHK(hipEventRecord(c->ev[4], s));
         HIPCHK(zh_launch_final_interval(c->wVisits.as<ZhVisit>(), ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), (uint32_t)B, (uint32_t)k,
@@ -2227,6 +2252,178 @@ extern "C" int zh_search_wait(zh_search_ctx *c) {
     return ctx_wait(c);
 }
 
+// ---- test / debug access (include/zebra_hip.h, "test / debug access") ----
+extern "C" int zh_debug_keep_raw(zh_index *ix, int on) {
+    if (!ix) return fail(ZH_EINVAL, "zh_debug_keep_raw: null index");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    ix->debug_keep_raw = on != 0;
+    return ZH_OK;
+}
+extern "C" int zh_debug_scan_pairs(zh_index *ix, zh_search_ctx *ctx, zh_debug_scan_info *info, zh_debug_pair *out, size_t cap, float *qmeta) {
+    if (!ix || !info || (cap && !out)) return fail(ZH_EINVAL, "zh_debug_scan_pairs: null argument");
+    std::unique_lock<std::shared_mutex> lk(ix->mu, std::defer_lock);
+    if (!ctx) lk.lock();
+    zh_search_ctx *c = ctx ? ctx : &ix->dctx;
+    if (c->ix != ix) return fail(ZH_EINVAL, "zh_debug_scan_pairs: the context belongs to another index");
+    if (c->state != 0) return fail(ZH_ESTATE, "zh_debug_scan_pairs: the context has a batch in flight");
+    int rc = set_device(ix);
+    if (rc) return rc;
+    memset(info, 0, sizeof(*info));
+    if (!c->dbg_valid) return ZH_OK;  // (approx_scan 0: the last batch was not a half-width one)
+    const ZhTotals tot = c->tot;
+    const ZhApprox &ap = c->dbg_ap;
+    info->approx_scan = c->approx_leaf ? 3 : (c->approx_mfma ? 2 : 1);
+    info->queries = (uint32_t)c->B; info->top_k = (uint32_t)c->k; info->metric = c->metric; info->cosine_mode = c->mode;
+    info->raw_kept = c->dbg_raw ? 1 : 0; info->overflow = c->h_ap[1];
+    info->bound_const = zh_approx_bound(c->metric, ix->opt.dim, (int)ap.mfma);
+    info->row_rho = ap.row_rho; info->rho_norm = ap.rho_norm;
+    info->pairs = tot.rows; info->visits = tot.visits;
+    HIPCHK(hipDeviceSynchronize());
+    if (qmeta) HIPCHK(hipMemcpy(qmeta, ap.qmeta, c->B * sizeof(float4), hipMemcpyDeviceToHost));
+    if (!cap) return ZH_OK;
+    if (cap < tot.rows) return fail(ZH_ELIMIT, "zh_debug_scan_pairs: %llu pairs, room for %zu", (unsigned long long)tot.rows, cap);
+    std::vector<ZhVisit> hv(tot.visits);
+    std::vector<uint64_t> iv(tot.rows), raw(c->dbg_raw ? tot.rows : 0);
+    std::vector<uint32_t> lids(ix->n_leaf_ids);
+    if (tot.visits) HIPCHK(hipMemcpy(hv.data(), c->wVisits.p, tot.visits * sizeof(ZhVisit), hipMemcpyDeviceToHost));
+    if (tot.rows) HIPCHK(hipMemcpy(iv.data(), c->wKeys.p, tot.rows * 8, hipMemcpyDeviceToHost));
+    if (c->dbg_raw && tot.rows) HIPCHK(hipMemcpy(raw.data(), c->wRaw.p, tot.rows * 8, hipMemcpyDeviceToHost));
+    if (ix->n_leaf_ids) HIPCHK(hipMemcpy(lids.data(), ix->leaf_ids.p, ix->n_leaf_ids * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tot.rows; i++) { out[i].row = out[i].query = 0xFFFFFFFFu; out[i].flags = 0; out[i].visit = 0xFFFFFFFFu; }
+    for (size_t v = 0; v < hv.size(); v++) {
+        const ZhVisit &z = hv[v];
+        if (z.row_off + z.len > tot.rows || (uint64_t)z.leaf_off + z.len > ix->n_leaf_ids) return fail(ZH_ESTATE, "zh_debug_scan_pairs: visit %zu out of range", v);
+        const uint32_t fl = (z.take ? 1u : 0u) | ((z.take && z.take < z.len && z.take < c->k) ? 2u : 0u);
+        for (uint32_t i = 0; i < z.len; i++) {
+            zh_debug_pair &o = out[z.row_off + i];
+            o.row = lids[(size_t)z.leaf_off + i]; o.query = z.b; o.visit = (uint32_t)v; o.flags = fl;
+            const uint64_t w = iv[z.row_off + i];
+            o.lo = (uint32_t)w; o.hi = (uint32_t)(w >> 32);
+            o.raw_s = o.raw_a2 = 0.f;
+            if (c->dbg_raw) { const uint64_t r = raw[z.row_off + i]; uint32_t a = (uint32_t)r, b2 = (uint32_t)(r >> 32); memcpy(&o.raw_s, &a, 4); memcpy(&o.raw_a2, &b2, 4); }
+        }
+    }
+    return ZH_OK;
+}
+
+// ---- a large HOST-resident batch (zh_search_batch; Database::query_vectors -> the shim's search_batch, core.rs:290-313): windows over two contexts ----
+// The device-pointer context API keeps two windows in flight (bench.py's loop: one sweeping, the next in its light phases, the copies beside both);
+// a blocking host-pointer call used to run H2D -> one internal batch -> D2H back to back (132 k against 185-192 k QPS at
+// cfg3).  Here the call cuts its batch into windows of `wq` queries (the size at which the half-width scan's query halves still fit the L2s beside
+// the streamed rows), alternates them between the lane's two contexts -- light kernels on the contexts' own high-priority streams, the sweeps back
+// to back on the index's sweep stream -- stages queries and results through pinned memory window by window, and hands out results as windows
+// complete.  Same ids / keys / counts as one batch: the queries of a batch never interact.  Only in the few-visits-per-pair regime (long leaves):
+// the wandering walk of small-leaf forests has its own limits per internal batch (search_locked splits by visits) and stays on the classic path.
+static size_t host_window_queries(uint32_t d) {
+    const char *e = getenv("ZH_HOST_WINDOW");  // tests / A-B, read per call (unset or 0: by dimension)
+    const size_t forced = e ? (size_t)atoll(e) : (size_t)0;
+    if (forced) return forced;
+    return d >= 512 ? 2048 : (d >= 256 ? 1024 : 4096);
+}
+static bool host_windows_wanted(zh_index *ix, size_t B) {
+    const bool off = getenv("ZH_NO_HOST_WINDOWS") != nullptr;  // (read per call: tests switch it)
+    if (off || ix->n_trees == 0 || ix->n_rows == 0) return false;
+    const size_t wq = host_window_queries(ix->opt.dim);
+    if (B < 2 * wq && B < wq + wq / 2) return false;
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    return ix->visits_per_pair > 0 && ix->visits_per_pair <= 4.0;  // (known from earlier batches: the first batch of an index goes the classic way)
+}
+// returns ZH_OK with every result in the caller's buffers, or an error after which BOTH contexts are idle and nothing is in flight (the caller
+// then runs the classic path: a window that passes a per-batch limit is not an error of the call)
+static int search_host_windows(zh_index *ix, zh_index::Lane &ln, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
+                               uint64_t *out_keys, uint32_t *out_counts) {
+    const uint32_t d = ix->opt.dim;
+    int rc;
+    if (!ln.init2) {
+        if ((rc = ctx_init(&ln.ctx2, ix))) { ln.ctx2.release_all(); return rc; }
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipError_t e = hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, hi);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ln.ev_d2h[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            ln.ctx2.release_all();
+            if (ln.s2) { hipStreamDestroy(ln.s2); ln.s2 = nullptr; }
+            for (auto &ev : ln.ev_d2h) if (ev) { hipEventDestroy(ev); ev = nullptr; }
+            return fail(ZH_EHIP, "host windows: %s", hipGetErrorString(e));
+        }
+        ln.init2 = true;
+    }
+    const size_t wq = host_window_queries(d), nw = (B + wq - 1) / wq, per = (B + nw - 1) / nw;
+    const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;
+    if (need > ln.h_stage_cap) {
+        if (ln.h_stage) hipHostFree(ln.h_stage);
+        ln.h_stage = nullptr; ln.h_stage_cap = 0;
+        const size_t cap = need + need / 2;
+        hipError_t e = hipHostMalloc(&ln.h_stage, cap, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ZH_ENOMEM, "hipHostMalloc(%zu): %s", cap, hipGetErrorString(e));
+        ln.h_stage_cap = cap;
+    }
+    uint8_t *hs = static_cast<uint8_t *>(ln.h_stage);
+    float *dQ = ln.wQ.as<float>();
+    uint64_t *dIds = ln.wOutIds.as<uint64_t>(), *dKeys = ln.wOutKeys.as<uint64_t>();
+    uint32_t *dCounts = ln.wOutCounts.as<uint32_t>();
+    uint64_t *hIds = reinterpret_cast<uint64_t *>(hs + off_ids), *hKeys = reinterpret_cast<uint64_t *>(hs + off_keys);
+    uint32_t *hCounts = reinterpret_cast<uint32_t *>(hs + off_counts);
+    zh_search_ctx *ctxs[2] = {&ln.ctx, &ln.ctx2};
+    hipStream_t str[2] = {ln.s, ln.s2};
+    auto win = [&](size_t w, size_t *b0, size_t *nb) { *b0 = w * per; *nb = std::min(per, B - *b0); };
+    auto bail = [&](int code) {  // leave nothing in flight: what was begun is abandoned, what was finished is retired, both streams drained
+        const std::string why = g_err;
+        for (int i = 0; i < 2; i++) {
+            zh_search_ctx_abandon(ctxs[i]);
+            if (ctxs[i]->state == 2) ctx_wait(ctxs[i]);
+            hipStreamSynchronize(str[i]);
+        }
+        hipStreamSynchronize(ix->sweep_stream);
+        g_err = why;
+        return code;
+    };
+    auto retire = [&](size_t w) -> int {  // window w: wait (its outputs are complete only then), results -> pinned staging, behind them an event
+        const int i = (int)(w & 1);
+        size_t b0, nb;
+        win(w, &b0, &nb);
+        int r = ctx_wait(ctxs[i]);
+        if (r) return r;
+        hipError_t e = hipSuccess;
+        if (k) {
+            e = hipMemcpyAsync(hIds + b0 * k, dIds + b0 * k, nb * k * 8, hipMemcpyDeviceToHost, str[i]);
+            if (e == hipSuccess) e = hipMemcpyAsync(hKeys + b0 * k, dKeys + b0 * k, nb * k * 8, hipMemcpyDeviceToHost, str[i]);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hCounts + b0, dCounts + b0, nb * 4, hipMemcpyDeviceToHost, str[i]);
+        if (e == hipSuccess) e = hipEventRecord(ln.ev_d2h[i], str[i]);
+        return e == hipSuccess ? ZH_OK : fail(ZH_EHIP, "host windows, D2H: %s", hipGetErrorString(e));
+    };
+    auto hand_out = [&](size_t w) -> int {  // window w's results, once its copies have landed, into the caller's buffers
+        size_t b0, nb;
+        win(w, &b0, &nb);
+        hipError_t e = hipEventSynchronize(ln.ev_d2h[w & 1]);
+        if (e != hipSuccess) return fail(ZH_EHIP, "host windows: %s", hipGetErrorString(e));
+        if (k) { memcpy(out_ids + b0 * k, hIds + b0 * k, nb * k * 8); memcpy(out_keys + b0 * k, hKeys + b0 * k, nb * k * 8); }
+        memcpy(out_counts + b0, hCounts + b0, nb * 4);
+        return ZH_OK;
+    };
+    for (size_t w = 0; w < nw; w++) {
+        const int i = (int)(w & 1);
+        size_t b0, nb;
+        win(w, &b0, &nb);
+        if (w >= 2 && (rc = retire(w - 2))) return bail(rc);
+        memcpy(hs + b0 * d * 4, q + b0 * d, nb * d * 4);  // (pageable -> pinned: the copy engine then runs beside the other window's kernels)
+        hipError_t e = hipMemcpyAsync(dQ + b0 * d, hs + b0 * d * 4, nb * d * 4, hipMemcpyHostToDevice, str[i]);
+        if (e != hipSuccess) return bail(fail(ZH_EHIP, "host windows, H2D: %s", hipGetErrorString(e)));
+        const float *dq = dQ + b0 * d;
+        uint64_t *oi = dIds + b0 * k, *ok = dKeys + b0 * k;
+        uint32_t *oc = dCounts + b0;
+        if ((rc = ctx_begin(ctxs[i], &dq, 1, nb, k, metric, mode, str[i]))) return bail(rc);
+        if ((rc = ctx_finish(ctxs[i], &oi, &ok, &oc, ix->sweep_stream))) return bail(rc);
+        if (w >= 3 && (rc = hand_out(w - 3))) return bail(rc);  // (its copies were queued one iteration ago: landed long since)
+    }
+    for (size_t w = nw >= 2 ? nw - 2 : 0; w < nw; w++)
+        if ((rc = retire(w))) return bail(rc);
+    for (size_t w = nw >= 3 ? nw - 3 : 0; w < nw; w++)
+        if ((rc = hand_out(w))) return bail(rc);
+    return ZH_OK;
+}
+
 // one round of the combining front end: the requests of `grp` (same top_k, metric, mode) as ONE internal batch on lane `ln`
 static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_index::CombineReq *> &grp) {
     auto all_fail = [&](int rc) {
@@ -2238,10 +2435,12 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     if (rc) return all_fail(rc);
     hipError_t e;
     auto hip_fail = [&](hipError_t err, const char *what) { all_fail(fail(ZH_EHIP, "%s: %s", what, hipGetErrorString(err))); };
-    if (!ln.init) {
-        if ((rc = ctx_init(&ln.ctx, ix))) return all_fail(rc);
+    if (!ln.init) {  // (`init` only once BOTH the context and its stream exist; a partial lane is taken down again)
+        if ((rc = ctx_init(&ln.ctx, ix))) { ln.ctx.release_all(); return all_fail(rc); }
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi = the numerically lowest = highest priority: the light kernels' pool, as the pipelined callers')
+        if ((e = hipStreamCreateWithPriority(&ln.s, hipStreamNonBlocking, hi)) != hipSuccess) { ln.ctx.release_all(); ln.s = nullptr; return hip_fail(e, "hipStreamCreate"); }
         ln.init = true;
-        if ((e = hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     }
     hipStream_t s = ln.s;
     const uint32_t d = ix->opt.dim;
@@ -2251,6 +2450,14 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     if ((rc = ln.wQ.ensure(B * d * 4)) || (rc = ln.wOutIds.ensure(std::max<size_t>(B * k, 1) * 8)) ||
         (rc = ln.wOutKeys.ensure(std::max<size_t>(B * k, 1) * 8)) || (rc = ln.wOutCounts.ensure(B * 4)))
         return all_fail(rc);
+    if (grp.size() == 1 && host_windows_wanted(ix, B)) {  // one large batch: windows over two contexts, copies beside the kernels
+        if (search_host_windows(ix, ln, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
+            std::lock_guard<std::mutex> ls(ix->stats_mu);
+            ix->stats.host_window_calls_accum++;
+            return;
+        }
+        // (a window passed a per-batch limit, or an allocation failed: nothing is in flight; the classic path below decides what the call returns)
+    }
     const bool staged = grp.size() > 1;  // a lone caller's buffers are used as they are
     uint8_t *hs = nullptr;
     const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;

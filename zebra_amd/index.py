@@ -253,6 +253,24 @@ class LSHIndex:
         check(lib().zh_search_batch_device(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode, d_ids_ptr,
                                            d_keys_ptr, d_counts_ptr, stream))
 
+    def debug_keep_raw(self, on=True):
+        """tests: half-width batches keep a copy of the scan's raw pairs (zh_debug_keep_raw)"""
+        check(lib().zh_debug_keep_raw(self._h, 1 if on else 0))
+
+    def debug_scan_pairs(self, ctx=None):
+        """tests: every scored (row, query) pair of the most recent half-width batch of `ctx` (None: the blocking context, i.e. the last
+        search_batch_device call) as the scan made it -> (info dict, structured array of zh_debug_pair, qmeta [queries x 4]); zh_debug_scan_pairs"""
+        info = _ffi.DebugScanInfo()
+        h = ctx._h if ctx is not None else None
+        check(lib().zh_debug_scan_pairs(self._h, h, C.byref(info), None, 0, None))
+        dt = np.dtype([("row", "<u4"), ("query", "<u4"), ("lo", "<u4"), ("hi", "<u4"), ("raw_s", "<f4"), ("raw_a2", "<f4"), ("flags", "<u4"), ("visit", "<u4")])
+        assert dt.itemsize == C.sizeof(_ffi.DebugPair)
+        pairs = np.zeros(int(info.pairs), dt)
+        qmeta = np.zeros((int(info.queries), 4), np.float32)
+        if info.approx_scan:
+            check(lib().zh_debug_scan_pairs(self._h, h, C.byref(info), pairs.ctypes.data_as(C.c_void_p), pairs.shape[0], qmeta.ctypes.data_as(C.c_void_p)))
+        return info.as_dict(), pairs, qmeta
+
     def read_rows(self, first, n):
         """KeyValue::embedding (lsh.rs:107-119) for a run of rows."""
         out = np.empty((n, self.dim), np.float32)
