@@ -184,10 +184,13 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH CPU baseline leg (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-main-recall", action="store_true", help="debug: no recall run (torch brute force) for the bench line's own workload only")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: only the bench line's own workload")
-    ap.add_argument("--only-other", default=None, help="debug: comma list of other_configs keys to run")
-    ap.add_argument("--data", choices=["iid", "clustered"], default="iid",
-                    help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative")
+    ap.add_argument("--only-other", default=None, help="debug: comma list of other_configs keys to run (in THIS order)")
+    ap.add_argument("--sleep-before-other", type=float, default=0.0, help="debug: idle seconds before each of the other configurations (the order effect, DESIGN.md s9)")
+    ap.add_argument("--data", choices=["iid", "clustered", "clustered-shuffled"], default="iid",
+                    help="iid: BASELINE.md's ~N(0,1) rows (the bench line); clustered: 128-row clusters, where recall@k is informative; "
+                         "clustered-shuffled: the same clusters with their rows scattered over the table (a row's cluster from a hash of its id)")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking search call per step")
     ap.add_argument("--in-flight", type=int, default=2, help="windows in flight when pipelined (contexts); the look-ahead host loop uses one more")
     ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
@@ -679,7 +682,10 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                   "survivors_scored_exactly_per_query": st["approx_survivors"] / max(st["batch"], 1),
                                   "visits_ranked_exactly": st["approx_exact_visits"],
                                   # device memory the index holds for the fp16 copy of its stored rows (0: the VALU kernel on the f32 rows)
-                                  "fp16_row_copy_bytes": st.get("row_copy_bytes", 0)}
+                                  "fp16_row_copy_bytes": st.get("row_copy_bytes", 0),
+                                  # the matrix-core scan: a tile column is a DISTINCT query of a wave's pairs -- columns per pair of the last batch (a 1-in-64
+                                  # sample of the waves; 1.0 = nothing shared: every pair fetches its own copy of its query)
+                                  "columns_per_pair": (st["approx_columns"] / st["approx_column_pairs"]) if st.get("approx_column_pairs") else None}
     if lat_store["ms"]:
         ls = sorted(lat_store["ms"])
         lr = sorted(lat_store["ready_ms"])
@@ -1006,11 +1012,14 @@ def compact_line(full, limit=LINE_LIMIT):
             e["recall_at_10_reference_key"] = (r10.get("iid_rows") or {}).get("reference_key")
         if "recall_at_100" in v:
             e["recall_at_100"] = v["recall_at_100"]
+        cpp = (v.get("half_width_scan") or {}).get("columns_per_pair")
+        if cpp is not None:
+            e["columns_per_pair"] = cpp
         oc[key] = {a: b for a, b in e.items() if b is not None}
     optional.append(("other_configs", oc or None))
     hw = full.get("half_width_scan")
     optional.append(("half_width_scan", _pick(hw or {}, ("redone_by_the_f32_scan", "list_entries_per_query", "survivors_scored_exactly_per_query",
-                                                          "visits_ranked_exactly", "fp16_row_copy_bytes")) or None))
+                                                          "visits_ranked_exactly", "fp16_row_copy_bytes", "columns_per_pair")) or None))
     for key in ("preflight", "ranks_seen", "emulated", "pipelined_batches_in_flight", "timed_span", "detail"):
         optional.append((key, full.get(key)))
     for key, v in optional:
@@ -1057,9 +1066,9 @@ def main():
     emu = args.emulate_ranks if env.world == 1 else 0
     S = emu or env.world
     name = args.workload or ("cfg3" if S == 1 else "scale64m")
-    kind = 2 if args.data == "clustered" and WORKLOADS[name]["kind"] == 0 else None
+    kind = {"clustered": 2, "clustered-shuffled": 3}.get(args.data) if WORKLOADS[name]["kind"] == 0 else None
     res, ix, group, wl, M_shard = run_workload(env, name, S, env.rank if not emu else 0, args.steps, args.warmup, exchange=S > 1,
-                                               recall=not args.no_recall, M_override=args.max_node_size,
+                                               recall=not (args.no_recall or args.no_main_recall), M_override=args.max_node_size,
                                                rows_override=args.rows, batch_override=args.batch, kind_override=kind)
     pmc_traffic(args, name, S, res["roofline"])
     cpu = None
@@ -1074,10 +1083,12 @@ def main():
     other = None
     if S == 1 and env.world == 1 and not args.no_other_configs and name == "cfg3" and not args.rows:
         other = {}
-        only = set(args.only_other.split(",")) if args.only_other else None
-        for key, wname, shards, steps, *win in OTHER_CONFIGS:
-            if only and key not in only:
-                continue
+        only = args.only_other.split(",") if args.only_other else None
+        todo = OTHER_CONFIGS if not only else sorted((c for c in OTHER_CONFIGS if c[0] in only), key=lambda c: only.index(c[0]))
+        for key, wname, shards, steps, *win in todo:
+            if args.sleep_before_other > 0:
+                torch.cuda.synchronize()
+                time.sleep(args.sleep_before_other)
             is_cos = WORKLOADS[wname]["metric"] == "cosine" and not args.no_recall
             r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=is_cos, window_override=win[0] if win else None)
             ix2.close()
@@ -1127,7 +1138,18 @@ def main():
             r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=2)
             ix2.close()
             other["recall_clustered"] = {"workload": "cfg3 shape, clustered rows", "queries_per_s_this_gpu": r["qps"],
-                                         "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")}
+                                         "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate"),
+                                         "half_width_scan": r.get("half_width_scan"), "roofline": {kk: r["roofline"].get(kk) for kk in ("kernel", "launch_ms", "frac")}}
+            # ... and the same clusters with their rows scattered over the table (inserted in arbitrary order): what the scan's tree-0 row order is for
+            ix2.close()
+            del ix2
+            torch.cuda.empty_cache()
+            r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=3)
+            ix2.close()
+            other["recall_clustered_shuffled"] = {"workload": "cfg3 shape, clustered rows scattered over the table", "queries_per_s_this_gpu": r["qps"],
+                                                  "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate"),
+                                                  "half_width_scan": r.get("half_width_scan"),
+                                                  "roofline": {kk: r["roofline"].get(kk) for kk in ("kernel", "launch_ms", "frac")}}
 
     if env.rank == 0:
         k = wl["k"]
@@ -1138,7 +1160,8 @@ def main():
             # the arithmetic type of the path's RESULTS: every returned key is the canonical f32 sum (bit-equal to the oracle).  The scan that
             # PICKS the candidates may multiply fp16 copies on the matrix cores: `prefilter_dtype` says so at top level.
             "dtype": "f32",
-            "data": "synthetic" if args.data == "iid" else "synthetic (clustered: 128-row clusters)",
+            "data": {"iid": "synthetic", "clustered": "synthetic (clustered: 128-row clusters)",
+                     "clustered-shuffled": "synthetic (clustered, ~150 rows per cluster scattered over the table)"}[args.data],
             "pipelined_batches_in_flight": max(2, args.in_flight) if not args.no_pipeline else 1,
             "timed_span": "queries resident in HBM -> merged top-k in pinned host memory (D2H inside the span)",
             "config": res["config"],

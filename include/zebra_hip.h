@@ -162,6 +162,8 @@ typedef struct zh_stats_t {
     uint64_t approx_exact_visits;   /* ... leaf visits that take fewer than top_k rows: scored and ranked exactly */
     uint64_t approx_survivors;      /* ... rows (over all queries) that got the reference's key for the final top_k */
     uint64_t approx_list_entries;   /* ... candidates handed to the per-query stage (before de-duplication) */
+    uint64_t approx_columns;        /* ... approx_scan 2: a tile column of the matrix-core scan is a DISTINCT query of a wave's pairs; columns and pairs of */
+    uint64_t approx_column_pairs;   /*     (a 1-in-64 sample of) the waves of the most recent such batch: what the pairs share (1.0 = nothing) */
     uint64_t approx_batches_accum;  /* timed internal batches scanned this way */
     uint64_t approx_fallbacks_accum; /* batches redone by the f32 scan ON THE DEVICE, in stream order, because a list ran over */
     uint64_t approx_last_overflow;  /* ... what ran over: 1 a query's candidate list, 2 a query's survivors, 4 the table of exact

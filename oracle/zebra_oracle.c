@@ -79,9 +79,11 @@ static inline float synth_value(uint64_t seed, uint64_t idx, int kind) {
     return (float)t * (1.0f / 37837.2f);
 }
 
+/* kind 3 ("clustered, shuffled"): a row's cluster is drawn by a hash of its id (65,536 clusters): cluster-mates scattered over the table */
 static inline float synth_elem(uint64_t seed, uint64_t row, uint32_t col, uint32_t d, int kind) {
-    if (kind == 2) {
-        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, (row / ZO_CLUSTER_ROWS) * d + col) * (1.0f / 37837.2f);
+    if (kind == 2 || kind == 3) {
+        const uint64_t cluster = kind == 2 ? row / ZO_CLUSTER_ROWS : (splitmix64(seed ^ 0x5C0FF1Eull ^ (row * 0x9E3779B97F4A7C15ull)) & 0xFFFFull);
+        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, cluster * d + col) * (1.0f / 37837.2f);
         float own = (float)synth_centered(seed, row * d + col) * (1.0f / 37837.2f);
         return fmaf(0.25f, own, centre);
     }
@@ -103,7 +105,7 @@ ZO_EXPORT void zo_synth_queries(uint64_t seed_rows, uint64_t seed_q, uint64_t n_
         for (uint32_t c = 0; c < d; c++) {
             float x = synth_elem(seed_rows, r, c, d, kind);
             float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, (b0 + i) * d + c) * (1.0f / 37837.2f);
-            out[i * d + c] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : fmaf(kind == 2 ? 0.1f : 0.3f, g, x);
+            out[i * d + c] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : fmaf(kind >= 2 ? 0.1f : 0.3f, g, x);
         }
     }
 }

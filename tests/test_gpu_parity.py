@@ -282,7 +282,11 @@ def test_synthetic_generators_bit_exact(za):
     ix3.append_synthetic(700, seed=zo.SEED_ROWS, first_row=250, kind=2)
     assert (ix3.read_rows(0, 700).view(np.uint32) == zo.synth_rows(700, 64, row0=250, kind=2).view(np.uint32)).all()
     import torch
-    for kind, dd in ((0, 384), (1, 128), (2, 64)):
+    ix4 = za.LSHIndex(64, za.LSHIndexOptions(5, 15))
+    ix4.append_synthetic(900, seed=zo.SEED_ROWS, first_row=4_000_000_000, kind=3)
+    assert (ix4.read_rows(0, 900).view(np.uint32) == zo.synth_rows(900, 64, row0=4_000_000_000, kind=3).view(np.uint32)).all()
+    ix4.close()
+    for kind, dd in ((0, 384), (1, 128), (2, 64), (3, 96)):
         q = torch.empty((33, dd), dtype=torch.float32, device="cuda")
         za.synth_queries_device(0, q.data_ptr(), 12345, 33, dd, b0=7, kind=kind)
         want = zo.synth_queries(33, dd, 12345, b0=7, kind=kind)

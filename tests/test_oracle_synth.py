@@ -13,6 +13,7 @@ from oracle import zebra_oracle as zo
     (3000, 32, 5, 6, 10, 0, 0),         # reference defaults: the wandering walk (F5)
     (4096, 128, 256, 4, 10, 1, 7_000_000),   # SIFT-style integer rows, a shard that starts at row 7M
     (2500, 48, 100, 3, 100, 2, 123),    # clustered rows, k = 100 = leaves barely >= k
+    (2500, 48, 100, 3, 10, 3, 77),      # clustered rows scattered over the table (a row's cluster from a hash of its id)
 ])
 def test_synth_search_equals_in_memory_search(n, d, M, T, k, kind, row0):
     X = zo.synth_rows(n, d, row0=row0, kind=kind)

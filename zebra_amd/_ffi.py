@@ -54,7 +54,7 @@ class Stats(C.Structure):
                 ("prefiltered", C.c_uint64), ("prefilter_exact_visits", C.c_uint64), ("prefilter_exact_rows", C.c_uint64),
                 ("prefilter_fallbacks_accum", C.c_uint64), ("prefilter_last_overflow", C.c_uint64),
                 ("approx_scan", C.c_uint64), ("approx_exact_visits", C.c_uint64), ("approx_survivors", C.c_uint64),
-                ("approx_list_entries", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
+                ("approx_list_entries", C.c_uint64), ("approx_columns", C.c_uint64), ("approx_column_pairs", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
                 ("approx_last_overflow", C.c_uint64), ("combined_batches_accum", C.c_uint64), ("combined_calls_accum", C.c_uint64),
                 ("host_window_calls_accum", C.c_uint64), ("row_copy_bytes", C.c_uint64)]
 

@@ -228,6 +228,15 @@ struct zh_index {
     std::atomic<bool> h128_failed{false};
     std::atomic<uint64_t> scale_rows{0}, scale_gen{0};
     float row_rho = 0.f;
+    // Round 5 (VERDICT r4 #4b): the matrix-core scan's OWN view of the rows -- the fp16 tiles, their {|x|^2, 1 / scale} and the row -> leaf entries --
+    // is kept in TREE-0 LEAF ORDER: position p holds row scan_perm[p].  The scan never needs a row's id (its outputs go to key slots that the
+    // row -> leaf entries name), so nothing else changes; a wave's 16 rows then share tree 0's leaf -- its visitors are ONE tile column each for
+    // all 16 -- and, on data with structure, most other trees' too, whatever order the rows were inserted in.  Made with the copy (every live row
+    // must be in tree 0: no pending, no removed rows; else identity), rows appended later keep position = id; the f32 rows and every other kernel
+    // stay in id order.  row_leaf_p = the row -> leaf table gathered into that order (for row_leaf generation row_leaf_p_gen).
+    DevBuf scan_perm, row_leaf_p;
+    bool row_order_off = false;
+    uint64_t perm_rows = 0, row_leaf_gen = 0, row_leaf_p_gen = 0, perm_gen = 0, row_leaf_p_perm = 0;
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
     // the blocking entry points run on this context (under `mu`); staging buffers of the host-pointer variant
@@ -441,6 +450,7 @@ extern "C" void zh_index_destroy(zh_index *ix) {
     free_forest(ix);
     ix->X.release();
     ix->row_hn2.release(); ix->row_norm.release(); ix->row_half.release(); ix->row_meta.release(); ix->row_rho_dev.release(); ix->row_half128.release();
+    ix->scan_perm.release(); ix->row_leaf_p.release();
     ix->dctx.release_all();
     DevBuf *ws[] = {&ix->wQ, &ix->wOutIds, &ix->wOutKeys, &ix->wOutCounts};
     for (DevBuf *b : ws) b->release();
@@ -467,6 +477,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->row_hn2.release(); ix->row_norm.release();
     std::lock_guard<std::mutex> lb(ix->blk_mu);  // (the fp16 copies' state is blk_mu's: zh_stats reads it under that lock)
     ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
+    ix->perm_rows = 0; ix->perm_gen++; ix->scan_perm.release(); ix->row_leaf_p.release();
     ix->h128_rows = 0; ix->h128_gen = 0; ix->h128_rho = 0.f; ix->row_half128.release(); ix->h128_failed = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
     ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
@@ -1356,6 +1367,54 @@ static int build_row_leaf(zh_index *ix) {
     if (e != hipSuccess) return fail(ZH_EHIP, "row -> leaf table: %s", hipGetErrorString(e));
     ix->row_leaf_valid = true;
     ix->row_leaf_rows = ix->n_rows;
+    ix->row_leaf_gen++;
+    return ZH_OK;
+}
+
+// positions of the matrix-core scan's row order (under blk_mu): tree 0's leaves left to right, every leaf's rows as they stand.  perm_rows = 0:
+// identity (no trees, rows in no tree, or switched off)
+static int build_scan_perm(zh_index *ix) {
+    static const bool off = getenv("ZH_NO_ROW_ORDER") != nullptr;
+    ix->perm_rows = 0;
+    ix->perm_gen++;
+    if (off || ix->row_order_off || ix->h_roots.empty() || ix->n_dead || ix->n_rows == 0 || ix->n_rows > 0xFFFFFFF0ull) return ZH_OK;
+    std::vector<uint2> leaves;  // {offset into leaf_ids, first position}
+    std::vector<uint32_t> lens, st(1, ix->h_roots[0]);
+    uint64_t total = 0;
+    while (!st.empty()) {
+        const uint32_t n = st.back(); st.pop_back();
+        if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
+        else if (ix->h_right[n] > 0) {
+            leaves.push_back(make_uint2((uint32_t)ix->h_left[n], (uint32_t)total));
+            lens.push_back((uint32_t)ix->h_right[n]);
+            total += (uint32_t)ix->h_right[n];
+        }
+    }
+    if (total != ix->n_rows) return ZH_OK;  // rows that are in no tree yet (appended, not inserted): identity
+    DevBuf dl, dn;
+    int rc;
+    if ((rc = ix->scan_perm.ensure(ix->n_rows * 4)) || (rc = dl.ensure(leaves.size() * 8)) || (rc = dn.ensure(lens.size() * 4))) { dl.release(); dn.release(); return ZH_OK; }
+    hipError_t e = hipMemcpyAsync(dl.p, leaves.data(), leaves.size() * 8, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dn.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = zh_launch_perm_from_leaves(dl.as<uint2>(), dn.as<uint32_t>(), (uint32_t)leaves.size(), ix->leaf_ids.as<uint32_t>(), ix->scan_perm.as<uint32_t>(), ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    dl.release(); dn.release();
+    if (e != hipSuccess) return fail(ZH_EHIP, "row order of the scan: %s", hipGetErrorString(e));
+    ix->perm_rows = ix->n_rows;
+    return ZH_OK;
+}
+// the row -> leaf table in the scan's row order (under blk_mu; row_leaf must be valid)
+static int ensure_row_leaf_p(zh_index *ix) {
+    if (!ix->perm_rows) return ZH_OK;
+    if (ix->row_leaf_p_gen == ix->row_leaf_gen && ix->row_leaf_p_perm == ix->perm_gen) return ZH_OK;
+    const uint32_t T = ix->n_trees;
+    int rc = ix->row_leaf_p.ensure(std::max<uint64_t>(ix->n_rows * T, 1) * sizeof(uint2));
+    if (rc) { ix->perm_rows = 0; return ZH_OK; }  // (no room: the scan reads the table in id order -- but its tiles are in tree-0 order: the copy is remade)
+    hipError_t e = zh_launch_permute_row_leaf(ix->row_leaf.as<uint2>(), ix->scan_perm.as<uint32_t>(), ix->perm_rows, ix->n_rows, T, ix->row_leaf_p.as<uint2>(), ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) return fail(ZH_EHIP, "row -> leaf table in the scan's order: %s", hipGetErrorString(e));
+    ix->row_leaf_p_gen = ix->row_leaf_gen;
+    ix->row_leaf_p_perm = ix->perm_gen;
     return ZH_OK;
 }
 
@@ -1383,8 +1442,12 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
         from = 0;
         HIPCHK(hipMemsetAsync(ix->row_rho_dev.p, 0, 4, ix->stream));
     }
+    if (from == 0) {  // a copy made from scratch: in tree-0 leaf order where the forest allows (rows appended later keep position = id)
+        int rcp = build_scan_perm(ix);
+        if (rcp) return rcp;
+    }
     HIPCHK(zh_launch_row_half(ix->X.as<float>(), from, ix->n_rows - from, (uint32_t)d, ix->row_half.p, ix->row_meta.as<float2>(),
-                              ix->row_rho_dev.as<uint32_t>(), ix->stream));
+                              ix->row_rho_dev.as<uint32_t>(), ix->perm_rows ? ix->scan_perm.as<uint32_t>() : nullptr, ix->perm_rows, ix->stream));
     float rho = 0.f;
     HIPCHK(hipMemcpyAsync(&rho, ix->row_rho_dev.p, 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
@@ -1939,9 +2002,19 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     // the scan on the matrix cores, from an fp16 copy of the stored rows (+50 % of the row table, made on first use); no room for it, or mode 5:
     // the VALU kernel on the f32 rows
     bool mfma = c->approx && !c->approx_leaf && mfma_wanted(ix);
+    const uint2 *scan_row_leaf = ix->row_leaf.as<uint2>();
     if (mfma) {
         std::lock_guard<std::mutex> lk(ix->blk_mu);
         if ((rc = ensure_row_half(ix, &mfma))) return rc;
+        if (mfma && ix->perm_rows) {
+            if ((rc = ensure_row_leaf_p(ix))) return rc;
+            if (!ix->perm_rows) {  // no room for the table in the scan's order: the copy again, in id order, and no further attempt
+                ix->row_order_off = true;
+                ix->scale_gen = 0;
+                if ((rc = ensure_row_half(ix, &mfma))) return rc;
+            } else
+                scan_row_leaf = ix->row_leaf_p.as<uint2>();
+        }
     }
     c->approx_mfma = mfma;
     if (c->approx) {
@@ -1965,6 +2038,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         ap.ex_visits = c->wApEx.as<uint2>(); ap.ex_cap = ex_cap;
         ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
+        ap.n_queries = (uint32_t)B; ap.iv_cap = tot.rows;
         ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;
         ap.row_rho = mfma ? ix->row_rho : 0.f;
         if (c->approx_leaf) { ap.mfma = 2u; ap.row_rho = ap.rho_norm = ix->h128_rho; }
@@ -1983,7 +2057,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         HIPCHK(zh_launch_sweep128h(ix->row_half128.p, c->wQh.p, ldexpf(1.f, ix->h128_ex - 14), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(),
                                    tot.groups, c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->wKeys.as<uint64_t>(), hs));
     else if (c->approx)
-        HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
+        HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, mfma ? scan_row_leaf : ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
                                      c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group, c->metric, c->mode, hs));
     else if (c->scan)
         HIPCHK(zh_launch_scan_sweep(ix->X.as<float>(), d, ix->n_rows, c->dQ, c->wQQ.as<float>(), ix->row_leaf.as<uint2>(), T,
@@ -2097,6 +2171,9 @@ int ctx_wait(zh_search_ctx *c) {
     st.approx_exact_visits = apx ? c->h_ap[0] : 0;
     st.approx_survivors = apx ? c->h_ap[3] : 0;
     st.approx_list_entries = apx ? c->h_ap[4] : 0;
+    if (apx && c->h_ap[7]) fprintf(stderr, "zebra_hip: scan guard tripped, bits %u (diagnostic build)\n", c->h_ap[7]);
+    st.approx_columns = apx && c->approx_mfma ? c->h_ap[5] : 0;
+    st.approx_column_pairs = apx && c->approx_mfma ? c->h_ap[6] : 0;
     if (apx && c->h_ap[1]) {
         st.approx_fallbacks_accum++;
         st.approx_last_overflow = c->h_ap[1];

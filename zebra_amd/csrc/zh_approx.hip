@@ -502,14 +502,17 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 // scan wave's whole operand is D / 32 fully coalesced 1-KiB loads -- half the HBM bytes of the f32 rows, an eighth of the tag look-ups of
 // loading them fragment-shaped, nothing to convert in the scan.  rowMeta[row] = {f32 |x|^2, 1 / sigma_x (NaN: scale out of range or a
 // non-finite element: nothing is certain about this row)}; *rhoMax = the largest |x - xh / sigma_x| / |x| (f32 bits; atomicMax).
+// perm (may be null): the scan's row order -- POSITION p < perm_rows holds stored row perm[p] (tree-0 leaf order, zh_api.hip build_scan_perm); tiles and
+// rowMeta are indexed by position, which is all the scan ever uses.
 __global__ __launch_bounds__(256) void row_half_kernel(const float *__restrict__ X, uint64_t row0, uint64_t n_rows, uint32_t d,
-                                                       _Float16 *__restrict__ Xh, float2 *__restrict__ rowMeta, uint32_t *__restrict__ rhoMax) {
+                                                       _Float16 *__restrict__ Xh, float2 *__restrict__ rowMeta, uint32_t *__restrict__ rhoMax,
+                                                       const uint32_t *__restrict__ perm, uint64_t perm_rows) {
     const uint32_t lane = threadIdx.x & 63, NS = d / 32;
     const uint64_t nw = (uint64_t)gridDim.x * 4;
     float rho_w = 0.f;
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_rows; i += nw) {
-        const uint64_t row = row0 + i;
-        const float *x = X + (size_t)row * d;
+        const uint64_t row = row0 + i;  // the POSITION written
+        const float *x = X + (size_t)(perm && row < perm_rows ? perm[row] : row) * d;
         float m = 0.f, a2 = 0.f;
         bool bad = false;
         for (uint32_t e = lane; e < d; e += 64) {
@@ -549,22 +552,62 @@ __global__ __launch_bounds__(256) void row_half_kernel(const float *__restrict__
 }
 
 hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
-                              hipStream_t s) {
+                              const uint32_t *dPerm, uint64_t perm_rows, hipStream_t s) {
     if (!n_rows) return hipSuccess;
     const uint64_t blocks = std::min<uint64_t>((n_rows + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(row_half_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, row0, n_rows, d, (_Float16 *)dXh, dRowMeta, dRhoMax);
+    hipLaunchKernelGGL(row_half_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dX, row0, n_rows, d, (_Float16 *)dXh, dRowMeta, dRhoMax, dPerm, perm_rows);
+    return hipGetLastError();
+}
+
+// perm[first position of leaf j + i] = the i-th row of tree 0's j-th leaf (left to right)
+__global__ __launch_bounds__(256) void perm_from_leaves_kernel(const uint2 *__restrict__ leaves, const uint32_t *__restrict__ lens, uint32_t n_leaves,
+                                                               const uint32_t *__restrict__ leaf_ids, uint32_t *__restrict__ perm) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_leaves; j += gridDim.x * 4) {
+        const uint2 lf = leaves[j];
+        const uint32_t len = lens[j];
+        for (uint32_t i = lane; i < len; i += 64) perm[(size_t)lf.y + i] = leaf_ids[(size_t)lf.x + i];
+    }
+}
+hipError_t zh_launch_perm_from_leaves(const uint2 *dLeaves, const uint32_t *dLens, uint32_t n_leaves, const uint32_t *dLeafIds, uint32_t *dPerm, hipStream_t s) {
+    if (!n_leaves) return hipSuccess;
+    hipLaunchKernelGGL(perm_from_leaves_kernel, dim3(std::min<uint32_t>((n_leaves + 3) / 4, 256 * 16)), dim3(256), 0, s, dLeaves, dLens, n_leaves, dLeafIds, dPerm);
+    return hipGetLastError();
+}
+// out[p][t] = rowLeaf[perm[p]][t] for p < perm_rows, rowLeaf[p][t] beyond (rows appended after the order was made)
+__global__ __launch_bounds__(256) void permute_row_leaf_kernel(const uint2 *__restrict__ rowLeaf, const uint32_t *__restrict__ perm, uint64_t perm_rows,
+                                                               uint64_t n_entries, uint32_t T, uint2 *__restrict__ out) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = e / T, t = e % T;
+        out[e] = rowLeaf[(size_t)(p < perm_rows ? perm[p] : p) * T + t];
+    }
+}
+hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPerm, uint64_t perm_rows, uint64_t n_rows, uint32_t T, uint2 *dOut, hipStream_t s) {
+    const uint64_t n = n_rows * T;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(permute_row_leaf_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 64)), dim3(256), 0, s, dRowLeaf, dPerm, perm_rows, n, T, dOut);
     return hipGetLastError();
 }
 
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
 #endif
+// -DZH_SCAN_GUARD (diagnostic builds, never shipped): every index the matrix-core scan derives from its inputs is checked before it is used as an address;
+// a violation sets a bit of ctl[7] (printed by zh_search_wait) instead of faulting: 1 a query id >= the batch, 2 a key slot >= the scratch, 4 a list
+// position past the wave's list, 8 a column >= the wave's columns, 16 a probe sequence that does not end
+#ifdef ZH_SCAN_GUARD
+#define ZH_GUARD(cond, bit) ((cond) ? true : (atomicOr(guard, (bit)), false))
+#else
+#define ZH_GUARD(cond, bit) true
+#endif
 template <int D>
 __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
                                                          const uint4 *__restrict__ Qh, const uint2 *__restrict__ rowLeaf, uint32_t T,
                                                          uint32_t RW, const uint32_t *__restrict__ visitBits,
                                                          const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
-                                                         uint32_t GRP, uint64_t row_begin, uint64_t row_end, uint64_t *__restrict__ iv) {
+                                                         uint32_t GRP, uint64_t row_begin, uint64_t row_end, uint64_t *__restrict__ iv,
+                                                         uint32_t *__restrict__ colStats /* {columns, pairs} of (a sample of) the listed waves */,
+                                                         uint32_t nq, uint64_t iv_cap, uint32_t *__restrict__ guard) {
     constexpr int NS = D / 32;   // MFMA steps of a tile
     constexpr int NL = D / 64;   // 128-byte lines of a query = two steps each
     constexpr int CL = ZH_MFMA_CL ? ZH_MFMA_CL : (NL % 4 == 0 ? 2 : 3);  // lines per chunk: 2 CL load instructions, 2 CL KB of the wave's LDS
@@ -629,6 +672,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     const uint32_t rd0 = (c16 >> 3) * 64u + (c16 & 7u) * 8u + ((h ^ (c16 >> 1)) & 7u);   // even steps: piece h
     const uint32_t rd1 = (c16 >> 3) * 64u + (c16 & 7u) * 8u + (((4u + h) ^ (c16 >> 1)) & 7u);
     auto issue = [&](uint32_t bA, uint32_t bB, int chunk, u32x4v *dst) {
+        if (!ZH_GUARD(bA < nq && bB < nq, 1u)) { bA = 0; bB = 0; }
         const u32x4v *qa = Qv + (size_t)bA * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swA);
         const u32x4v *qb = Qv + (size_t)bB * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swB);
 #pragma unroll
@@ -652,7 +696,8 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
             const uint32_t i = rl & 3u;
             const float sv = i == 0 ? t[0] : (i == 1 ? t[1] : (i == 2 ? t[2] : t[3]));
             const float2 rm = rmeta[rl];
-            __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + slot);
+            if (ZH_GUARD(slot < iv_cap, 2u))
+                __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + slot);
         }
     };
     if (listed) {
@@ -703,7 +748,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
                 const uint64_t rec = list[pi];
                 const uint32_t b = (uint32_t)(rec >> 36) & 0xFFFFFFu, key = b + 1u;
                 uint32_t hs = hash_of(b), w = tab[hs];
-                while ((w >> 9) != key) { hs = (hs + 1u) & 1023u; w = tab[hs]; }
+                for (uint32_t tries = 0; (w >> 9) != key && ZH_GUARD(tries < 1024u, 16u); tries++) { (void)tries; hs = (hs + 1u) & 1023u; w = tab[hs]; }
                 const uint32_t col = w & 0x1FFu, pos = atomicAdd(&tstart[1 + (col >> 4)], 1u);
                 list[pi] = (rec & ~(0xFFFFFFull << 36)) | ((uint64_t)(col | (pos << 9)) << 36);
             }
@@ -732,7 +777,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
             for (int i = 0; i < ZH_APX_CAP / 64; i++)
                 if ((uint32_t)(64 * i) + lane < P) {
                     const uint32_t cp = (uint32_t)(recs[i] >> 36) & 0xFFFFFFu, col = cp & 0x1FFu, pos = (cp >> 9) & 0x1FFu;
-                    tl[tstart[col >> 4] + pos] = recs[i];
+                    if (ZH_GUARD(tstart[col >> 4] + pos < (uint32_t)ZH_APX_CAP && col < nd, 4u | (col < nd ? 0u : 8u))) tl[tstart[col >> 4] + pos] = recs[i];
                 }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -740,6 +785,9 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
         // the wave's distinct queries sixteen at a time; the next chunk of query lines is requested before the current one is multiplied,
         // across tile boundaries
         const uint32_t nt = (nd + 15) / 16;
+        // what the sharing is worth (zh_stats_t::approx_columns / approx_column_pairs): every 64th wave reports -- same-address atomics from all
+        // 200k waves of a launch serialise in one L2 channel (measured: 3.6 -> 5.5 ms per launch)
+        if (colStats && lane == 0 && (wave & 63u) == 0u) { atomicAdd(&colStats[0], nd); atomicAdd(&colStats[1], P); }
         auto col_b = [&](uint32_t t, uint32_t col) { const uint32_t ci = 16 * t + col; return colq[ci < nd ? ci : nd - 1]; };
         uint32_t bA = col_b(0, g8), bB = col_b(0, 8 + g8);
         u32x4v ra[2 * CL], rb[2 * CL];
@@ -770,7 +818,8 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
                 const uint32_t rl = (uint32_t)(rec >> 60), col = (uint32_t)(rec >> 36) & 15u;
                 const float sv = reinterpret_cast<const float *>(al)[col * 16 + rl];
                 const float2 rm = rmeta[rl];
-                __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + (rec & 0xFFFFFFFFFull));
+                if (ZH_GUARD((rec & 0xFFFFFFFFFull) < iv_cap, 2u))
+                    __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + (rec & 0xFFFFFFFFFull));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -818,7 +867,7 @@ static hipError_t launch_scan_mfma_d(const float *dX, uint64_t n_rows, const ZhA
         const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
         hipLaunchKernelGGL((scan_mfma_kernel<D>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)ap.row_half, ap.row_meta, (const uint4 *)ap.Qh, dRowLeaf, T, RW,
-                           dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv);
+                           dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv, ap.ctl + 5, ap.n_queries, ap.iv_cap, ap.ctl + 7);
     }
     return hipGetLastError();
 }
@@ -1516,15 +1565,19 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ X, uint3
     return key_of(metric, param, s0, s1, qq);
 }
 
-template <int D, int KIND, int LCAP>
-__global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_t k, const float *__restrict__ X, uint32_t d,
-                                                              const float *__restrict__ Q, const float *__restrict__ QQ, int metric,
-                                                              int param, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
-                                                              uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
-    __shared__ uint64_t sk[LCAP];  // id << 32 | sortable hi: equal ids end up side by side; later: the survivors' keys
+// Round 5: three kernels instead of one block per query doing everything.  The survivors' canonical keys were computed INSIDE the
+// query's block -- four waves, two rows in flight each -- so a query with thousands of survivors (the literal cosine key on 20k-row leaves: 3120 per
+// query at 64M rows, 879 on a cfg4 shard) kept its block, and 96 KB of LDS, for 7.6-23 ms.  Now: (1) final_survivors_kernel, a block per query:
+// duplicates out, tau, the survivors' ids back to the query's list slots; (2) final_exact_kernel, waves over ALL queries' survivors (grid.y = query,
+// a wave strides over the query's survivors with the query in registers): the reference's arithmetic at the rate HBM gives random rows; (3)
+// final_topk_kernel, a block per query: sort by (key, id), top_k (lsh.rs:557-564).  The survivors' keys live where the lists' lo / hi words were
+// (both arrays are dead once (1) has run; list_lo and list_hi are contiguous: B * capq u64 slots).
+template <int LCAP>
+__global__ __launch_bounds__(256) void final_survivors_kernel(uint32_t B, uint32_t k, ZhApprox ap) {
+    __shared__ uint64_t sk[LCAP];  // id << 32 | sortable hi: equal ids end up side by side
     __shared__ uint32_t sl[LCAP];  // sortable lo; later: the survivors' ids
     __shared__ uint32_t hist[256], scan[256], s_u[8];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
     // something ran over in select_interval / exact_visit (complete by now: same stream): a list whose count ran past its
     // capacity has slots nobody wrote -- nothing here may be dereferenced, and the f32 scan behind redoes the batch anyway
     if (ap.ctl[1] & (1u | 4u | 8u)) return;
@@ -1579,7 +1632,7 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
 #undef ZH_APX_HI
     }
     __syncthreads();
-    // the survivors (lo <= tau), compacted in place: their ids into sl (a thread's slice is read whole before anything is written)
+    // the survivors (lo <= tau): their ids go back to the front of the query's list slots (everything of the list is in LDS by now)
     cntl = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
@@ -1590,42 +1643,66 @@ __global__ __launch_bounds__(256) void final_interval_kernel(uint32_t B, uint32_
     }
     rank = block_scan(cntl);
     const uint32_t ns = scan[255];
-    __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++)
-        if (keep[j]) sl[rank++] = el[j];
-    __syncthreads();
-    // the survivors' keys, the reference's arithmetic (canonical sums): a wave takes every fourth, two rows in flight
-    {
-        const float *q = Q + (size_t)b * d;
-        const float qq = KIND == K_COS ? QQ[b] : 0.f;
-        float4 qreg[D > 0 ? RowVec<(D > 0 ? D : 4)>::NV : 1];
-        if constexpr (D > 0) load_row<D>(q, lane, qreg);
-        for (uint32_t i = wv; i < ns; i += 8) {
-            const uint32_t i2 = i + 4;
-            const uint64_t k0 = exact_key<D, KIND>(X, d, sl[i], q, qreg, qq, lane, metric, param);
-            uint64_t k1 = 0;
-            if (i2 < ns) k1 = exact_key<D, KIND>(X, d, sl[i2], q, qreg, qq, lane, metric, param);
-            if (lane == 0) {
-                sk[i] = k0;
-                if (i2 < ns) sk[i2] = k1;
-            }
+        if (keep[j]) ap.list_id[ob + rank++] = el[j];
+    if (tid == 0) {
+        ap.qcount[b] = ns;  // (from here on: the query's survivors)
+        atomicAdd(&ap.ctl[3], ns);
+        atomicAdd(&ap.ctl[4], n);
+    }
+}
+
+// the survivors' keys, the reference's arithmetic (canonical sums): grid (SX, B); the block's four waves stride over query blockIdx.y's
+// survivors, two rows in flight per wave, the query's float4s in registers (D > 0) -- a wave per ROW over all queries' survivors
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void final_exact_kernel(const float *__restrict__ X, uint32_t d, const float *__restrict__ Q,
+                                                           const float *__restrict__ QQ, int metric, int param, uint32_t b_first, ZhApprox ap) {
+    if (ap.ctl[1] & (1u | 4u | 8u)) return;
+    const uint32_t b = b_first + blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ns = ap.qcount[b], stride = gridDim.x * 4u, w0 = blockIdx.x * 4u + wv;
+    if (w0 >= ns) return;
+    const size_t ob = (size_t)b * ap.capq;
+    uint64_t *__restrict__ skeys = reinterpret_cast<uint64_t *>(ap.list_lo) + ob;
+    const float *q = Q + (size_t)b * d;
+    const float qq = KIND == K_COS ? QQ[b] : 0.f;
+    float4 qreg[D > 0 ? RowVec<(D > 0 ? D : 4)>::NV : 1];
+    if constexpr (D > 0) load_row<D>(q, lane, qreg);
+    for (uint32_t i = w0; i < ns; i += 2 * stride) {
+        const uint32_t i2 = i + stride;
+        const uint64_t k0 = exact_key<D, KIND>(X, d, ap.list_id[ob + i], q, qreg, qq, lane, metric, param);
+        uint64_t k1 = 0;
+        if (i2 < ns) k1 = exact_key<D, KIND>(X, d, ap.list_id[ob + i2], q, qreg, qq, lane, metric, param);
+        if (lane == 0) {
+            skeys[i] = k0;
+            if (i2 < ns) skeys[i2] = k1;
         }
     }
+}
+
+template <int LCAP>
+__global__ __launch_bounds__(256) void final_topk_kernel(uint32_t B, uint32_t k, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
+                                                          uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
+    __shared__ uint64_t sk[LCAP];
+    __shared__ uint32_t sl[LCAP];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (ap.ctl[1] & (1u | 4u | 8u)) return;
+    uint32_t ns = ap.qcount[b];
+    if (ns > (uint32_t)LCAP) ns = LCAP;
+    const size_t ob = (size_t)b * ap.capq;
+    const uint64_t *__restrict__ skeys = reinterpret_cast<const uint64_t *>(ap.list_lo) + ob;
     const uint32_t sp2 = next_pow2(ns);
-    __syncthreads();
-    for (uint32_t i = ns + tid; i < sp2; i += 256) { sk[i] = ~0ull; sl[i] = ~0u; }
+    for (uint32_t i = tid; i < sp2; i += 256) {
+        sk[i] = i < ns ? skeys[i] : ~0ull;
+        sl[i] = i < ns ? ap.list_id[ob + i] : ~0u;
+    }
     block_bitonic_sort<uint32_t>(sk, sl, sp2);
     const uint32_t have = ns < k ? ns : k;
     for (uint32_t i = tid; i < k; i += 256) {
         out_ids[(size_t)b * k + i] = i < have ? id_base + sl[i] : ~0ull;
         out_keys[(size_t)b * k + i] = i < have ? sk[i] : ~0ull;
     }
-    if (tid == 0) {
-        out_counts[b] = have;
-        atomicAdd(&ap.ctl[3], ns);
-        atomicAdd(&ap.ctl[4], n);
-    }
+    if (tid == 0) out_counts[b] = have;
 }
 
 hipError_t zh_launch_select_interval(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, const uint32_t *dLeafIds, ZhApprox ap,
@@ -1652,21 +1729,22 @@ static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uin
                                     uint64_t *dOutIds, uint64_t *dOutKeys, uint32_t *dOutCounts, uint32_t max_leaf_len, hipStream_t s) {
     hipLaunchKernelGGL(exact_keys_kernel<KIND>, dim3(512, (max_leaf_len + 255) / 256), dim3(256), 0, s, dVisits, dX, d, dQ, dQQ, dLeafIds, metric, mode, ap);
     hipLaunchKernelGGL(exact_visit_kernel, dim3(1024), dim3(256), 0, s, dVisits, dLeafIds, ap);
-#define ZH_APX_FIN(DD, LC) \
-    hipLaunchKernelGGL((final_interval_kernel<DD, KIND, LC>), dim3(B), dim3(256), 0, s, B, k, dX, d, dQ, dQQ, metric, mode, id_base, ap, dOutIds, \
-                       dOutKeys, dOutCounts)
-    if (ap.capq > 4096) {
-        if (d == 768) ZH_APX_FIN(768, 8192);
-        else ZH_APX_FIN(0, 8192);
-        return;
-    }
+    // (1) survivors per query, (2) their keys by waves over all queries' survivors, (3) top_k per query
+    const uint32_t SX = ap.capq > 4096 ? 16u : 8u;  // blocks of four waves per query in (2): a wave with no survivor left returns at once
+#define ZH_APX_EXACT(DD) \
+    for (uint32_t b0 = 0; b0 < B; b0 += 65535u) /* (gridDim.y <= 65535) */ \
+        hipLaunchKernelGGL((final_exact_kernel<DD, KIND>), dim3(SX, std::min(B - b0, 65535u)), dim3(256), 0, s, dX, d, dQ, dQQ, metric, mode, b0, ap)
+    if (ap.capq > 4096) hipLaunchKernelGGL((final_survivors_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, ap);
+    else hipLaunchKernelGGL((final_survivors_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, ap);
     switch (d) {
-    case 128: ZH_APX_FIN(128, 4096); break;
-    case 384: ZH_APX_FIN(384, 4096); break;
-    case 768: ZH_APX_FIN(768, 4096); break;
-    default: ZH_APX_FIN(0, 4096); break;
+    case 128: ZH_APX_EXACT(128); break;
+    case 384: ZH_APX_EXACT(384); break;
+    case 768: ZH_APX_EXACT(768); break;
+    default: ZH_APX_EXACT(0); break;
     }
-#undef ZH_APX_FIN
+#undef ZH_APX_EXACT
+    if (ap.capq > 4096) hipLaunchKernelGGL((final_topk_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts);
+    else hipLaunchKernelGGL((final_topk_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts);
 }
 
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,

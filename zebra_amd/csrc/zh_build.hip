@@ -38,9 +38,12 @@ __device__ __forceinline__ float synth_value(uint64_t seed, uint64_t idx, int ki
 }
 
 // kind 2 ("clustered"): 128 consecutive rows share a centre: x = centre + 0.25 * own noise
+// kind 3 ("clustered, shuffled"): the same with a row's cluster drawn by a hash of its id (65,536 clusters): cluster-mates are scattered
+// over the table, as rows inserted in arbitrary order are -- what the scan's tree-0 row order is for
 __device__ __forceinline__ float synth_elem(uint64_t seed, uint64_t row, uint32_t col, uint32_t d, int kind) {
-    if (kind == 2) {
-        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, (row / 128) * d + col) * (1.0f / 37837.2f);
+    if (kind == 2 || kind == 3) {
+        const uint64_t cluster = kind == 2 ? row / 128 : (zh_splitmix64(seed ^ 0x5C0FF1Eull ^ (row * 0x9E3779B97F4A7C15ull)) & 0xFFFFull);
+        float centre = (float)synth_centered(seed ^ 0xC1A57E5ull, cluster * d + col) * (1.0f / 37837.2f);
         float own = (float)synth_centered(seed, row * d + col) * (1.0f / 37837.2f);
         return __builtin_fmaf(0.25f, own, centre);
     }
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void synth_queries_kernel(float *__restrict__ 
     uint64_t r = zh_splitmix64(seed_q ^ (q * 0xA24BAED4963EE407ull)) % n_rows;
     float x = synth_elem(seed_rows, r, c, d, kind);
     float g = (float)synth_centered(seed_q + 0x51ED270B5EB2A002ull, q * d + c) * (1.0f / 37837.2f);
-    out[i] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : __builtin_fmaf(kind == 2 ? 0.1f : 0.3f, g, x);
+    out[i] = (kind == 1) ? x + (float)((int32_t)(g * 4.0f)) : __builtin_fmaf(kind >= 2 ? 0.1f : 0.3f, g, x);
 }
 
 hipError_t zh_launch_synth_queries(float *dOut, uint64_t seed_rows, uint64_t seed_q, uint64_t n_rows, uint64_t b0,

@@ -215,7 +215,8 @@ hipError_t zh_launch_distance_rows(const float *dX, uint64_t n, uint32_t d, cons
 // ---- the table scan with half-width queries (zh_approx.inl): intervals instead of keys, exact keys for the few rows they cannot
 // decide.  ctl[0] = visits sent to the exact path, ctl[1] = overflow bits (1 a query's candidate list, 2 a query's survivors,
 // 4 the table of exact visits, 8 the exact visits' key scratch) -- nonzero: the exact scan + select + final enqueued behind
-// redo the batch (their predicate), ctl[2] = key scratch handed out, ctl[3] = survivors scored exactly, ctl[4] = list entries.
+// redo the batch (their predicate), ctl[2] = key scratch handed out, ctl[3] = survivors scored exactly, ctl[4] = list entries,
+// ctl[5] / ctl[6] = tile columns / pairs of the matrix-core scan's listed waves (a column per distinct query: how much the pairs share).
 #define ZH_APX_CTL_WORDS 8
 struct ZhApprox {
     const void *Qh;          // the fp16 copy of the batch's queries (2 * d bytes each, qhalf_kernel's layout)
@@ -239,6 +240,8 @@ struct ZhApprox {
     float row_rho;           // |x - xh / sigma_x| <= row_rho |x| for every usable stored row (0 with f32 rows)
     float rho_norm;          // = row_rho where |x|^2 itself comes from the rounded row (sweep128h_kernel), else 0
     uint32_t mfma;           // zh_approx_bound's kind: 0 VALU scans, 1 scan_mfma_kernel, 2 sweep128h_kernel
+    uint32_t n_queries;      // queries of the internal batch, entries of iv (diagnostic builds check every index against them: -DZH_SCAN_GUARD)
+    uint64_t iv_cap;
 };
 uint32_t zh_approx_groups(uint32_t d);
 bool zh_approx_pays(uint32_t d);
@@ -247,7 +250,11 @@ bool zh_scan_mfma_supported(uint32_t d, uint32_t T);
 // the fp16 copy of rows [row0, row0 + n_rows) in scan_mfma_kernel's operand order (2 * d bytes per row, tiles of 16 rows), per row {|x|^2,
 // 1 / sigma_x}; *dRhoMax = the largest relative rounding error of a row (f32 bits, atomicMax)
 hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
-                              hipStream_t s);
+                              const uint32_t *dPerm /* null, or: position p < perm_rows holds row dPerm[p] */, uint64_t perm_rows, hipStream_t s);
+// the matrix-core scan's row order (tree-0 leaf order): the permutation from tree 0's leaves, and the row -> leaf table gathered into it
+hipError_t zh_launch_perm_from_leaves(const uint2 *dLeaves /* {offset into leaf_ids, first position} */, const uint32_t *dLens, uint32_t n_leaves,
+                                      const uint32_t *dLeafIds, uint32_t *dPerm, hipStream_t s);
+hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPerm, uint64_t perm_rows, uint64_t n_rows, uint32_t T, uint2 *dOut, hipStream_t s);
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
 hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, int layout, hipStream_t s);
 // d = 128, leaf by leaf at half width (sweep128h_kernel): the table's common scale from its largest finite element, the row-major fp16 copy, the sweep

@@ -145,10 +145,19 @@ class LSHIndex:
 
     def close(self):
         if getattr(self, "_h", None):
+            # contexts (and shard groups) hold a pointer to the index: they go first, whatever order the garbage collector would pick
+            for c in list(getattr(self, "_children", ())):
+                c.close()
             lib().zh_index_destroy(self._h)
             self._h = None
 
     __del__ = close
+
+    def _adopt(self, child):
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = weakref.WeakSet()
+        self._children.add(child)
 
     # lsh.rs:389-409
     def no_vectors(self):
@@ -318,6 +327,7 @@ class SearchContext:
         self._index = index  # keeps the index alive
         self._h = C.c_void_p()
         check(lib().zh_search_ctx_create(index._h, C.byref(self._h)))
+        index._adopt(self)
 
     def begin(self, d_q_ptr, b, top_k, metric, stream=None):
         check(lib().zh_search_begin(self._h, d_q_ptr, b, top_k, metric.metric, metric.mode, stream))
