@@ -685,7 +685,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
                                   "fp16_row_copy_bytes": st.get("row_copy_bytes", 0),
                                   # the matrix-core scan: a tile column is a DISTINCT query of a wave's pairs -- columns per pair of the last batch (a 1-in-64
                                   # sample of the waves; 1.0 = nothing shared: every pair fetches its own copy of its query)
-                                  "columns_per_pair": (st["approx_columns"] / st["approx_column_pairs"]) if st.get("approx_column_pairs") else None}
+                                  "columns_per_pair": (st["approx_columns"] / st["approx_column_pairs"]) if st.get("approx_column_pairs") else None,
+                                  # the order the scan keeps its view of the rows in (0 id order, 2 / 3 sorted by the leaves of that many trees; measured, best kept)
+                                  "scan_order_keys": st.get("scan_order_keys"), "scan_order_share": st.get("scan_order_share_permille", 0) / 1000.0}
     if lat_store["ms"]:
         ls = sorted(lat_store["ms"])
         lr = sorted(lat_store["ready_ms"])
@@ -1019,7 +1021,7 @@ def compact_line(full, limit=LINE_LIMIT):
     optional.append(("other_configs", oc or None))
     hw = full.get("half_width_scan")
     optional.append(("half_width_scan", _pick(hw or {}, ("redone_by_the_f32_scan", "list_entries_per_query", "survivors_scored_exactly_per_query",
-                                                          "visits_ranked_exactly", "fp16_row_copy_bytes", "columns_per_pair")) or None))
+                                                          "visits_ranked_exactly", "fp16_row_copy_bytes", "columns_per_pair", "scan_order_keys")) or None))
     for key in ("preflight", "ranks_seen", "emulated", "pipelined_batches_in_flight", "timed_span", "detail"):
         optional.append((key, full.get(key)))
     for key, v in optional:

@@ -172,6 +172,9 @@ typedef struct zh_stats_t {
     uint64_t combined_calls_accum;   /* ... and the calls they served */
     uint64_t host_window_calls_accum; /* zh_search_batch calls whose (large, host-resident) batch ran as windows over two contexts, copies beside
                                       * the kernels (since reset) */
+    uint64_t scan_order_keys;        /* the matrix-core scan keeps ITS view of the rows (fp16 tiles, row -> leaf entries) in the order that lets a tile's 16 rows
+                                      * share the most leaves: 0 id order, 2 / 3 sorted by the leaves in that many trees -- measured when the copy is made */
+    uint64_t scan_order_share_permille; /* ... (adjacent rows, tree) combinations in the same leaf under the kept order, per thousand */
     uint64_t row_copy_bytes;         /* device memory the index holds for fp16 copies of its stored rows (the half-width sweeps: zh_set_sweep_mode);
                                      * 0 until a batch has used one, and with modes 1 / 2 / 5 */
 } zh_stats_t;

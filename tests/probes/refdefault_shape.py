@@ -65,7 +65,18 @@ print(f"blocks (<= 64 nodes): {blocks.shape[0]} (mean {blocks.mean():.1f} nodes,
 usize = np.zeros(nn, np.int64)
 for v in order[::-1]:
     usize[v] = 1 if size[v] <= 64 else 1 + usize[left[v]] + usize[right[v]]
-sblocks, upper2 = decompose(None, np.where(size <= 64, 10**9, usize), 63)  # (blocks themselves are not super-blocks)
+sb, upper2, st = [], 0, [int(r) for r in roots]
+while st:
+    v = st.pop()
+    if size[v] <= 64:
+        continue              # a block hanging off a high upper node: not a super-block by itself
+    if usize[v] <= 63:
+        sb.append(int(usize[v]))
+    else:
+        upper2 += 1
+        st.append(int(right[v]))
+        st.append(int(left[v]))
+sblocks = np.array(sb)
 print(f"super-blocks (<= 63 slots of upper nodes + block leaves): {sblocks.shape[0]} (mean {sblocks.mean():.1f} slots), upper nodes left above them {upper2} "
       f"({upper2 / len(roots):.0f} per tree)")
 print(f"a DP over the whole forest reads {nn} nodes x 256 queries = {nn * 256 / 1e9:.2f} G node-queries per batch")

@@ -229,13 +229,15 @@ struct zh_index {
     std::atomic<uint64_t> scale_rows{0}, scale_gen{0};
     float row_rho = 0.f;
     // Round 5 (VERDICT r4 #4b): the matrix-core scan's OWN view of the rows -- the fp16 tiles, their {|x|^2, 1 / scale} and the row -> leaf entries --
-    // is kept in TREE-0 LEAF ORDER: position p holds row scan_perm[p].  The scan never needs a row's id (its outputs go to key slots that the
-    // row -> leaf entries name), so nothing else changes; a wave's 16 rows then share tree 0's leaf -- its visitors are ONE tile column each for
-    // all 16 -- and, on data with structure, most other trees' too, whatever order the rows were inserted in.  Made with the copy (every live row
-    // must be in tree 0: no pending, no removed rows; else identity), rows appended later keep position = id; the f32 rows and every other kernel
-    // stay in id order.  row_leaf_p = the row -> leaf table gathered into that order (for row_leaf generation row_leaf_p_gen).
+    // is kept sorted by (leaf in tree 0, leaf in tree 1, leaf in tree 2, id): position p holds row scan_perm[p] (zh_order.hip).  The scan never needs
+    // a row's id (its outputs go to key slots that the row -> leaf entries name), so nothing else changes; a wave's 16 rows then share tree 0's leaf --
+    // its visitors are ONE tile column each for all 16 -- and, on data with structure, most other trees' too, whatever order the rows were inserted
+    // in.  Made with the copy, from the row -> leaf table; rows appended later keep position = id; the f32 rows and every other kernel stay in id
+    // order.  row_leaf_p = the row -> leaf table gathered into that order (for row_leaf generation row_leaf_p_gen).
     DevBuf scan_perm, row_leaf_p;
     bool row_order_off = false;
+    uint32_t order_keys = 0;   // trees whose leaves the kept order sorts by (0: id order)
+    double order_worth = 0;    // share of (adjacent positions, tree) combinations in the same leaf under the kept order
     uint64_t perm_rows = 0, row_leaf_gen = 0, row_leaf_p_gen = 0, perm_gen = 0, row_leaf_p_perm = 0;
     uint64_t row_leaf_rows = 0;  // stored rows the table was built for (rows appended since are in no tree yet, but must not be scanned past it)
 
@@ -1240,6 +1242,8 @@ extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
     }
     std::lock_guard<std::mutex> lk(ix->blk_mu);  // (the copies are made and dropped under it)
     out->row_copy_bytes = ix->row_half.cap + ix->row_meta.cap + ix->row_half128.cap;
+    out->scan_order_keys = ix->perm_rows ? ix->order_keys : 0;
+    out->scan_order_share_permille = (uint64_t)(ix->order_worth * 1000.0 + 0.5);
     return ZH_OK;
 }
 extern "C" int zh_stats_reset(zh_index *ix) {
@@ -1371,36 +1375,48 @@ static int build_row_leaf(zh_index *ix) {
     return ZH_OK;
 }
 
-// positions of the matrix-core scan's row order (under blk_mu): tree 0's leaves left to right, every leaf's rows as they stand.  perm_rows = 0:
-// identity (no trees, rows in no tree, or switched off)
+// the matrix-core scan's row order (under blk_mu; zh_order.hip), from the row -> leaf table, which must be valid for the stored rows.  Candidates:
+// id order (rows inserted cluster by cluster are best left alone), sorted by (leaf in tree 0, leaf in tree 1, id), and by three trees' leaves; each
+// is MEASURED -- (adjacent positions, tree) combinations that share a leaf = visitors a tile fetches once -- and the best one kept.
+// perm_rows = 0: id order (it won, there is no table, the order is switched off, or there is no room for the sort).  ZH_ROW_ORDER=0|2|3 forces one.
 static int build_scan_perm(zh_index *ix) {
-    static const bool off = getenv("ZH_NO_ROW_ORDER") != nullptr;
+    const char *env_o = getenv("ZH_ROW_ORDER");  // (read when a copy is made: tests and A/B switch it)
+    const int forced = env_o ? atoi(env_o) : (getenv("ZH_NO_ROW_ORDER") ? 0 : -1);
     ix->perm_rows = 0;
     ix->perm_gen++;
-    if (off || ix->row_order_off || ix->h_roots.empty() || ix->n_dead || ix->n_rows == 0 || ix->n_rows > 0xFFFFFFF0ull) return ZH_OK;
-    std::vector<uint2> leaves;  // {offset into leaf_ids, first position}
-    std::vector<uint32_t> lens, st(1, ix->h_roots[0]);
-    uint64_t total = 0;
-    while (!st.empty()) {
-        const uint32_t n = st.back(); st.pop_back();
-        if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
-        else if (ix->h_right[n] > 0) {
-            leaves.push_back(make_uint2((uint32_t)ix->h_left[n], (uint32_t)total));
-            lens.push_back((uint32_t)ix->h_right[n]);
-            total += (uint32_t)ix->h_right[n];
+    ix->order_keys = 0;
+    if (forced == 0 || ix->row_order_off || !ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows || ix->n_rows < 32 || ix->n_rows > 0x7FFFFFF0ull) return ZH_OK;
+    size_t mem_free = 0, mem_total = 0;  // the sort's scratch: ~28 bytes per row, released before the copy is made
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < ix->n_rows * 48 + mem_total / 16) return ZH_OK;
+    DevBuf cand, dsum;
+    if (ix->scan_perm.ensure(ix->n_rows * 4) || cand.ensure(ix->n_rows * 4) || dsum.ensure(8)) { cand.release(); dsum.release(); return ZH_OK; }
+    const uint2 *rl = ix->row_leaf.as<uint2>();
+    const uint32_t T = ix->n_trees;
+    auto worth = [&](const uint32_t *perm, unsigned long long *out) -> hipError_t {
+        hipError_t e = zh_launch_order_agreement(rl, perm, ix->n_rows, T, dsum.as<unsigned long long>(), ix->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dsum.p, 8, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        return e;
+    };
+    unsigned long long best = 0, w = 0;
+    hipError_t e = forced > 0 ? hipSuccess : worth(nullptr, &best);
+    uint32_t best_keys = 0;
+    for (uint32_t keys = 2; keys <= 3 && e == hipSuccess; keys++) {
+        if (forced > 0 && (uint32_t)forced != keys) continue;
+        if ((e = zh_launch_scan_order(rl, ix->n_rows, T, keys, cand.as<uint32_t>(), ix->stream)) != hipSuccess) break;
+        if ((e = worth(cand.as<uint32_t>(), &w)) != hipSuccess) break;
+        if (forced > 0 || w > best + best / 50) {  // (an order must be worth 2 % more than what there is)
+            best = w; best_keys = keys;
+            e = hipMemcpyAsync(ix->scan_perm.p, cand.p, ix->n_rows * 4, hipMemcpyDeviceToDevice, ix->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
         }
     }
-    if (total != ix->n_rows) return ZH_OK;  // rows that are in no tree yet (appended, not inserted): identity
-    DevBuf dl, dn;
-    int rc;
-    if ((rc = ix->scan_perm.ensure(ix->n_rows * 4)) || (rc = dl.ensure(leaves.size() * 8)) || (rc = dn.ensure(lens.size() * 4))) { dl.release(); dn.release(); return ZH_OK; }
-    hipError_t e = hipMemcpyAsync(dl.p, leaves.data(), leaves.size() * 8, hipMemcpyHostToDevice, ix->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dn.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, ix->stream);
-    if (e == hipSuccess) e = zh_launch_perm_from_leaves(dl.as<uint2>(), dn.as<uint32_t>(), (uint32_t)leaves.size(), ix->leaf_ids.as<uint32_t>(), ix->scan_perm.as<uint32_t>(), ix->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-    dl.release(); dn.release();
+    cand.release(); dsum.release();
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return ZH_OK; }
     if (e != hipSuccess) return fail(ZH_EHIP, "row order of the scan: %s", hipGetErrorString(e));
-    ix->perm_rows = ix->n_rows;
+    ix->order_keys = best_keys;
+    ix->order_worth = (double)best / ((double)(ix->n_rows - 1) * T);
+    if (best_keys) ix->perm_rows = ix->n_rows;
     return ZH_OK;
 }
 // the row -> leaf table in the scan's row order (under blk_mu; row_leaf must be valid)
@@ -2001,7 +2017,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     ZhApprox ap{};
     // the scan on the matrix cores, from an fp16 copy of the stored rows (+50 % of the row table, made on first use); no room for it, or mode 5:
     // the VALU kernel on the f32 rows
-    bool mfma = c->approx && !c->approx_leaf && mfma_wanted(ix);
+    bool mfma = c->approx && !c->approx_leaf && mfma_wanted(ix) && B < (1u << 23) - 1;  // (the column pass packs query + 1 into 23 bits of an LDS word)
     const uint2 *scan_row_leaf = ix->row_leaf.as<uint2>();
     if (mfma) {
         std::lock_guard<std::mutex> lk(ix->blk_mu);

@@ -559,21 +559,6 @@ hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, u
     return hipGetLastError();
 }
 
-// perm[first position of leaf j + i] = the i-th row of tree 0's j-th leaf (left to right)
-__global__ __launch_bounds__(256) void perm_from_leaves_kernel(const uint2 *__restrict__ leaves, const uint32_t *__restrict__ lens, uint32_t n_leaves,
-                                                               const uint32_t *__restrict__ leaf_ids, uint32_t *__restrict__ perm) {
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_leaves; j += gridDim.x * 4) {
-        const uint2 lf = leaves[j];
-        const uint32_t len = lens[j];
-        for (uint32_t i = lane; i < len; i += 64) perm[(size_t)lf.y + i] = leaf_ids[(size_t)lf.x + i];
-    }
-}
-hipError_t zh_launch_perm_from_leaves(const uint2 *dLeaves, const uint32_t *dLens, uint32_t n_leaves, const uint32_t *dLeafIds, uint32_t *dPerm, hipStream_t s) {
-    if (!n_leaves) return hipSuccess;
-    hipLaunchKernelGGL(perm_from_leaves_kernel, dim3(std::min<uint32_t>((n_leaves + 3) / 4, 256 * 16)), dim3(256), 0, s, dLeaves, dLens, n_leaves, dLeafIds, dPerm);
-    return hipGetLastError();
-}
 // out[p][t] = rowLeaf[perm[p]][t] for p < perm_rows, rowLeaf[p][t] beyond (rows appended after the order was made)
 __global__ __launch_bounds__(256) void permute_row_leaf_kernel(const uint2 *__restrict__ rowLeaf, const uint32_t *__restrict__ perm, uint64_t perm_rows,
                                                                uint64_t n_entries, uint32_t T, uint2 *__restrict__ out) {

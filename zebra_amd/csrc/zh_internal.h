@@ -251,9 +251,11 @@ bool zh_scan_mfma_supported(uint32_t d, uint32_t T);
 // 1 / sigma_x}; *dRhoMax = the largest relative rounding error of a row (f32 bits, atomicMax)
 hipError_t zh_launch_row_half(const float *dX, uint64_t row0, uint64_t n_rows, uint32_t d, void *dXh, float2 *dRowMeta, uint32_t *dRhoMax,
                               const uint32_t *dPerm /* null, or: position p < perm_rows holds row dPerm[p] */, uint64_t perm_rows, hipStream_t s);
-// the matrix-core scan's row order (tree-0 leaf order): the permutation from tree 0's leaves, and the row -> leaf table gathered into it
-hipError_t zh_launch_perm_from_leaves(const uint2 *dLeaves /* {offset into leaf_ids, first position} */, const uint32_t *dLens, uint32_t n_leaves,
-                                      const uint32_t *dLeafIds, uint32_t *dPerm, hipStream_t s);
+// the matrix-core scan's row order: the permutation (zh_order.hip) and the row -> leaf table gathered into it
+// (zh_order.hip) dPerm[p] = the row at position p of the order (leaf in tree 0, leaf in tree 1[, leaf in tree 2], row id); synchronises the stream
+hipError_t zh_launch_scan_order(const uint2 *dRowLeaf, uint64_t n_rows, uint32_t T, uint32_t n_keys, uint32_t *dPerm, hipStream_t s);
+// ... and what an order is worth: (adjacent positions, tree) combinations in the same leaf (dPerm null: id order)
+hipError_t zh_launch_order_agreement(const uint2 *dRowLeaf, const uint32_t *dPerm, uint64_t n_rows, uint32_t T, unsigned long long *dOut, hipStream_t s);
 hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPerm, uint64_t perm_rows, uint64_t n_rows, uint32_t T, uint2 *dOut, hipStream_t s);
 bool zh_scan_approx_supported(uint32_t d, uint32_t T, int metric);
 hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, float4 *dQmeta, int layout, hipStream_t s);
