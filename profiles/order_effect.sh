@@ -21,3 +21,6 @@ echo "== cfg2 then the cfg4 shard, no recall runs at all:"
 python bench.py --steps 4 --warmup 2 --cpu-seconds 0 --no-recall --only-other cfg2,cfg4_one_of_8_shards 2>gpurun_out/order.err | python3 -c "$fmt" || tail -3 gpurun_out/order.err
 kill $SMI
 wc -l gpurun_out/order_effect_smi.txt
+echo "== one window on the GPU at a time (--serial-windows): is the SCAN slower, or what runs beside it?  cfg2 (recall) then cfg4, then cfg4 then cfg2:"
+python bench.py --steps 4 --warmup 2 --cpu-seconds 0 --no-main-recall --serial-windows --only-other cfg2,cfg4_one_of_8_shards 2>gpurun_out/order.err | python3 -c "$fmt" || tail -3 gpurun_out/order.err
+python bench.py --steps 4 --warmup 2 --cpu-seconds 0 --no-main-recall --serial-windows --only-other cfg4_one_of_8_shards,cfg2 2>gpurun_out/order.err | python3 -c "$fmt" || tail -3 gpurun_out/order.err

@@ -69,19 +69,29 @@ def test_every_row_order_gives_the_oracles_answer(za, monkeypatch, order, kind):
 
 
 def test_sorted_order_shares_more_on_scattered_clusters(za, monkeypatch):
-    """what the order is for: with a cluster's rows scattered over the table a tile's 16 rows share few visitors in id order, most in the sorted one"""
-    n, d, M, T, k, B = 60000, 256, 600, 15, 10, 512
-    X = zo.synth_rows(n, d, kind=3)
-    Q = zo.synth_queries(B, d, n, kind=3)
+    """what the order is for: with a cluster's rows scattered over the table a tile's 16 rows share few visitors in id order, most in a sorted one --
+    and the library's own (measured) choice is a sorted one"""
+    rng = np.random.default_rng(5)
+    n, d, M, T, k, B, per = 48000, 256, 600, 15, 10, 64, 120
+    centres = rng.standard_normal((n // per, d)).astype(np.float32)
+    owner = rng.permutation(np.repeat(np.arange(n // per), per))          # a row's cluster: scattered over the ids
+    X = (centres[owner] + 0.25 * rng.standard_normal((n, d))).astype(np.float32)
+    Q = (X[rng.integers(0, n, B)] + 0.1 * rng.standard_normal((B, d))).astype(np.float32)
     share = {}
-    for order in ("0", "2"):
-        monkeypatch.setenv("ZH_ROW_ORDER", order)
+    for order in ("0", "2", None):
+        if order is None:
+            monkeypatch.delenv("ZH_ROW_ORDER", raising=False)
+        else:
+            monkeypatch.setenv("ZH_ROW_ORDER", order)
         ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
         ix.add(X)
         ix.set_sweep_mode("approx")
         ix.search_batch(Q, k, za.L2Distance())
         st = ix.stats()
-        assert st["approx_scan"] == 2 and st["scan_order_keys"] == int(order)
-        share[order] = (st["approx_columns"] / st["approx_column_pairs"], st["scan_order_share_permille"])
+        assert st["approx_scan"] == 2 and st["approx_column_pairs"] > 0, st
+        if order is not None:
+            assert st["scan_order_keys"] == int(order)
+        share[order] = (st["approx_columns"] / st["approx_column_pairs"], st["scan_order_share_permille"], st["scan_order_keys"])
         ix.close()
-    assert share["2"][1] > share["0"][1] and share["2"][0] < share["0"][0], share
+    assert share["2"][1] > share["0"][1] and share["2"][0] < 0.9 * share["0"][0], share
+    assert share[None][2] in (2, 3) and share[None][0] <= share["2"][0] * 1.05, share
