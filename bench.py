@@ -721,6 +721,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     if recall and args.recall_queries > 0:
         nq = min(args.recall_queries, B)
         q = queries[-1][:nq]
+        brute = recall != "planted"  # "planted": only whether the planted neighbour is returned (no torch brute force in this process yet: DESIGN.md s9, the order effect)
 
         def search_ids(m):
             if group is None:
@@ -734,11 +735,13 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
 
         rec_metric = metric if wl["metric"] != "cosine" else make_metric(za, "cosine", parity=False)
         got = search_ids(rec_metric)
-        got_parity = search_ids(metric) if wl["metric"] == "cosine" else None
+        got_parity = search_ids(metric) if wl["metric"] == "cosine" and brute else None
         # exact neighbours over the whole (sharded) set: local exact top-k, gathered, re-ranked by true distance
-        Xt = _wrap_rows(torch, ix, rows_local, d, dev)
-        true_local = exact_topk(torch, Xt, q, k, "cosine" if wl["metric"] == "cosine" else "l2") + first_row
-        if env.dist and S == env.world:
+        Xt = _wrap_rows(torch, ix, rows_local, d, dev) if brute else None
+        true_local = exact_topk(torch, Xt, q, k, "cosine" if wl["metric"] == "cosine" else "l2") + first_row if brute else None
+        if not brute:
+            true_ids = None
+        elif env.dist and S == env.world:
             all_true = [torch.empty_like(true_local, device="cpu") for _ in range(S)]
             env.dist.all_gather(all_true, true_local.cpu())
             cand = torch.cat(all_true, 1).to(dev)
@@ -760,8 +763,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
             return sum(len(set(gt[b].tolist()) & set(tt[b].tolist())) for b in idx) / (len(idx) * k) if idx else None
 
         out["planted_neighbour_hit_rate"] = float((got.cpu().numpy()[here] == pl[here, None]).any(1).mean()) if here.any() else None
-        out[f"recall_at_{k}"] = rec(got)
-        out[f"recall_at_{k}_reference_key"] = rec(got_parity) if got_parity is not None else out[f"recall_at_{k}"]
+        out[f"recall_at_{k}"] = rec(got) if brute else None
+        out[f"recall_at_{k}_reference_key"] = (rec(got_parity) if got_parity is not None else out[f"recall_at_{k}"]) if brute else None
         if S > 1 and (group is None or group.ranks() < S):
             out["recall_note"] = ("one shard of %d: recall is against this shard's rows only, over the %d of %d sampled queries whose planted "
                                   "neighbour lives in this shard" % (S, int(here.sum()), nq))
@@ -1069,8 +1072,14 @@ def main():
     S = emu or env.world
     name = args.workload or ("cfg3" if S == 1 else "scale64m")
     kind = {"clustered": 2, "clustered-shuffled": 3}.get(args.data) if WORKLOADS[name]["kind"] == 0 else None
+    will_run_others = S == 1 and env.world == 1 and not args.no_other_configs and name == "cfg3" and not args.rows
+    # The order of things ("order effect"): an index whose device buffers are allocated after torch's brute-force recall ran in this
+    # process scans up to a third slower (the matrix-core scan; not clocks, not the TLB, not the L2 hit rate: profiles/r05_order_effect*.txt).  So the
+    # TIMED runs come first -- the bench line's own workload, then the other configurations, each with only the planted-neighbour check -- and the
+    # brute-force recall runs (which rebuild their small / medium indexes) after all of them.  --no-other-configs: the recall in place, as before.
+    main_recall = False if (args.no_recall or args.no_main_recall) else ("planted" if will_run_others else True)
     res, ix, group, wl, M_shard = run_workload(env, name, S, env.rank if not emu else 0, args.steps, args.warmup, exchange=S > 1,
-                                               recall=not (args.no_recall or args.no_main_recall), M_override=args.max_node_size,
+                                               recall=main_recall, M_override=args.max_node_size,
                                                rows_override=args.rows, batch_override=args.batch, kind_override=kind)
     pmc_traffic(args, name, S, res["roofline"])
     cpu = None
@@ -1083,41 +1092,24 @@ def main():
     torch.cuda.empty_cache()
 
     other = None
-    if S == 1 and env.world == 1 and not args.no_other_configs and name == "cfg3" and not args.rows:
+    if will_run_others:
         other = {}
         only = args.only_other.split(",") if args.only_other else None
         todo = OTHER_CONFIGS if not only else sorted((c for c in OTHER_CONFIGS if c[0] in only), key=lambda c: only.index(c[0]))
+        later = []  # the cosine configurations' recall runs, after every timed run
         for key, wname, shards, steps, *win in todo:
             if args.sleep_before_other > 0:
                 torch.cuda.synchronize()
                 time.sleep(args.sleep_before_other)
             is_cos = WORKLOADS[wname]["metric"] == "cosine" and not args.no_recall
-            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=is_cos, window_override=win[0] if win else None)
+            in_place = is_cos and wname == "scale64m"  # (64M rows are not built twice: the last timed configuration, its scan the VALU kernel)
+            r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=(True if in_place else ("planted" if is_cos else False)),
+                                            window_override=win[0] if win else None)
             ix2.close()
             del ix2
             torch.cuda.empty_cache()
-            rec10 = None
             if is_cos:
-                # BASELINE.json's metric is "queries/sec + recall@10" on the 768-d cosine top-10 shape: recall against GPU brute force under
-                # BOTH keys -- the corrected one (cosine distance) and the reference's literal one (distance.rs:23-25 sorts by similarity:
-                # ~0 by construction) -- on the bench's iid rows (where only the planted neighbour can be found) and on
-                # clustered rows (128 consecutive rows share a centre: informative), same shape, same index options
-                kq = WORKLOADS[wname]["k"]
-                rcl, ix3, _, _, _ = run_workload(env, wname, shards, 0, 2, 1, exchange=False, recall=True, kind_override=2,
-                                                 window_override=win[0] if win else None)
-                ix3.close()
-                del ix3
-                torch.cuda.empty_cache()
-                rec10 = {"top_k": kq,
-                         "iid_rows": {"corrected_key": r.get(f"recall_at_{kq}"), "reference_key": r.get(f"recall_at_{kq}_reference_key"),
-                                      "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")},
-                         "clustered_rows": {"corrected_key": rcl.get(f"recall_at_{kq}"), "reference_key": rcl.get(f"recall_at_{kq}_reference_key"),
-                                            "planted_neighbour_hit_rate": rcl.get("planted_neighbour_hit_rate"),
-                                            "queries_per_s_this_gpu": rcl["qps"]},
-                         "against": "GPU brute force over this GPU's stored rows" + ((" (one shard of %d: over the sampled queries planted in this "
-                                                                                       "shard -- %s)" % (shards, rcl.get("recall_note"))) if shards > 1 else ""),
-                         "note": "iid rows in 768-d: every non-planted neighbour is a random row, recall@k ~ rows scanned / rows for ANY index; "
-                                 "the literal key returns the LEAST similar candidates, so its recall is ~0 by construction"}
+                later.append((key, wname, shards, win, r if in_place else None))
             pmc_traffic(args, wname, shards, r["roofline"])
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
@@ -1132,26 +1124,57 @@ def main():
                           "stage_ms_per_batch": r["stage_ms_per_batch"], "host_loop": r["host_loop"], "visits_per_batch": r["visits_per_batch"],
                           "rows_scored_per_batch": r["rows_scored_per_batch"], "latency_ms": r.get("latency_ms"),
                           "host_buffers_qps": r.get("host_buffers_qps"), "host_buffers": r.get("host_buffers"),
-                          "half_width_scan": r.get("half_width_scan")}
-            if rec10:
-                other[key]["recall_at_10"] = rec10
+                          "half_width_scan": r.get("half_width_scan"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")}
+        # ---- the recall runs (torch brute force) ----
+        for key, wname, shards, win, r_iid in later:
+            # BASELINE.json's metric is "queries/sec + recall@10" on the 768-d cosine top-10 shape: recall against GPU brute force under
+            # BOTH keys -- the corrected one (cosine distance) and the reference's literal one (distance.rs:23-25 sorts by similarity:
+            # ~0 by construction) -- on the bench's iid rows (where only the planted neighbour can be found) and on
+            # clustered rows (128 consecutive rows share a centre: informative), same shape, same index options
+            kq = WORKLOADS[wname]["k"]
+            runs = {}
+            for tag, kd in (("iid", None), ("clustered", 2)):
+                if tag == "iid" and r_iid is not None:
+                    runs[tag] = r_iid
+                    continue
+                rr, ix3, _, _, _ = run_workload(env, wname, shards, 0, 2, 1, exchange=False, recall=True, kind_override=kd,
+                                                window_override=win[0] if win else None)
+                ix3.close()
+                del ix3
+                torch.cuda.empty_cache()
+                runs[tag] = rr
+            r, rcl = runs["iid"], runs["clustered"]
+            other[key]["recall_at_10"] = {
+                "top_k": kq,
+                "iid_rows": {"corrected_key": r.get(f"recall_at_{kq}"), "reference_key": r.get(f"recall_at_{kq}_reference_key"),
+                             "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate")},
+                "clustered_rows": {"corrected_key": rcl.get(f"recall_at_{kq}"), "reference_key": rcl.get(f"recall_at_{kq}_reference_key"),
+                                   "planted_neighbour_hit_rate": rcl.get("planted_neighbour_hit_rate"),
+                                   "queries_per_s_this_gpu": rcl["qps"]},
+                "against": "GPU brute force over this GPU's stored rows" + ((" (one shard of %d: over the sampled queries planted in this "
+                                                                              "shard -- %s)" % (shards, rcl.get("recall_note"))) if shards > 1 else ""),
+                "note": "iid rows in 768-d: every non-planted neighbour is a random row, recall@k ~ rows scanned / rows for ANY index; "
+                        "the literal key returns the LEAST similar candidates, so its recall is ~0 by construction"}
         if not only or "recall_clustered" in only:
-            # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative
-            r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=2)
-            ix2.close()
-            other["recall_clustered"] = {"workload": "cfg3 shape, clustered rows", "queries_per_s_this_gpu": r["qps"],
-                                         "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate"),
-                                         "half_width_scan": r.get("half_width_scan"), "roofline": {kk: r["roofline"].get(kk) for kk in ("kernel", "launch_ms", "frac")}}
-            # ... and the same clusters with their rows scattered over the table (inserted in arbitrary order): what the scan's tree-0 row order is for
-            ix2.close()
-            del ix2
-            torch.cuda.empty_cache()
-            r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, 5, 2, exchange=False, recall=True, kind_override=3)
-            ix2.close()
-            other["recall_clustered_shuffled"] = {"workload": "cfg3 shape, clustered rows scattered over the table", "queries_per_s_this_gpu": r["qps"],
-                                                  "recall_at_100": r.get("recall_at_100"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate"),
-                                                  "half_width_scan": r.get("half_width_scan"),
-                                                  "roofline": {kk: r["roofline"].get(kk) for kk in ("kernel", "launch_ms", "frac")}}
+            # clustered rows (128 consecutive rows share a centre), where recall@k against brute force is informative; then the same clusters with
+            # their rows scattered over the table (rows inserted in arbitrary order: what the scan's measured row order is for); then the bench
+            # line's own iid rows (whose recall run was put off until here)
+            for okey, kd, what, st_ in (("recall_clustered", 2, "cfg3 shape, clustered rows", 12),
+                                        ("recall_clustered_shuffled", 3, "cfg3 shape, clustered rows scattered over the table", 12),
+                                        ("recall_iid", None, "cfg3 (the bench line's rows)", 2)):
+                if okey == "recall_iid" and main_recall != "planted":
+                    continue
+                r, ix2, _, _, _ = run_workload(env, "cfg3", 1, 0, st_, 2, exchange=False, recall=True, kind_override=kd)
+                ix2.close()
+                del ix2
+                torch.cuda.empty_cache()
+                other[okey] = {"workload": what, "queries_per_s_this_gpu": r["qps"], "steps": st_,
+                               "recall_at_100": r.get(f"recall_at_{wl['k']}"), "planted_neighbour_hit_rate": r.get("planted_neighbour_hit_rate"),
+                               "half_width_scan": r.get("half_width_scan"), "roofline": {kk: r["roofline"].get(kk) for kk in ("kernel", "launch_ms", "frac")}}
+            ri = other.get("recall_iid")
+            if ri:  # the bench line's own recall figures
+                res[f"recall_at_{wl['k']}"] = ri["recall_at_100"]
+                res[f"recall_at_{wl['k']}_reference_key"] = ri["recall_at_100"]
 
     if env.rank == 0:
         k = wl["k"]

@@ -2638,7 +2638,24 @@ extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k,
             }
         }
         // the head of the queue and everything behind it that can share its batch (same top_k, metric, mode; arrival order kept)
+        // (nothing between taking requests off the queue and handing the lead on may throw across the extern "C" boundary or leave
+        // `cleader` set with nobody leading: the list's room is reserved BEFORE anything is taken, and a round that throws fails its requests)
         std::vector<zh_index::CombineReq *> grp;
+        try {
+            grp.reserve(ix->cpend.size());
+        } catch (...) {  // no memory to even list the round: my own request fails, the lead goes to whoever heads the queue without me
+            for (auto it = ix->cpend.begin(); it != ix->cpend.end(); ++it)
+                if (*it == &me) { ix->cpend.erase(it); break; }
+            me.rc = ZH_ENOMEM;
+            if (ix->cpend.empty()) ix->cleader = false;
+            else {
+                zh_index::CombineReq *nx = ix->cpend.front();
+                std::lock_guard<std::mutex> l(nx->m);
+                nx->lead = true;
+                nx->cv.notify_one();
+            }
+            break;
+        }
         const zh_index::CombineReq *head = ix->cpend.front();  // (never empty: the leader's own request is in it until served)
         size_t total = 0;
         for (auto it = ix->cpend.begin(); it != ix->cpend.end();) {
@@ -2651,7 +2668,11 @@ extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k,
                 ++it;
         }
         lk.unlock();
-        run_group(ix, ix->lanes[0], grp);
+        try {
+            run_group(ix, ix->lanes[0], grp);
+        } catch (...) {  // (bad_alloc in a message copy or a host vector: the round's requests fail, the queue lives on)
+            for (auto *r : grp) r->rc = ZH_ENOMEM;
+        }
         bool mine = false;
         for (auto *r : grp) {
             if (r == &me) { mine = true; continue; }
@@ -2672,7 +2693,7 @@ extern "C" int zh_search_batch(zh_index *ix, const float *q, size_t b, size_t k,
         }
         break;
     }
-    if (me.rc) return fail(me.rc, "%s", me.err.c_str());
+    if (me.rc) return fail(me.rc, "%s", me.err.empty() ? "zh_search_batch: out of host memory" : me.err.c_str());
     return ZH_OK;
 }
 

@@ -474,26 +474,28 @@ void scan_approx_kernel(const float *__restrict__ X, const uint4 *__restrict__ Q
     flush();
 }
 
-// ---- the table scan on the matrix cores (round 4, second half; zh_set_sweep_mode 5 -- measurement, not the default) ----
-// The VALU scan above spends 36 vector instructions per pair (profiles/r04_pmc_scan_mix.txt): a 32-lane fma column, its reduce, its
-// record and its stash.  Here a wave's 16 stored rows are the A operand of v_mfma_f32_16x16x32_f16 (converted ONCE per window to
-// fp16, power-of-two scaled per row, held in registers for all of the wave's pairs) and SIXTEEN pairs of the wave's list are the 16
-// columns of B; D / 32 MFMAs produce the 16 x 16 products of which the 16 wanted ones (column c wants row rec.x) are picked from the
-// accumulators: no reduce, no per-pair arithmetic at all.  15 of 16 products are waste; the matrix pipe has forty times the rate this
-// needs (16 cycles per MFMA and SIMD, D / 32 of them per 16 pairs).
-// RESULT (profiles/r04_ab_scan_mfma.txt, r04_pmc_scan_mfma.txt): 40 % of the VALU kernel's vector instructions, a fifth of its scalar
-// ones -- and the same time per launch (4.55-4.75 against 4.4-4.55 ms at cfg3).  Both kernels run at the rate the L2s answer a CU's
-// line requests (0.19-0.22 lines per clock and CU; 15.6-16 TB/s of L2 requests against the 16.8-18.8 TB/s the guide measures for
-// L2-served gathers): a pair's 2 d bytes of query must come from L2 whatever multiplies them.  Rounding the ROWS as well widens the
-// intervals (the literal cosine key scores twice the rows exactly), so the VALU kernel stays the default.
+// ---- the table scan on the matrix cores (round 4, second half; reworked in round 5) -- THE DEFAULT half-width scan with up to 16 trees at
+// d = 256 / 384 / 512 / 768 / 1024 (zh_api.hip mfma_wanted; zh_set_sweep_mode(5) / ZH_NO_MFMA keep the VALU kernel above, which needs no copy of
+// the rows) ----
+// The VALU scan spends 36 vector instructions per pair (profiles/r04_pmc_scan_mix.txt): a 32-lane fma column, its reduce, its record and its
+// stash.  Here a wave's 16 stored rows are the A operand of v_mfma_f32_16x16x32_f16, loaded from the index's fp16 copy of the rows
+// (row_half_kernel: power-of-two scaled per row, tiles of 16 rows in the operand's own order -- + 2 d + 8 bytes of device memory per stored
+// row, +50 % of the f32 table) and held in registers for all of the wave's pairs; the columns of B are queries.  Round 4: sixteen PAIRS of the
+// wave's list were the 16 columns, 15 of 16 products waste, every pair its own d / 64 lines of query from L2 -- 3.4-3.5 ms per cfg3 launch
+// against 4.4-4.55 for the VALU kernel (profiles/r04_ab_scan_mfma.txt), at the rate the L2s answer a CU's line requests (16.7 TB/s of
+// requests).  Round 5: a column is a DISTINCT QUERY of the wave's pairs (the column pass below) and the scan's view of the rows is kept in the
+// order that lets 16 neighbours share the most leaves (zh_order.hip): 0.89 columns per pair on iid rows, 0.61 on clustered rows whose ids are
+// scattered, 0.40 on rows inserted cluster by cluster (profiles/r05_ab_row_order.txt): 3.4 / 3.0-3.1 / 2.5 ms per launch.
+// Rounding the ROWS as well widens the intervals (the literal cosine key scores twice the rows exactly: 879 against 395 per query on a cfg4
+// shard) -- paid back by the scan.
 // k order: both operands use the SAME map (step s, k-group h, element j -> stored element 32 s + 4 h + (j & 3) + 16 (j >> 2)), which is
-// all a dot product needs: a lane's eight row elements are two 16-byte loads of the f32 row, its eight query halves ONE 16-byte
-// load of qhalf_kernel<16>'s layout.
+// all a dot product needs: a lane's eight query halves are ONE 16-byte load of qhalf_kernel<16>'s layout.
 // What changes for the intervals: the row is rounded too.  |x - xh / sigma_x| <= rho |x| with rho MEASURED over the stored rows
-// (row_scale_kernel: the largest relative rounding error of any usable row, ~0.3 * 2^-11 on generic data, never above 2^-11), and the
+// (row_half_kernel: the largest relative rounding error of any usable row, ~0.3 * 2^-11 on generic data, never above 2^-11), and the
 // accumulation happens inside the MFMA in an order the ISA does not specify: four accumulators, each the target of D / 128 MFMAs of
 // 32 products -- any order, any rounding of at most 2 u per operation gives |acc - sum| <= (33 D / 128 + 2) 2 u sum |xh_i h_i|
-// (zh_approx_bound's `ops`).  Rows whose scale is out of range (or not finite) hand every pair the interval (-inf, +inf).
+// (zh_approx_bound's `ops`; MEASURED on the device, tests/test_gpu_intervals.py: <= 9.2 u where 400-532 u are assumed).  Rows whose scale is
+// out of range (or not finite) hand every pair the interval (-inf, +inf).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
