@@ -1081,7 +1081,8 @@ def main():
     res, ix, group, wl, M_shard = run_workload(env, name, S, env.rank if not emu else 0, args.steps, args.warmup, exchange=S > 1,
                                                recall=main_recall, M_override=args.max_node_size,
                                                rows_override=args.rows, batch_override=args.batch, kind_override=kind)
-    pmc_traffic(args, name, S, res["roofline"])
+    if args.data == "iid":  # (the committed counters are those of the iid command)
+        pmc_traffic(args, name, S, res["roofline"])
     cpu = None
     if env.rank == 0 and S == 1 and args.cpu_seconds > 0:
         cpu = cpu_baselines(env, ix, wl, M_shard, args.cpu_seconds)

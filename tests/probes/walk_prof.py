@@ -71,6 +71,7 @@ for i, nm in enumerate(names):
 print("  cycles per block load %.0f; per upper step %.0f; per flush(16 visits) %.0f; DFS cycles per (inner+visit+pop) %.1f" % (
     p[:, 2].sum() / p[:, 6].sum(), p[:, 3].sum() / max(p[:, 7].sum(), 1), p[:, 4].sum() / (p[:, 11].sum() / 16),
     p[:, 5].sum() / (p[:, 8].sum() + p[:, 11].sum() + p[:, 9].sum())))
+print("  flagged signs resolved at block entry (inner-node blocks): per pair mean %.1f" % p[:, 14].mean())
 hw = buf[:P, 13]
 cu = (hw >> 8) & 0xF
 sh = (hw >> 12) & 0x1

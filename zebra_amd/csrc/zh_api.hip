@@ -205,6 +205,8 @@ struct zh_index {
     DevBuf blk_recs, blk_upper, blk_roots;
     uint32_t n_blocks = 0, n_upper = 0;
     bool blocks_valid = false;
+    bool blocks_inner = false;  // the view holds blocks of INNER nodes only (round 5; ZhBlocksDev::inner_only)
+    size_t blk_recs_b = 0;      // ... whose records' second halves start at this index of blk_recs
     std::mutex blk_mu;
     // row -> (leaf, position) per tree for the table-scan sweep (zh_launch_row_leaf): built on first use, dropped with the trees
     DevBuf row_leaf;
@@ -1256,7 +1258,119 @@ extern "C" int zh_stats_reset(zh_index *ix) {
 // Blocked view of the forest (zh_internal.h, ZhBlocksDev): every maximal subtree of at most ZH_BLOCK_NODES nodes becomes
 // one block with its nodes in pre-order; the nodes above keep pointer records whose child refs say "upper node" or
 // "block".  Host pass over the node mirrors (iterative: trees may be 60 levels deep), then four uploads.
+// Round 5: blocks of INNER nodes only.  A block of the round-2 view spends half of its 64 records on leaves; here a block is a maximal subtree of at
+// most ZH_BLOCK_INNER inner nodes, one 32-byte record per inner node in pre-order -- {plane, code of the left child | code of the right child << 8 |
+// inner nodes of the block << 16 (root record), left leaf: offset into leaf_ids, length} {left leaf: node id, right leaf: offset, length, node id} --
+// and its leaves live in their parent's record: a child code is the child's record (0 .. 62) or 0x80 | side << 6 | the parent's record for a leaf.
+// Twice the tree nodes per block: half the blocks, half the upper nodes, and the walk's dependent round trips with them (1M x 384 at the
+// reference's default options: 346k blocks / 346k upper nodes -> see tests/probes/refdefault_shape.py).  A leaf hanging directly off an upper node
+// (or a tree that is one leaf) is a block of zero inner nodes: record {-1, 0, offset, length} {node id, 0, 0, 0}.
+static int build_blocks_inner(zh_index *ix) {
+    const size_t nn = ix->h_plane.size();
+    const uint32_t T = (uint32_t)ix->h_roots.size();
+    std::vector<uint32_t> isize(nn, 0), order, st;
+    order.reserve(nn);
+    for (uint32_t t = 0; t < T; t++) {  // pre-order of every tree; inner-node counts of the subtrees in a reverse pass
+        const size_t o0 = order.size();
+        st.assign(1, ix->h_roots[t]);
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            order.push_back(n);
+            if (ix->h_plane[n] >= 0) { st.push_back((uint32_t)ix->h_right[n]); st.push_back((uint32_t)ix->h_left[n]); }
+        }
+        for (size_t i = order.size(); i-- > o0;) {
+            const uint32_t n = order[i];
+            isize[n] = ix->h_plane[n] >= 0 ? 1 + isize[(uint32_t)ix->h_left[n]] + isize[(uint32_t)ix->h_right[n]] : 0;
+        }
+    }
+    std::vector<int4> recs, recsB, upper;  // recs / recsB: the first / second int4 of every inner node's record (two arrays: a wave's two loads of a
+                                           // block are 1 KiB contiguous each -- interleaved 32-byte records made a block load 3404 cycles against 1795)
+    std::vector<int2> roots(std::max<uint32_t>(T, 1), make_int2(0, 0));
+    recs.reserve(nn / 2 + ZH_BLOCK_NODES);
+    recsB.reserve(nn / 2 + ZH_BLOCK_NODES);
+    std::vector<uint32_t> nodes;
+    uint32_t n_blocks = 0;
+    auto emit_block = [&](uint32_t root) -> int32_t {  // the subtree's INNER nodes in pre-order; a ref is -(first 32-byte record + 1)
+        const size_t base = recs.size();
+        n_blocks++;
+        if (ix->h_plane[root] < 0) {  // a leaf by itself
+            recs.push_back(make_int4(-1, 0, ix->h_left[root], ix->h_right[root]));
+            recsB.push_back(make_int4((int)root, 0, 0, 0));
+            return -(int32_t)base - 1;
+        }
+        nodes.clear();
+        st.assign(1, root);
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            nodes.push_back(n);
+            const uint32_t l = (uint32_t)ix->h_left[n], r = (uint32_t)ix->h_right[n];
+            if (ix->h_plane[r] >= 0) st.push_back(r);
+            if (ix->h_plane[l] >= 0) st.push_back(l);
+        }
+        // inner pre-order: the left child (when inner) is i + 1, the right child i + 1 + (inner nodes of the left subtree)
+        for (uint32_t i = 0; i < nodes.size(); i++) {
+            const uint32_t n = nodes[i], l = (uint32_t)ix->h_left[n], r = (uint32_t)ix->h_right[n];
+            const bool li = ix->h_plane[l] >= 0, ri = ix->h_plane[r] >= 0;
+            const uint32_t cl = li ? i + 1 : (0x80u | i), cr = ri ? i + 1 + isize[l] : (0x80u | 0x40u | i);
+            const uint32_t word = cl | (cr << 8) | (i == 0 ? (uint32_t)nodes.size() << 16 : 0u);
+            recs.push_back(make_int4(ix->h_plane[n], (int)word, li ? 0 : ix->h_left[l], li ? 0 : ix->h_right[l]));
+            recsB.push_back(make_int4(li ? 0 : (int)l, ri ? 0 : ix->h_left[r], ri ? 0 : ix->h_right[r], ri ? 0 : (int)r));
+        }
+        return -(int32_t)base - 1;
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> todo;  // (node, its upper id)
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t rt = ix->h_roots[t];
+        if (isize[rt] <= ZH_BLOCK_INNER) { roots[t] = make_int2(emit_block(rt), 0); continue; }
+        roots[t] = make_int2((int32_t)(upper.size() / 2), ix->h_plane[rt]);
+        upper.push_back(make_int4(0, 0, 0, 0)); upper.push_back(make_int4(0, 0, 0, 0));
+        todo.assign(1, {rt, (uint32_t)(upper.size() / 2 - 1)});
+        while (!todo.empty()) {
+            const auto [n, uid] = todo.back(); todo.pop_back();
+            const uint32_t ch[2] = {(uint32_t)ix->h_left[n], (uint32_t)ix->h_right[n]};
+            int32_t ref[2], cpl[2];
+            for (int e = 0; e < 2; e++) {
+                if (isize[ch[e]] <= ZH_BLOCK_INNER) { ref[e] = emit_block(ch[e]); cpl[e] = 0; }
+                else {
+                    ref[e] = (int32_t)(upper.size() / 2); cpl[e] = ix->h_plane[ch[e]];
+                    upper.push_back(make_int4(0, 0, 0, 0)); upper.push_back(make_int4(0, 0, 0, 0));
+                    todo.push_back({ch[e], (uint32_t)ref[e]});
+                }
+            }
+            upper[2 * (size_t)uid] = make_int4(ix->h_plane[n], ref[0], ref[1], 0);
+            upper[2 * (size_t)uid + 1] = make_int4(cpl[0], cpl[1], 0, 0);
+        }
+    }
+    if (recs.size() > 0x7FFFFFF0ull || upper.size() > 0x7FFFFFF0ull) return fail(ZH_ELIMIT, "forest too large for the blocked view");
+    recs.resize(recs.size() + ZH_BLOCK_NODES, make_int4(-1, 0, 0, 0));  // a wave always reads 64 records
+    recsB.resize(recs.size(), make_int4(0, 0, 0, 0));
+    const size_t n_inner_recs = recs.size();
+    recs.insert(recs.end(), recsB.begin(), recsB.end());  // one buffer: [first halves][second halves]
+    std::vector<int4>().swap(recsB);
+    if (upper.empty()) upper.assign(2, make_int4(0, 0, 0, 0));
+    int rc;
+    if ((rc = ix->blk_recs.ensure(recs.size() * sizeof(int4)))) return rc;
+    if ((rc = ix->blk_upper.ensure(upper.size() * sizeof(int4)))) return rc;
+    if ((rc = ix->blk_roots.ensure(roots.size() * sizeof(int2)))) return rc;
+    HIPCHK(hipMemcpy(ix->blk_recs.p, recs.data(), recs.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->blk_upper.p, upper.data(), upper.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->blk_roots.p, roots.data(), roots.size() * sizeof(int2), hipMemcpyHostToDevice));
+    ix->n_blocks = n_blocks;
+    ix->n_upper = (uint32_t)(upper.size() / 2);
+    ix->blocks_valid = true;
+    ix->blocks_inner = true;
+    ix->blk_recs_b = n_inner_recs;
+    if (getenv("ZH_DEBUG_BLOCKS")) fprintf(stderr, "zebra_hip: blocked view (inner-node blocks): %u blocks, %u upper nodes, %zu inner records\n", n_blocks, ix->n_upper, n_inner_recs);
+    return ZH_OK;
+}
+
 static int build_blocks(zh_index *ix) {
+    // ZH_WALK_BLOCKS=inner (read when a forest's view is built): the round-5 blocks of inner nodes only.  Measured and NOT the default: half the
+    // blocks and upper nodes, 27 % fewer block entries and 31 % fewer upper steps per pair -- and the same 8.5 ms per batch (DESIGN.md s9,
+    // profiles/r05_walk_prof.txt): the walk's time is its instruction stream and the exact sign chains, not its round trips.
+    const char *bv = getenv("ZH_WALK_BLOCKS");
+    if (bv && bv[0] == 'i') return build_blocks_inner(ix);
+    ix->blocks_inner = false;
     const size_t nn = ix->h_plane.size();
     const uint32_t T = (uint32_t)ix->h_roots.size();
     std::vector<uint32_t> size(nn, 0), order;
@@ -1340,6 +1454,7 @@ static int build_blocks(zh_index *ix) {
     ix->n_blocks = n_blocks;
     ix->n_upper = (uint32_t)(upper.size() / 2);
     ix->blocks_valid = true;
+    if (getenv("ZH_DEBUG_BLOCKS")) fprintf(stderr, "zebra_hip: blocked view (round-2 blocks): %u blocks, %u upper nodes\n", n_blocks, ix->n_upper);
     return ZH_OK;
 }
 
@@ -1833,7 +1948,8 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     if (blocked) {
         ZhBlocksDev bd;
         bd.recs = ix->blk_recs.as<int4>(); bd.upper = ix->blk_upper.as<int4>(); bd.root = ix->blk_roots.as<int2>();
-        bd.n_blocks = ix->n_blocks; bd.n_upper = ix->n_upper;
+        bd.n_blocks = ix->n_blocks; bd.n_upper = ix->n_upper; bd.inner_only = ix->blocks_inner ? 1u : 0u;
+        bd.recs_b = ix->blocks_inner ? bd.recs + ix->blk_recs_b : nullptr;
         HIPCHK(zh_launch_walk_blocked(f, bd, (uint32_t)B, (int32_t)k, c->wBits.as<uint32_t>(), c->wpq, c->wCounts.as<ZhPairCounts>(),
                                       c->wInline.as<ZhVisit>(), leaf_count, walk_log(c), c->lazy_fix ? c->wUnc.as<uint32_t>() : nullptr, dQ, d, s));
     } else

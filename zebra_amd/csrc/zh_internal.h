@@ -73,11 +73,16 @@ struct ZhWalkLog {
 // -- a child's sign can be requested together with its record.  A ref is >= 0 for an upper node and -(offset of the
 // block's first record + 1) for a block: no directory lookup between a ref and its data.
 #define ZH_BLOCK_NODES 64
+// Round 5 (inner_only): a block = a maximal subtree of at most ZH_BLOCK_INNER INNER nodes, one 32-byte record (two int4) per inner node in
+// pre-order; its leaves live in their parent's record (zh_api.hip build_blocks_inner); a ref is -(index of the block's first 32-byte record + 1).
+#define ZH_BLOCK_INNER 63
 struct ZhBlocksDev {
     const int4 *recs;           // all blocks' node records (+ ZH_BLOCK_NODES records of padding: a wave always loads 64)
     const int4 *upper;          // 2 records per upper node
     const int2 *root;           // per tree: {ref, plane of the root when it is an upper node}
     uint32_t n_blocks, n_upper;
+    uint32_t inner_only;        // 1: the round-5 records
+    const int4 *recs_b;         // ... their second halves (same indices as recs)
 };
 
 struct ZhForestDev {

@@ -880,13 +880,252 @@ __global__ __launch_bounds__(64) void walk_blocked_kernel(ZhForestDev f, ZhBlock
     })
 }
 
+// ---- the same walk over blocks of INNER nodes (round 5): twice the tree per block entry, half the upper nodes ----
+__global__ __launch_bounds__(64) void walk_blocked_inner_kernel(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n0,
+                                                           const uint32_t *__restrict__ bits, uint32_t wpq,
+                                                           ZhPairCounts *__restrict__ counts, ZhVisit *__restrict__ inl,
+                                                           uint32_t *__restrict__ leafCount, ZhWalkLog wlog,
+                                                           const uint32_t *__restrict__ unc, const float *__restrict__ Q, uint32_t d) {
+    // unc != null: the row-score hash left its uncertain signs flagged instead of fixing them (zh_score.hip, "lazy"): a flagged sign
+    // is recomputed here with point_is_above's own arithmetic (plane_above_wave) when -- and only when -- the walk steps on its node
+    __shared__ int4 ust[WALK_STACK];  // upper-level stack {child ref, n, the child's plane when it is an upper node}
+    static_assert(ZH_BLOCK_INNER + 1 + WALK_FLUSH <= WALK_RING, "a block's visits and the pending ones fit the ring");
+    __shared__ uint4 vb_a[WALK_RING + 1];
+    __shared__ uint32_t vb_r[WALK_RING + 1], vb_c[WALK_RING + 1];
+    const uint32_t T = f.n_trees, lane = threadIdx.x;
+    const uint64_t pair = blockIdx.x;
+    const uint32_t b = (uint32_t)(pair / T), t = (uint32_t)(pair % T);
+    const uint32_t *__restrict__ qbits = bits + (size_t)b * wpq;
+    const uint32_t *__restrict__ qunc = unc ? unc + (size_t)b * wpq : nullptr;
+    if (n0 <= 0) {  // lsh.rs:306: the first leaf takes nothing and nothing is ever < 0: no visit
+        if (lane == 0) { ZhPairCounts c; c.visits = 0; c.rows = 0; c.takes = 0; c.pad = 0; counts[pair] = c; }
+        return;
+    }
+    // the pair's running totals: wave-uniform, kept in VGPRs (see in_vgpr)
+    uint32_t v_nv = in_vgpr(0), v_nrows = in_vgpr(0), v_ntakes = in_vgpr(0);
+    uint32_t flushed = 0;
+    uint32_t log_chunk = 0xFFFFFFFFu;
+    int32_t log_cn = -1;
+    bool log_ok = true;
+    WP(uint64_t p_t0 = clock64(); uint64_t p_w0 = wall_clock64(); uint64_t p_load = 0, p_upper = 0, p_flush = 0, p_dfs = 0;
+       uint32_t p_blocks = 0, p_uppers = 0, p_inner = 0, p_pops = 0, p_upops = 0, p_flags = 0;)
+    auto flush = [&](uint32_t cnt) {  // as walk_kernel's count-pass flush: the ring's oldest `cnt` (<= WALK_FLUSH) visits leave, one lane each
+        WP(const uint64_t p_f0 = clock64();)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t first = flushed, vi = first + lane, upto = first + cnt;
+        const bool mine = lane < cnt;
+        const uint32_t slot = mine ? (vi & (WALK_RING - 1)) : WALK_RING;
+        const uint4 va = vb_a[slot];
+        ZhVisit v;
+        v.b = b; v.leaf_off = va.y; v.len = va.z; v.take = va.w; v.node = va.x; v.pad = 0;
+        v.row_off = vb_r[slot]; v.cand_off = vb_c[slot];
+        if (mine) {
+            if (leafCount) atomicAdd(&leafCount[v.node], 1u);  // (a prefiltered batch forms no leaf groups)
+            if (vi < ZH_INLINE_VISITS) inl[pair * ZH_INLINE_VISITS + vi] = v;
+        }
+        if (upto > ZH_INLINE_VISITS && log_ok) {
+            constexpr uint32_t PER = ZH_LOG_CHUNK - 1;
+            static_assert(WALK_FLUSH < PER, "a flush may open at most one log chunk");
+            const int32_t c1 = (int32_t)((upto - 1 - ZH_INLINE_VISITS) / PER);
+            uint32_t newc = 0xFFFFFFFFu;
+            if (c1 > log_cn) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&wlog.ctl->next_chunk, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= wlog.capacity) {
+                    if (lane == 0) wlog.ctl->overflow = 1u;
+                    log_ok = false;
+                } else {
+                    newc = c;
+                    if (lane == 0) {
+                        if (log_cn < 0) wlog.head[pair] = c;
+                        else wlog.pool[(size_t)log_chunk * ZH_LOG_CHUNK].x = c;
+                    }
+                }
+            }
+            if (log_ok) {
+                if (mine && vi >= ZH_INLINE_VISITS) {
+                    const uint32_t li = vi - ZH_INLINE_VISITS;
+                    const uint32_t id = (int32_t)(li / PER) == log_cn ? log_chunk : newc;
+                    wlog.pool[(size_t)id * ZH_LOG_CHUNK + 1 + li % PER] = wlog.leaf_entries ? make_uint2(v.leaf_off, v.take | (v.len << 16)) : make_uint2(v.node, v.take);
+                }
+                if (newc != 0xFFFFFFFFu) { log_chunk = newc; log_cn = c1; }
+            }
+        }
+        flushed = upto;
+        __builtin_amdgcn_wave_barrier();
+        WP(p_flush += clock64() - p_f0;)
+    };
+    const int2 root = blk.root[t];
+    int32_t ref = __builtin_amdgcn_readfirstlane(root.x), pl = __builtin_amdgcn_readfirstlane(root.y);
+    int32_t n = n0;
+    int usp = 0;
+    for (;;) {
+        if (ref >= 0) {  // an upper (inner) node: its records and its sign word are requested together
+            WP(const uint64_t p_u0 = clock64(); p_uppers++;)
+            // wave-uniform addresses: scalar loads (through the constant address space) -- the records arrive in SGPRs, no vector
+            // memory instruction, no v_readfirstlane per word
+            typedef const int32_t __attribute__((address_space(4))) *cptr_t;
+            const cptr_t up = (cptr_t)(uintptr_t)(blk.upper + 2 * (size_t)ref);
+            const int4 a = make_int4(up[0], up[1], up[2], up[3]), c2 = make_int4(up[4], up[5], up[6], up[7]);
+            const uint32_t word = (uint32_t)((cptr_t)(uintptr_t)qbits)[(uint32_t)pl >> 5];
+            const uint32_t uword = qunc ? (uint32_t)((cptr_t)(uintptr_t)qunc)[(uint32_t)pl >> 5] : 0u;
+            bool above = (word >> (pl & 31)) & 1;
+            if ((uword >> (pl & 31)) & 1)
+                above = plane_above_wave(f.planes + (size_t)pl * d, f.consts[pl], Q + (size_t)b * d, d, lane);
+            if (usp < WALK_STACK && lane == 0) ust[usp] = make_int4(above ? a.y : a.z, n, above ? c2.x : c2.y, 0);
+            usp++;
+            ref = above ? a.z : a.y;  // lsh.rs:335-338: above -> right is main
+            pl = above ? c2.y : c2.x;
+            WP(p_upper += clock64() - p_u0;)
+            continue;
+        }
+        // ---- a block of INNER nodes (round 5; ZhBlocksDev::inner_only): 32-byte records and signs into registers, then the DFS without memory ----
+        // Lane i holds inner node i of the block: {plane, codes, left leaf: offset, length} {left leaf: node, right leaf: offset, length, node}.  A child
+        // code is an inner node's lane (0 .. 62) or, with bit 7, a LEAF: bit 6 = which child, bits 5:0 = the parent's lane -- the leaf's numbers are
+        // read from its parent's registers and the parent's lane records the visit (a DFS meets a leaf once: one slot per side).  0xFF (lane 63,
+        // never a node) is where the stack's sentinel leads once the block is exhausted.  A block of zero inner nodes is a leaf by itself: its
+        // record has the layout of a left leaf of lane 0.
+        WP(const uint64_t p_l0 = clock64(); p_blocks++;)
+        const uint32_t s0 = (uint32_t)(-ref - 1);
+        int4 ra = blk.recs[(size_t)s0 + lane], rb = blk.recs_b[(size_t)s0 + lane];  // (padded: 64 records can always be read; two contiguous 1-KiB loads)
+        const uint32_t cnt = rl(ra.x, 0) >= 0 ? ((uint32_t)rl(ra.y, 0) >> 16) & 0x7Fu : 0u;
+        int sgn = 0;
+        uint32_t ub = 0;
+        if (lane < cnt) {
+            sgn = (int)((qbits[(uint32_t)ra.x >> 5] >> (ra.x & 31)) & 1u);
+            if (qunc) ub = (qunc[(uint32_t)ra.x >> 5] >> (ra.x & 31)) & 1u;
+        }
+        // A flagged sign (the row-score hash left it uncertain: one node in ~400, 0.16 per block) is recomputed HERE, with point_is_above's own
+        // arithmetic, for every flagged node of the block the walk enters -- not when the walk steps on it: the DFS below then has no flag to test
+        // (its loop is bound by the SIMD's scalar issue slot: every scalar instruction per step counts; ~4x the exact chains of the lazy scheme,
+        // < 1 % of a pair's cycles)
+#ifndef ZH_PROBE_NO_EAGER_FLAGS  // (timing probe only: results are wrong without it)
+        WP(p_flags += (uint32_t)__builtin_popcountll(__ballot(ub != 0));)
+        for (unsigned long long um = __ballot(ub != 0); um; um &= um - 1) {
+            const int j = __builtin_ctzll(um);
+            const int p_ = rl(ra.x, (uint32_t)j);
+            const bool ab = plane_above_wave(f.planes + (size_t)p_ * d, f.consts[p_], Q + (size_t)b * d, d, lane);
+            if ((int)lane == j) sgn = ab ? 1 : 0;
+        }
+#endif
+        // one word per inner node: main child's code | backup child's code << 8 (lsh.rs:335-338: above -> right is main)
+        uint32_t pk;
+        {
+            const uint32_t cl = (uint32_t)ra.y & 0xFFu, cr = ((uint32_t)ra.y >> 8) & 0xFFu;
+            pk = sgn ? (cr | (cl << 8)) : (cl | (cr << 8));
+        }
+        const uint32_t kL = lane | 0x80u, kR = lane | 0xC0u;  // the codes of this lane's left / right leaf child
+        WP(if (__builtin_amdgcn_readfirstlane((int)pk) == 12345) p_blocks++; const uint64_t p_d0 = clock64(); p_load += p_d0 - p_l0;
+           const uint64_t p_fl0 = p_flush;)
+        // the block's DFS stack: lane j holds entry j = backup child's code | n << 8; entry 0 is a sentinel no return value ever exhausts
+        uint32_t lstk = lane == 0 ? ((0x7FFFFFu << 8) | 0xFFu) : 0u;
+        uint32_t lsp = 1;
+        uint32_t vidxL = 0xFFFFFFFFu, vtkL = 0, vrowL = 0, vcandL = 0, vidxR = 0xFFFFFFFFu, vtkR = 0, vrowR = 0, vcandR = 0;
+        uint32_t n8 = in_vgpr_shl8((uint32_t)n);
+        int32_t ret = 0;
+        uint32_t c = 0x80u;  // (wave-uniform) the code of the node the walk stands on: a lone leaf has the layout of lane 0's left leaf
+        // from inner node `w` (its word) down the main children to a leaf's code: per inner node the perm, the stack write (compare + select), one
+        // scalar add, the bit test + branch and the v_readlane whose lane select is the word itself (the hardware uses bits 5:0)
+#define WALK_DESCEND()                                                                                                       \
+        for (;;) {                                                                                                           \
+            const uint32_t e_ = __builtin_amdgcn_perm(n8, w, 0x07060501u); /* byte 0 = the word's byte 1 (backup), bytes 1-3 = n */ \
+            lstk = lane == lsp ? e_ : lstk;                                                                                  \
+            lsp++;                                                                                                           \
+            WP(p_inner++;)                                                                                                   \
+            if (w & 0x80u) break;                                                                                            \
+            w = (uint32_t)rl((int)pk, w);                                                                                    \
+        }                                                                                                                    \
+        c = w & 0xFFu;
+        if (cnt) {
+            uint32_t w = (uint32_t)rl((int)pk, 0);
+            WALK_DESCEND();
+        }
+        while (c != 0xFFu) {  // one leaf per turn; 0xFF: through the sentinel -- the block is done and `ret` is its return value
+            // the leaf: child (c >> 6 & 1) of the inner node in lane c & 63; an empty one (lsh.rs:306 / 329: it returns 0) is stepped on, not a visit
+            const uint32_t lenl = (uint32_t)rl(ra.w, c), lenr = (uint32_t)rl(rb.z, c);  // (v_readlane takes bits 5:0 of the code)
+            const uint32_t len = (c & 0x40u) ? lenr : lenl;
+            const uint32_t take = len < (uint32_t)n ? len : (uint32_t)n;  // n >= 1 here (n0 >= 1; a backup is entered with nn - ret > 0)
+            ret = (int32_t)take;
+            const uint32_t cm = len ? c : 0xFFFFFFFFu;  // (an empty leaf matches no lane)
+            const bool meL = kL == cm, meR = kR == cm;
+            vidxL = meL ? v_nv : vidxL; vtkL = meL ? take : vtkL; vrowL = meL ? v_nrows : vrowL; vcandL = meL ? v_ntakes : vcandL;
+            vidxR = meR ? v_nv : vidxR; vtkR = meR ? take : vtkR; vrowR = meR ? v_nrows : vrowR; vcandR = meR ? v_ntakes : vcandR;
+            v_nv += in_vgpr(len) != 0u ? 1u : 0u; v_nrows += len; v_ntakes += take;
+            uint32_t e;
+            do {  // lsh.rs:341-343: the nearest pending backup whose n the return value has not used up
+                lsp--;
+                WP(p_pops++;)
+                e = (uint32_t)rl((int)lstk, lsp);
+            } while ((uint32_t)ret >= (e >> 8));
+            n = (int32_t)((e >> 8) - (uint32_t)ret);
+            n8 = in_vgpr_shl8((uint32_t)n);
+            c = e & 0xFFu;
+            if (!(c & 0x80u)) {  // the backup child is an inner node: down its main children
+                uint32_t w = (uint32_t)rl((int)pk, c);
+                WALK_DESCEND();
+            }
+        }
+#undef WALK_DESCEND
+        // the visited leaves' records join the ring (a lane without a visit on that side writes the spare slot: no branch), full groups leave the wave
+        {
+            const uint32_t sl = vidxL != 0xFFFFFFFFu ? (vidxL & (WALK_RING - 1)) : WALK_RING;
+            vb_a[sl] = make_uint4((uint32_t)rb.x, (uint32_t)ra.z, (uint32_t)ra.w, vtkL);
+            vb_r[sl] = vrowL; vb_c[sl] = vcandL;
+            __builtin_amdgcn_wave_barrier();  // (the spare slot is written by both sides' idle lanes: keep the two rounds apart)
+            const uint32_t sr = vidxR != 0xFFFFFFFFu ? (vidxR & (WALK_RING - 1)) : WALK_RING;
+            vb_a[sr] = make_uint4((uint32_t)rb.w, (uint32_t)rb.y, (uint32_t)rb.z, vtkR);
+            vb_r[sr] = vrowR; vb_c[sr] = vcandR;
+            const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_nv);
+            while (nv - flushed >= WALK_FLUSH) flush(WALK_FLUSH);
+        }
+        // the block returned `ret` to the upper walk
+        WP(p_dfs += clock64() - p_d0 - (p_flush - p_fl0); const uint64_t p_p0 = clock64();)
+        bool down = false;
+        __builtin_amdgcn_wave_barrier();
+        while (usp > 0) {
+            usp--;
+            WP(p_upops++;)
+            if (usp < WALK_STACK) {
+                const int4 e = ust[usp];
+                const int32_t nn = __builtin_amdgcn_readfirstlane(e.y);
+                if (ret < nn) {
+                    ref = __builtin_amdgcn_readfirstlane(e.x); pl = __builtin_amdgcn_readfirstlane(e.z); n = nn - ret;
+                    down = true;
+                    break;
+                }
+            }
+        }
+        WP(p_upper += clock64() - p_p0;)
+        if (!down) break;
+    }
+    const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_nv);
+    if (nv > flushed) flush(nv - flushed);
+    if (lane == 0) {
+        ZhPairCounts c;
+        c.visits = nv; c.rows = v_nrows; c.takes = v_ntakes; c.pad = 0;
+        counts[pair] = c;
+    }
+    WP(if (lane == 0 && pair < 8192) {
+        uint64_t *o = zh_walk_prof_buf + pair * 16;
+        o[0] = clock64() - p_t0; o[1] = wall_clock64() - p_w0; o[2] = p_load; o[3] = p_upper; o[4] = p_flush; o[5] = p_dfs;
+        o[6] = p_blocks; o[7] = p_uppers; o[8] = p_inner; o[9] = p_pops; o[10] = p_upops; o[11] = nv; o[12] = p_w0;
+        uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); o[13] = hw; o[14] = p_flags;
+    })
+}
+
 hipError_t zh_launch_walk_blocked(ZhForestDev f, ZhBlocksDev blk, uint32_t B, int32_t n, const uint32_t *dBits,
                                   uint32_t words_per_q, ZhPairCounts *dCounts, ZhVisit *dInline, uint32_t *dLeafCount,
                                   ZhWalkLog log, const uint32_t *dUnc, const float *dQ, uint32_t d, hipStream_t s) {
     const uint64_t pairs = (uint64_t)B * f.n_trees;
     if (!pairs) return hipSuccess;
-    hipLaunchKernelGGL(walk_blocked_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, blk, B, n, dBits, words_per_q, dCounts,
-                       dInline, dLeafCount, log, dUnc, dQ, d);
+    if (blk.inner_only)
+        hipLaunchKernelGGL(walk_blocked_inner_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, blk, B, n, dBits, words_per_q, dCounts,
+                           dInline, dLeafCount, log, dUnc, dQ, d);
+    else
+        hipLaunchKernelGGL(walk_blocked_kernel, dim3((uint32_t)pairs), dim3(64), 0, s, f, blk, B, n, dBits, words_per_q, dCounts,
+                           dInline, dLeafCount, log, dUnc, dQ, d);
     return hipGetLastError();
 }
 
