@@ -1559,8 +1559,10 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ X, uint3
 // a wave strides over the query's survivors with the query in registers): the reference's arithmetic at the rate HBM gives random rows; (3)
 // final_topk_kernel, a block per query: sort by (key, id), top_k (lsh.rs:557-564).  The survivors' keys live where the lists' lo / hi words were
 // (both arrays are dead once (1) has run; list_lo and list_hi are contiguous: B * capq u64 slots).
+// `only` (an index whose lists have 8192 slots runs BOTH instantiations over all queries): 1 = the queries whose list holds <= 4096 entries (this
+// instantiation sorts in 48 KB of LDS: three blocks per CU), 2 = the longer ones (96 KB: one block per CU), 0 = every query
 template <int LCAP>
-__global__ __launch_bounds__(256) void final_survivors_kernel(uint32_t B, uint32_t k, ZhApprox ap) {
+__global__ __launch_bounds__(256) void final_survivors_kernel(uint32_t B, uint32_t k, ZhApprox ap, uint32_t only) {
     __shared__ uint64_t sk[LCAP];  // id << 32 | sortable hi: equal ids end up side by side
     __shared__ uint32_t sl[LCAP];  // sortable lo; later: the survivors' ids
     __shared__ uint32_t hist[256], scan[256], s_u[8];
@@ -1570,6 +1572,7 @@ __global__ __launch_bounds__(256) void final_survivors_kernel(uint32_t B, uint32
     if (ap.ctl[1] & (1u | 4u | 8u)) return;
     uint32_t n = ap.qcount[b];
     if (n > ap.capq) n = ap.capq;
+    if ((only == 1 && n > 4096u) || (only == 2 && n <= 4096u)) return;  // (the other instantiation's query; block-uniform)
     if (n > (uint32_t)LCAP) n = LCAP;  // capq <= LCAP
     const size_t ob = (size_t)b * ap.capq;
     for (uint32_t i = tid; i < n; i += 256) {
@@ -1669,12 +1672,13 @@ __global__ __launch_bounds__(256) void final_exact_kernel(const float *__restric
 
 template <int LCAP>
 __global__ __launch_bounds__(256) void final_topk_kernel(uint32_t B, uint32_t k, uint64_t id_base, ZhApprox ap, uint64_t *__restrict__ out_ids,
-                                                          uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts) {
+                                                          uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts, uint32_t only) {
     __shared__ uint64_t sk[LCAP];
     __shared__ uint32_t sl[LCAP];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     if (ap.ctl[1] & (1u | 4u | 8u)) return;
     uint32_t ns = ap.qcount[b];
+    if ((only == 1 && ns > 4096u) || (only == 2 && ns <= 4096u)) return;  // (survivors: as final_survivors_kernel's `only`)
     if (ns > (uint32_t)LCAP) ns = LCAP;
     const size_t ob = (size_t)b * ap.capq;
     const uint64_t *__restrict__ skeys = reinterpret_cast<const uint64_t *>(ap.list_lo) + ob;
@@ -1721,8 +1725,12 @@ static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uin
 #define ZH_APX_EXACT(DD) \
     for (uint32_t b0 = 0; b0 < B; b0 += 65535u) /* (gridDim.y <= 65535) */ \
         hipLaunchKernelGGL((final_exact_kernel<DD, KIND>), dim3(SX, std::min(B - b0, 65535u)), dim3(256), 0, s, dX, d, dQ, dQQ, metric, mode, b0, ap)
-    if (ap.capq > 4096) hipLaunchKernelGGL((final_survivors_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, ap);
-    else hipLaunchKernelGGL((final_survivors_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, ap);
+    // 8192-slot lists (an index whose lists ran over once): most queries' lists still hold <= 4096 entries -- those sort in the 48-KB instantiation
+    // (three blocks per CU), only the longer ones in the 96-KB one (r05_scale64m_kernel_stats.csv: 4.4 ms per window with every query in the latter)
+    if (ap.capq > 4096) {
+        hipLaunchKernelGGL((final_survivors_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, ap, 1u);
+        hipLaunchKernelGGL((final_survivors_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, ap, 2u);
+    } else hipLaunchKernelGGL((final_survivors_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, ap, 0u);
     switch (d) {
     case 128: ZH_APX_EXACT(128); break;
     case 384: ZH_APX_EXACT(384); break;
@@ -1730,8 +1738,10 @@ static void launch_final_interval_k(const ZhVisit *dVisits, const float *dX, uin
     default: ZH_APX_EXACT(0); break;
     }
 #undef ZH_APX_EXACT
-    if (ap.capq > 4096) hipLaunchKernelGGL((final_topk_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts);
-    else hipLaunchKernelGGL((final_topk_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts);
+    if (ap.capq > 4096) {
+        hipLaunchKernelGGL((final_topk_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts, 1u);
+        hipLaunchKernelGGL((final_topk_kernel<8192>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts, 2u);
+    } else hipLaunchKernelGGL((final_topk_kernel<4096>), dim3(B), dim3(256), 0, s, B, k, id_base, ap, dOutIds, dOutKeys, dOutCounts, 0u);
 }
 
 hipError_t zh_launch_final_interval(const ZhVisit *dVisits, const float *dX, uint32_t d, const float *dQ, const float *dQQ, uint32_t B,
