@@ -587,6 +587,17 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
 #else
 #define ZH_GUARD(cond, bit) true
 #endif
+#ifdef ZH_SCAN_PROF  // tests/probes/scan_prof.py: where a wave of the matrix-core scan spends its cycles (never defined in the shipped build)
+__device__ unsigned long long zh_scan_prof_buf[16];  // sums over every 16th wave: [0] waves [1] phase 1 [2] list [3] column pass [4] first chunk's wait [5] tile loop [6] tiles [7] pairs [8] columns [9] total
+extern "C" __attribute__((visibility("default"))) int zh_debug_scan_prof(uint64_t *out, uint32_t words, int reset) {
+    static const unsigned long long zero[16] = {};
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(zh_scan_prof_buf), zero, sizeof(zero));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_scan_prof_buf), (size_t)words * 8);
+}
+#define SP(...) __VA_ARGS__
+#else
+#define SP(...)
+#endif
 template <int D>
 __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
                                                          const uint4 *__restrict__ Qh, const uint2 *__restrict__ rowLeaf, uint32_t T,
@@ -613,6 +624,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
     const uint64_t r0 = row_begin + wave * RW;
     if (r0 >= row_end) return;
+    SP(const uint64_t sp0 = clock64();)
     const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
     const uint32_t n_ent = nr * T;
     const uint2 *__restrict__ ent = rowLeaf + (size_t)r0 * T;
@@ -620,6 +632,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     uint64_t eK0[ZH_SCAN_NE];
     const uint32_t P = scan_phase1(lane, n_ent, ent, visitBits, nodeVisit, eGb, eWithin, eC, off, eB0, eK0);
     if (P == 0) return;
+    SP(const uint64_t sp1 = clock64();)
     uint64_t *list = pair_list[wid];
     const bool listed = P <= ZH_APX_CAP;
     auto pack = [](uint32_t rl, uint32_t b, uint64_t slot) { return slot | ((uint64_t)b << 36) | ((uint64_t)rl << 60); };
@@ -635,6 +648,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
             }
         }
     }
+    SP(__builtin_amdgcn_s_waitcnt(0); const uint64_t sp2 = clock64();)
     // ---- the wave's 16 rows: their fp16 copy, already in the A operand's order (row_half_kernel): D / 32 coalesced 1-KiB loads ----
     f16x8 A[NS];
     {
@@ -772,6 +786,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
         // the wave's distinct queries sixteen at a time; the next chunk of query lines is requested before the current one is multiplied,
         // across tile boundaries
         const uint32_t nt = (nd + 15) / 16;
+        SP(const uint64_t sp3 = clock64();)
         // what the sharing is worth (zh_stats_t::approx_columns / approx_column_pairs): every 64th wave reports -- same-address atomics from all
         // 200k waves of a launch serialise in one L2 channel (measured: 3.6 -> 5.5 ms per launch)
         if (colStats && lane == 0 && (wave & 63u) == 0u) { atomicAdd(&colStats[0], nd); atomicAdd(&colStats[1], P); }
@@ -779,6 +794,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
         uint32_t bA = col_b(0, g8), bB = col_b(0, 8 + g8);
         u32x4v ra[2 * CL], rb[2 * CL];
         issue(bA, bB, 0, ra);
+        SP(__builtin_amdgcn_s_waitcnt(0); const uint64_t sp4 = clock64();)
         f32x4v *al = acc_lds[wid];
         for (uint32_t t = 0; t < nt; t++) {
             f32x4v acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -810,6 +826,14 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
             }
             __builtin_amdgcn_wave_barrier();
         }
+        SP(if ((wave & 15u) == 0u && lane == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint64_t sp5 = clock64();
+            atomicAdd(&zh_scan_prof_buf[0], 1ull); atomicAdd(&zh_scan_prof_buf[1], sp1 - sp0); atomicAdd(&zh_scan_prof_buf[2], sp2 - sp1);
+            atomicAdd(&zh_scan_prof_buf[3], sp3 - sp2); atomicAdd(&zh_scan_prof_buf[4], sp4 - sp3); atomicAdd(&zh_scan_prof_buf[5], sp5 - sp4);
+            atomicAdd(&zh_scan_prof_buf[6], (unsigned long long)nt); atomicAdd(&zh_scan_prof_buf[7], (unsigned long long)P);
+            atomicAdd(&zh_scan_prof_buf[8], (unsigned long long)nd); atomicAdd(&zh_scan_prof_buf[9], sp5 - sp0);
+        })
     } else {
         // more pairs than the list holds (hot leaves): entry after entry, a leaf's visits sixteen at a time, records from the group array
 #pragma unroll
@@ -957,6 +981,7 @@ void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ 
     // set: once a tile is written to LDS its registers take the next tile's loads (across chunk boundaries, where the next chunk's rows
     // are known), which travel while this tile is multiplied.
     u32x4v R[4];
+    uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};  // the group record this lane's column last stored through: group, key_off[0..3] (low words; high nibbles | gsize << 16)
     auto issue_tile = [&](uint32_t ids, uint32_t n, uint32_t t) {  // flat rows 16 t .. 16 t + 15 of a chunk of n rows whose ids the lanes hold
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -991,6 +1016,20 @@ void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // this lane's column: flat row fr of the chunk, its group and where its results go.  The group's record is kept in registers and
+            // fetched again only when the group changes (a leaf is thousands of rows) -- BEFORE the next tile's rows are requested: loads return in
+            // order, and a fetch behind them (round 4: gsize and every key_off in the epilogue, each with its own wait) held every tile's stores
+            // until the NEXT tile's rows had arrived from HBM, then paid four more round trips
+            const uint32_t fr = 16 * t + c16;
+            const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
+            const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
+            if (rg != c_rg) {
+                const uint4 *gq = reinterpret_cast<const uint4 *>(groups + rg);
+                const uint4 g0 = gq[0], k01 = gq[2], k23 = gq[3];
+                c_rg = rg;
+                c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;  // (key slices are < 2^36: the four high nibbles and gsize share a word)
+                c_hi = (k01.y & 15u) | ((k01.w & 15u) << 4) | ((k23.y & 15u) << 8) | ((k23.w & 15u) << 12) | (g0.z << 16);
+            }
             if (t + 1 < ntile) issue_tile(my_id, cnt, t + 1);
             else if (fast) issue_tile(nxt_id, cntn, 0);
             f16x8 Bf[4];
@@ -998,12 +1037,9 @@ void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ 
             for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t fr = 16 * t + c16;                       // this lane's column: flat row fr of the chunk
             const uint32_t last = 16 * t + 15 < cnt ? 16 * t + 15 : cnt - 1;
             const uint32_t g_first = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)(16 * t));
             const uint32_t g_last = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)last);
-            const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
-            const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
             float a2 = 0.f;
 #pragma unroll
             for (int st = 0; st < 4; st++) a2 = dot8_self(Bf[st], a2);
@@ -1029,13 +1065,12 @@ void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ 
                 for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 const f32x4v dsum = (acc[0] + acc[1]) + (acc[2] + acc[3]);  // [i] = query slot i of group gp + h against stored row c16 of the tile
                 if (fr < cnt && rg == gp + h) {
-                    const ZhGroup *G = groups + rg;
-                    const uint32_t gs = G->gsize;
                     const uint32_t a2b = __float_as_uint(a2 * inv * inv);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if ((uint32_t)i < gs)
-                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv), iv + G->key_off[i] + rw);
+                        if ((uint32_t)i < (c_hi >> 16))
+                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv),
+                                                        iv + ((((uint64_t)((c_hi >> (4 * i)) & 15u)) << 32) | c_lo[i]) + rw);
                 }
             }
         }
@@ -1052,6 +1087,173 @@ void sweep128h_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ 
     }
 }
 
+// ---- the same sweep with the rows' tiles requested STRAIGHT INTO LDS (global_load_lds_dwordx4) and TWO tiles in flight per wave.
+// The kernel above keeps one tile travelling in 16 registers while the previous one is multiplied: 16 waves x 4 KiB = 64 KiB in flight per CU, and at
+// the latency a loaded HBM answers random 256-byte rows with that is 4.2-4.3 TB/s (a wave spends ~8000 cycles per tile, three quarters of them
+// waiting).  Here a tile needs no registers while it travels: a wave owns two 4-KiB tile buffers, tile t + 2 is requested (into the buffer tile t
+// was just read from) as soon as tile t's results are stored, so two tiles -- 128 KiB per CU at the same four waves per SIMD -- are on their way
+// while one is multiplied.  The XOR swizzle of the LDS image moves to the SOURCE side (lane (h, c) asks for piece c ^ row of its row: the DMA writes
+// lane after lane), the fragment reads are unchanged.  The compiler does not order LDS reads against LDS-DMA (it hoisted them above its own
+// waits in a probe): every wait of the steady state is explicit -- loads and stores of a wave complete in issue order, so "at most four VMEM
+// instructions outstanding" behind a younger tile's four, or none, says the tile has landed -- and anything else a wave loads meanwhile (the next
+// chunk's ids, a new group's record: rare) only makes those waits stricter.
+#define ZH_DMA16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src), (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
+template <int CH>
+__global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
+                                                             const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                                                             uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                                                             const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                                                             uint64_t *__restrict__ iv) {
+    __shared__ u32x4v rows_lds[4][2][16 * 16];  // per wave: TWO tiles = 16 rows x 16 pieces of 16 bytes, piece p of row R at R * 16 + (p ^ R)
+    __shared__ uint32_t ids_lds[4][64];         // per wave: the next chunk's row ids (requested the same way: no wait of the compiler's for them)
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    uint64_t r0 = row_begin + wave * (64 * CH);
+    if (r0 >= R_grouped) return;
+    uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+    uint32_t my_g, my_id, my_within, my_off, my_len;
+    resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
+    f16x8 Aq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t a_g0 = 0xFFFFFFFFu;  // the groups whose queries A holds: a_g0 .. a_g0 + 3 (wave-uniform)
+    uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};  // the group record this lane's column last stored through (as above)
+    // the issuing side runs up to two tiles ahead of the consuming side: its chunk's ids / row count, the next tile of it, and the chunk after it
+    // (known when the same leaf group continues)
+    uint32_t I_ids = my_id, I_cnt = cnt, I_t = 0, N_ids = 0, N_cnt = 0;
+    bool N_known = false;
+    uint32_t issued = 0, consumed = 0;  // tiles (wave-uniform); tile n lives in buffer n & 1
+    // LDS byte addresses: the wave's tile buffers, its id words, the lane's four fragment pieces of a tile ((c, h): piece 4 st + h of row c)
+    const uint32_t tile_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&rows_lds[wid][0][0];
+    const uint32_t ids_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&ids_lds[wid][0] + 4u * lane;
+    uint32_t frag_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) frag_off[st] = (c16 * 16u + ((4u * st + h) ^ c16)) * 16u;
+    auto issue_next = [&]() {
+        if (16u * I_t >= I_cnt) {
+            if (!N_known) return;
+            I_ids = N_ids; I_cnt = N_cnt; I_t = 0; N_known = false;
+        }
+        u32x4v *dst = rows_lds[wid][issued & 1u];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t rr = 4u * i + h, fr = 16u * I_t + rr;
+            const uint32_t id = (uint32_t)__shfl((int)I_ids, (int)(fr < I_cnt ? fr : I_cnt - 1));
+            ZH_DMA16(Xh + (size_t)id * 16 + (c16 ^ rr), dst + 64 * i);
+        }
+        I_t++; issued++;
+    };
+    issue_next();
+    issue_next();
+    for (int c = 0; c < CH; c++) {
+        // the next chunk: does it lie entirely in the group this chunk's last row belongs to?  (wave-uniform; as sweep128_kernel)
+        const uint64_t r0n = r0 + 64;
+        const bool have_next = c + 1 < CH && r0n < R_grouped;
+        const uint32_t cntn = have_next ? (uint32_t)(R_grouped - r0n < 64 ? R_grouped - r0n : 64) : 0;
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)my_within, (int)cnt - 1) + 1;
+        const uint32_t loff = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)cnt - 1);
+        const uint32_t llen = (uint32_t)__builtin_amdgcn_readlane((int)my_len, (int)cnt - 1);
+        const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)cnt - 1);
+        const bool fast = have_next && cnt == 64 && (uint64_t)lw + cntn <= llen;
+        if (fast) {  // (cnt == 64: four tiles follow)
+            const uint32_t wn = lw + (lane < cntn ? lane : cntn - 1);
+            if (leaf_ids) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(leaf_ids + (size_t)loff + wn),
+                                                           (__attribute__((address_space(3))) void *)ids_lds[wid], 4, 0, 0);
+            else { N_ids = loff + wn; N_cnt = cntn; N_known = true; }
+        }
+        const uint32_t ntile = (cnt + 15) / 16;
+#pragma unroll 1
+        for (uint32_t t = 0; t < ntile; t++) {
+            // tile `consumed` has landed once at most the younger tile's four requests are outstanding
+            if (issued - consumed >= 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // the next chunk's ids were requested before this chunk's first tile was waited for -- older than the tile requested behind that tile:
+            // the second tile's wait covers them
+            // (LDS reads of what the DMA wrote are inline asm: where the compiler SEES such a read it waits for every outstanding request)
+            if (t == 1 && fast && leaf_ids) {
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(N_ids) : "v"(ids_addr) : "memory");
+                N_cnt = cntn; N_known = true;
+            }
+            f16x8 Bf[4];
+            {
+                const uint32_t ta = tile_addr + (consumed & 1u) * 4096u;
+                u32x4v f0, f1, f2, f3;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
+                             : "v"(ta + frag_off[0]), "v"(ta + frag_off[1]), "v"(ta + frag_off[2]), "v"(ta + frag_off[3]) : "memory");
+                Bf[0] = __builtin_bit_cast(f16x8, f0); Bf[1] = __builtin_bit_cast(f16x8, f1);
+                Bf[2] = __builtin_bit_cast(f16x8, f2); Bf[3] = __builtin_bit_cast(f16x8, f3);
+            }
+            const uint32_t fr = 16 * t + c16;                       // this lane's column: flat row fr of the chunk
+            const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
+            const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
+            if (rg != c_rg) {
+                const uint4 *gq = reinterpret_cast<const uint4 *>(groups + rg);
+                const uint4 g0 = gq[0], k01 = gq[2], k23 = gq[3];
+                c_rg = rg;
+                c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;
+                c_hi = (k01.y & 15u) | ((k01.w & 15u) << 4) | ((k23.y & 15u) << 8) | ((k23.w & 15u) << 12) | (g0.z << 16);
+            }
+            const uint32_t last = 16 * t + 15 < cnt ? 16 * t + 15 : cnt - 1;
+            const uint32_t g_first = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)(16 * t));
+            const uint32_t g_last = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)last);
+            float a2 = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; st++) a2 = dot8_self(Bf[st], a2);
+            a2 = xor16<OpAdd>(a2);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(a2), false, false);
+                a2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            for (uint32_t gp = g_first; gp <= g_last; gp += 4) {
+                if (gp != a_g0) {  // (wave-uniform) the queries of groups gp .. gp + 3: A's row m = slot m & 3 of group gp + (m >> 2)
+                    a_g0 = gp;
+                    const uint32_t grp = gp + (c16 >> 2);
+                    const bool on = grp < n_groups && (c16 & 3u) < groups[grp < n_groups ? grp : 0].gsize;
+                    const uint32_t b = on ? groups[grp].b[c16 & 3u] : 0u;
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                        Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+                f32x4v acc[4];
+#pragma unroll
+                for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4v dsum = (acc[0] + acc[1]) + (acc[2] + acc[3]);  // [i] = query slot i of group gp + h against stored row c16 of the tile
+                if (fr < cnt && rg == gp + h) {
+                    const uint32_t a2b = __float_as_uint(a2 * inv * inv);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((uint32_t)i < (c_hi >> 16))
+                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv),
+                                                        iv + ((((uint64_t)((c_hi >> (4 * i)) & 15u)) << 32) | c_lo[i]) + rw);
+                }
+            }
+            consumed++;
+            // the buffer this tile was read from takes the tile after next (every fragment read has been consumed by the MFMAs above)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            issue_next();
+        }
+        if (!have_next) break;
+        r0 = r0n; cnt = cntn;
+        if (fast) {
+            my_g = lg; my_off = loff; my_len = llen;
+            my_within = lw + (lane < cntn ? lane : cntn - 1);
+            my_id = N_ids;
+        } else {
+            // (nothing of the next chunk was known: the issuing side has run dry and every tile issued is consumed)
+            resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
+            I_ids = my_id; I_cnt = cnt; I_t = 0; N_known = false;
+            issue_next();
+            issue_next();
+        }
+    }
+}
+
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
@@ -1061,8 +1263,15 @@ hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, cons
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         const uint64_t w = (r_end - r + 64 * CH - 1) / (64 * CH), blocks = (w + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
-                           dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
+        // ZH_S128H_DMA=1 (read per launch: tests switch it): the LDS-DMA kernel, two tiles in flight per wave -- measured EQUAL to the register-staged
+        // one (1.528-1.533 against 1.504-1.523 ms per launch on one box, profiles/r05_ab_sweep128h_dma.txt): the sweep is not bound by what a wave has in flight
+        const char *dma_e = getenv("ZH_S128H_DMA");
+        if (!(dma_e && dma_e[0] == '1'))
+            hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                               dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
+        else
+            hipLaunchKernelGGL((sweep128h_dma_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                               dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
     }
     return hipGetLastError();
 }
