@@ -576,6 +576,9 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
     return hipGetLastError();
 }
 
+#ifndef ZH_MFMA_EXP
+#define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores
+#endif
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
 #endif
@@ -674,21 +677,35 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     const uint32_t rd1 = (c16 >> 3) * 64u + (c16 & 7u) * 8u + (((4u + h) ^ (c16 >> 1)) & 7u);
     auto issue = [&](uint32_t bA, uint32_t bB, int chunk, u32x4v *dst) {
         if (!ZH_GUARD(bA < nq && bB < nq, 1u)) { bA = 0; bB = 0; }
+#if ZH_MFMA_EXP == 2   // timing experiment (results invalid): eight queries only -> the query lines hit the vector L1
+        bA &= 7u; bB &= 7u;
+#endif
         const u32x4v *qa = Qv + (size_t)bA * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swA);
         const u32x4v *qb = Qv + (size_t)bB * (D / 8) + (size_t)(chunk * CL * 8) + (pc ^ swB);
 #pragma unroll
         for (int i = 0; i < CL; i++) { dst[2 * i] = qa[8 * i]; dst[2 * i + 1] = qb[8 * i]; }
     };
     auto to_lds = [&](const u32x4v *src) {
+#if ZH_MFMA_EXP == 3   // timing experiment (results invalid): the staged lines are not written to LDS (one word keeps the loads alive)
+        u32x4v f = src[0];
+#pragma unroll
+        for (int i = 1; i < 2 * CL; i++) f ^= src[i];
+        if (f[0] == 0x12345678u) stg[lane] = f;
+#else
 #pragma unroll
         for (int i = 0; i < 2 * CL; i++) stg[64 * i + lane] = src[i];
+#endif
     };
     auto mfma_chunk = [&](int chunk, f32x4v *acc) {
 #pragma unroll
         for (int i = 0; i < 2 * CL; i++) {  // step 2 CL chunk + i: line i / 2 of the chunk
             const u32x4v v = stg[128 * (i / 2) + ((i & 1) ? rd1 : rd0)];
             const int st = chunk * 2 * CL + i;
+#if ZH_MFMA_EXP == 1   // timing experiment (results invalid): no MFMA
+            acc[st & 3] += __builtin_bit_cast(f32x4v, v) + __builtin_bit_cast(f32x4v, __builtin_shufflevector(A[st], A[st], 0, 1, 2, 3, 4, 5, 6, 7));
+#else
             acc[st & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[st], __builtin_bit_cast(f16x8, v), acc[st & 3], 0, 0, 0);
+#endif
         }
     };
     auto emit = [&](const f32x4v *acc, uint32_t rl, uint64_t slot, bool valid) {  // column c16 wants row rl: lane (c16, rl >> 2), register rl & 3
@@ -821,6 +838,9 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
                 const uint32_t rl = (uint32_t)(rec >> 60), col = (uint32_t)(rec >> 36) & 15u;
                 const float sv = reinterpret_cast<const float *>(al)[col * 16 + rl];
                 const float2 rm = rmeta[rl];
+#if ZH_MFMA_EXP == 4   // timing experiment (results invalid): one pair in 64 stores its result
+                if ((rec & 63u) == 0u)
+#endif
                 if (ZH_GUARD((rec & 0xFFFFFFFFFull) < iv_cap, 2u))
                     __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + (rec & 0xFFFFFFFFFull));
             }
