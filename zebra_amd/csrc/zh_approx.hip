@@ -601,8 +601,15 @@ extern "C" __attribute__((visibility("default"))) int zh_debug_scan_prof(uint64_
 #else
 #define SP(...)
 #endif
+// Waves per SIMD: the compiler's own choice at d = 768 is 224 registers (every query line of a tile requested up front) = two waves; held to 168 it
+// hoists a third of them and three waves fit (with `stage` in pair_list's words three blocks' LDS fits too) -- the third wave's preamble hides behind the
+// others' tiles: 3.46 -> 3.35 ms per cfg3 launch, 192 -> 198 k QPS (same box, alternating).  d = 1024 spills at 168 (196 bytes of scratch): two waves.
+#ifndef ZH_MFMA_WAVES
+#define ZH_MFMA_WAVES 3   // A/B: 2 = the compiler's choice at d = 768
+#endif
 template <int D>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D > 768 ? 2 : ZH_MFMA_WAVES, D > 768 ? 2 : ZH_MFMA_WAVES)))
+void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
                                                          const uint4 *__restrict__ Qh, const uint2 *__restrict__ rowLeaf, uint32_t T,
                                                          uint32_t RW, const uint32_t *__restrict__ visitBits,
                                                          const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
@@ -615,12 +622,13 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     constexpr int NCH = NL / CL;
     static_assert(D % 128 == 0 && NL % CL == 0 && NCH % 2 == 0, "four accumulators; the chunk registers alternate with a static parity");
     // pair records, 8 bytes: interval slot (36 bits) | query (24 bits; after the column pass: column (9) | position in its tile (9)) | row of the wave (4)
-    __shared__ uint64_t pair_list[4][ZH_APX_CAP];
+    __shared__ uint64_t pair_list[4][ZH_APX_CAP > CL * 256 ? ZH_APX_CAP : CL * 256];  // (... and, once the records are regrouped, the wave's chunk of query lines: `stage`)
     __shared__ uint64_t tile_list[4][ZH_APX_CAP];  // the same records grouped by tile of 16 columns; before that: the open-addressing table of the column pass (1024 words)
     __shared__ uint32_t col_query[4][ZH_APX_CAP];  // the query of every column (= distinct query of the wave's pairs)
     __shared__ uint32_t tile_start[4][36];         // pairs per tile -> exclusive scan
     __shared__ f32x4v acc_lds[4][64];              // a tile's 16 x 16 products: [column][row]
-    __shared__ uint4 stage[4][CL * 128];        // a chunk of the tile's query halves: [line][column / 8][column % 8][16-byte piece, swizzled]
+    // stage: a chunk of the tile's query halves, [line][column / 8][column % 8][16-byte piece, swizzled]: CL * 2 KiB per wave -- in pair_list's words, which are
+    // done with when the tile loop starts (45 KB of LDS per block instead of 62: three blocks per CU fit)
     __shared__ float2 row_meta[4][16];          // {|x|^2, 1 / sigma_x (NaN: nothing is certain about this row)}
     const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const u32x4v *__restrict
     // path, not L2, set the pace: 6.9 ms per launch (profiles/r04_pmc_scan_mfma.txt, v1).  The lines pass
     // through the wave's own LDS chunk (written as loaded, pieces XOR-swizzled by column so that the fragment reads -- ds_read_b128, lane
     // (c, h) piece 4 (s & 1) + h of column c -- meet no bank twice within their 16-lane groups).
-    u32x4v *stg = reinterpret_cast<u32x4v *>(stage[wid]);  // (native vectors: HIP's uint4 struct copies global -> private -> LDS stayed memcpys in scratch memory)
+    u32x4v *stg = reinterpret_cast<u32x4v *>(pair_list[wid]);  // (native vectors: HIP's uint4 struct copies global -> private -> LDS stayed memcpys in scratch memory)
     const u32x4v *__restrict__ Qv = reinterpret_cast<const u32x4v *>(Qh);
     const uint32_t g8 = lane >> 3, pc = lane & 7;
     const uint32_t swA = (g8 >> 1) & 7u, swB = (4u + (g8 >> 1)) & 7u;          // columns g8 and 8 + g8
