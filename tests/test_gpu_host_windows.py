@@ -62,21 +62,37 @@ def test_windows_equal_one_batch(za, monkeypatch, d, M, T, k, mode):
     ix.close()
 
 
-def test_small_leaf_forests_keep_the_classic_path(za, monkeypatch):
-    """the reference's default options (thousands of leaf visits per pair): per-batch limits are handled by the classic path's splitting"""
+def test_small_leaf_forests_run_as_windows_too(za, monkeypatch):
+    """the reference's default options (thousands of leaf visits per pair; row-score hash, blocked walk, prefilter): a large host batch runs as windows
+    sized for the score table (round 5, second session: the classic path's one-chunk-at-a-time split reached a quarter of the pipelined rate)"""
     n, d, M, T, k, B = 4000, 64, 5, 15, 10, 300
     X = zo.synth_rows(n, d)
     Q = zo.synth_queries(B, d, n)
     f = zo.Forest.build(X, M, T)
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
     ix.add(X)
-    monkeypatch.setenv("ZH_HOST_WINDOW", "64")
     m, om = za.L2SquaredDistance(), zo.L2SQ
     want = f.search_batch(Q, k, om, 0)
-    for _ in range(2):
-        ids, keys, counts = ix.search_batch(Q, k, m)
-        same(ids, keys, counts, *want)
+    ids, keys, counts = ix.search_batch(Q[:32], k, m)   # the first batch: classic (the visits per pair are not known yet)
+    same(ids, keys, counts, *[a[:32] for a in want])
     assert ix.stats()["host_window_calls_accum"] == 0
+    for wq in (64, 100, 7):
+        monkeypatch.setenv("ZH_HOST_WINDOW", str(wq))
+        before = ix.stats()["host_window_calls_accum"]
+        for _ in range(2):
+            ids, keys, counts = ix.search_batch(Q, k, m)
+            same(ids, keys, counts, *want)
+        assert ix.stats()["host_window_calls_accum"] == before + 2, wq
+    monkeypatch.delenv("ZH_HOST_WINDOW")   # by regime: 1024 queries per window at 4000 rows -> 300 queries are one classic batch
+    before = ix.stats()["host_window_calls_accum"]
+    ids, keys, counts = ix.search_batch(Q, k, m)
+    same(ids, keys, counts, *want)
+    assert ix.stats()["host_window_calls_accum"] == before
+    monkeypatch.setenv("ZH_HOST_WINDOW", "64")
+    monkeypatch.setenv("ZH_NO_HOST_WINDOWS", "1")
+    ids, keys, counts = ix.search_batch(Q, k, m)
+    same(ids, keys, counts, *want)
+    assert ix.stats()["host_window_calls_accum"] == before
     ix.close()
 
 

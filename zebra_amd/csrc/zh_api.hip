@@ -2523,23 +2523,38 @@ extern "C" int zh_debug_scan_pairs(zh_index *ix, zh_search_ctx *ctx, zh_debug_sc
 // to back on the index's sweep stream -- stages queries and results through pinned memory window by window, and hands out results as windows
 // complete.  Same ids / keys / counts as one batch: the queries of a batch never interact.  Only in the few-visits-per-pair regime (long leaves):
 // the wandering walk of small-leaf forests has its own limits per internal batch (search_locked splits by visits) and stays on the classic path.
-static size_t host_window_queries(uint32_t d) {
-    const char *e = getenv("ZH_HOST_WINDOW");  // tests / A-B, read per call (unset or 0: by dimension)
+// Queries per window of a large host batch.  Few visits per (query, tree) pair (leaves >= top_k): what keeps the scan's query halves in the L2s, by
+// dimension.  The wandering walk of small-leaf forests (the reference's default options: thousands of visits per pair): what keeps the row-score
+// hash's score table (n_rows x window x 4 bytes per context) at 1 GiB -- 256 queries at 1M rows; the classic path's own split there is by the visit
+// log alone (~2000 queries: a 7.8-GB score table per chunk, one chunk at a time: 7 k QPS where windows over two contexts reach the pipelined rate).
+static size_t host_window_queries(const zh_index *ix, bool wander) {
+    const char *e = getenv("ZH_HOST_WINDOW");  // tests / A-B, read per call (unset or 0: by regime and dimension)
     const size_t forced = e ? (size_t)atoll(e) : (size_t)0;
     if (forced) return forced;
+    const uint32_t d = ix->opt.dim;
+    if (wander) {
+        const size_t w = ((size_t)1 << 28) / std::max<uint64_t>(ix->n_rows, 1) / 64 * 64;
+        return std::min<size_t>(std::max<size_t>(w, 64), 1024);
+    }
     return d >= 512 ? 2048 : (d >= 256 ? 1024 : 4096);
 }
-static bool host_windows_wanted(zh_index *ix, size_t B) {
+// the window size for this call, or 0: the classic path (one internal batch, split only by its own limits)
+static size_t host_windows_wanted(zh_index *ix, size_t B) {
     const bool off = getenv("ZH_NO_HOST_WINDOWS") != nullptr;  // (read per call: tests switch it)
-    if (off || ix->n_trees == 0 || ix->n_rows == 0) return false;
-    const size_t wq = host_window_queries(ix->opt.dim);
-    if (B < 2 * wq && B < wq + wq / 2) return false;
-    std::lock_guard<std::mutex> lk(ix->stats_mu);
-    return ix->visits_per_pair > 0 && ix->visits_per_pair <= 4.0;  // (known from earlier batches: the first batch of an index goes the classic way)
+    if (off || ix->n_trees == 0 || ix->n_rows == 0) return 0;
+    double vpp;
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        vpp = ix->visits_per_pair;  // (known from earlier batches: the first batch of an index goes the classic way)
+    }
+    if (!(vpp > 0)) return 0;
+    const size_t wq = host_window_queries(ix, vpp > 4.0);
+    if (B < 2 * wq && B < wq + wq / 2) return 0;
+    return wq;
 }
 // returns ZH_OK with every result in the caller's buffers, or an error after which BOTH contexts are idle and nothing is in flight (the caller
 // then runs the classic path: a window that passes a per-batch limit is not an error of the call)
-static int search_host_windows(zh_index *ix, zh_index::Lane &ln, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
+static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
                                uint64_t *out_keys, uint32_t *out_counts) {
     const uint32_t d = ix->opt.dim;
     int rc;
@@ -2557,7 +2572,7 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, const float *q,
         }
         ln.init2 = true;
     }
-    const size_t wq = host_window_queries(d), nw = (B + wq - 1) / wq, per = (B + nw - 1) / nw;
+    const size_t nw = (B + wq - 1) / wq, per = (B + nw - 1) / nw;
     const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;
     if (need > ln.h_stage_cap) {
         if (ln.h_stage) hipHostFree(ln.h_stage);
@@ -2659,8 +2674,9 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     if ((rc = ln.wQ.ensure(B * d * 4)) || (rc = ln.wOutIds.ensure(std::max<size_t>(B * k, 1) * 8)) ||
         (rc = ln.wOutKeys.ensure(std::max<size_t>(B * k, 1) * 8)) || (rc = ln.wOutCounts.ensure(B * 4)))
         return all_fail(rc);
-    if (grp.size() == 1 && host_windows_wanted(ix, B)) {  // one large batch: windows over two contexts, copies beside the kernels
-        if (search_host_windows(ix, ln, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
+    const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B) : 0;
+    if (wq) {  // one large batch: windows over two contexts, copies beside the kernels
+        if (search_host_windows(ix, ln, wq, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
             std::lock_guard<std::mutex> ls(ix->stats_mu);
             ix->stats.host_window_calls_accum++;
             return;
