@@ -83,7 +83,8 @@ WORKLOADS = {
 # cfg3_window_of_one: the bench line's workload with every batch its own internal batch -- the latency / throughput trade of --window
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
 OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg4_one_of_8_shards", "cfg4", 8, 12), ("cfg2", "cfg2", 1, 40),
-                 ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6)]
+                 ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6),
+                 ("cfg1_single_query", "cfg1", 1, 60)]  # (configs[0]: the reference's own CPU-runnable case; what matters is latency_ms.p50_blocking_single_batch)
 
 
 def rank_env(base, rank, world, port):
@@ -1011,6 +1012,8 @@ def compact_line(full, limit=LINE_LIMIT):
              "frac": r.get("frac"), "launch_ms": r.get("launch_ms"), "traffic_ratio": r.get("traffic_over_algorithmic", r.get("traffic_over_hbm_by_design"))}
         if v.get("host_buffers_qps") is not None:
             e["host_buffers_qps"] = v["host_buffers_qps"]
+        if key == "cfg1_single_query":  # (the single-query configuration: what counts is one blocking call, results on the host)
+            e["p50_blocking_single_query_ms"] = (v.get("latency_ms") or {}).get("p50_blocking_single_batch")
         r10 = v.get("recall_at_10")
         if r10:
             e["recall_at_10_clustered_corrected_key"] = (r10.get("clustered_rows") or {}).get("corrected_key")
