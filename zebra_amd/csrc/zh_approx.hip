@@ -577,7 +577,7 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
 }
 
 #ifndef ZH_MFMA_EXP
-#define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores
+#define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores, 5 no tile loop
 #endif
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
@@ -810,7 +810,12 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
         __builtin_amdgcn_wave_barrier();
         // the wave's distinct queries sixteen at a time; the next chunk of query lines is requested before the current one is multiplied,
         // across tile boundaries
+#if ZH_MFMA_EXP == 5   // timing experiment (results invalid): no tile loop -- phase 1, pair list, column pass and the rows' tile loads only
+        const uint32_t nt = (nd + 15) / 16 > 4096u ? 1u : 0u;
+        if (lane == 0 && __builtin_bit_cast(u32x4v, A[NS - 1])[0] == 0x12345678u) iv[0] = 0;
+#else
         const uint32_t nt = (nd + 15) / 16;
+#endif
         SP(const uint64_t sp3 = clock64();)
         // what the sharing is worth (zh_stats_t::approx_columns / approx_column_pairs): every 64th wave reports -- same-address atomics from all
         // 200k waves of a launch serialise in one L2 channel (measured: 3.6 -> 5.5 ms per launch)
