@@ -73,9 +73,12 @@ def test_small_leaf_forests_run_as_windows_too(za, monkeypatch):
     ix.add(X)
     m, om = za.L2SquaredDistance(), zo.L2SQ
     want = f.search_batch(Q, k, om, 0)
-    ids, keys, counts = ix.search_batch(Q[:32], k, m)   # the first batch: classic (the visits per pair are not known yet)
-    same(ids, keys, counts, *[a[:32] for a in want])
-    assert ix.stats()["host_window_calls_accum"] == 0
+    # the FIRST batch of an index whose leaves are smaller than top_k already runs as windows (the visits per pair are guessed from the options)
+    monkeypatch.setenv("ZH_HOST_WINDOW", "128")
+    ids, keys, counts = ix.search_batch(Q, k, m)
+    same(ids, keys, counts, *want)
+    assert ix.stats()["host_window_calls_accum"] == 1
+    ix.stats(reset=True)
     for wq in (64, 100, 7):
         monkeypatch.setenv("ZH_HOST_WINDOW", str(wq))
         before = ix.stats()["host_window_calls_accum"]

@@ -2539,15 +2539,20 @@ static size_t host_window_queries(const zh_index *ix, bool wander) {
     return d >= 512 ? 2048 : (d >= 256 ? 1024 : 4096);
 }
 // the window size for this call, or 0: the classic path (one internal batch, split only by its own limits)
-static size_t host_windows_wanted(zh_index *ix, size_t B) {
+static size_t host_windows_wanted(zh_index *ix, size_t B, size_t k) {
     const bool off = getenv("ZH_NO_HOST_WINDOWS") != nullptr;  // (read per call: tests switch it)
     if (off || ix->n_trees == 0 || ix->n_rows == 0) return 0;
     double vpp;
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
-        vpp = ix->visits_per_pair;  // (known from earlier batches: the first batch of an index goes the classic way)
+        vpp = ix->visits_per_pair;  // (known from earlier batches)
     }
-    if (!(vpp > 0)) return 0;
+    // the first batch of an index: leaves below top_k wander (the guess choose_dense_planes makes too: lsh.rs:131-138's defaults against any
+    // top_k >= 2) -- windows at once, the one-chunk classic path is four times slower there; otherwise the classic way, once
+    if (!(vpp > 0)) {
+        if ((size_t)ix->opt.max_node_size >= 2 * k + 2) return 0;
+        vpp = 1000.0;
+    }
     const size_t wq = host_window_queries(ix, vpp > 4.0);
     if (B < 2 * wq && B < wq + wq / 2) return 0;
     return wq;
@@ -2674,7 +2679,7 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     if ((rc = ln.wQ.ensure(B * d * 4)) || (rc = ln.wOutIds.ensure(std::max<size_t>(B * k, 1) * 8)) ||
         (rc = ln.wOutKeys.ensure(std::max<size_t>(B * k, 1) * 8)) || (rc = ln.wOutCounts.ensure(B * 4)))
         return all_fail(rc);
-    const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B) : 0;
+    const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B, k) : 0;
     if (wq) {  // one large batch: windows over two contexts, copies beside the kernels
         if (search_host_windows(ix, ln, wq, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
             std::lock_guard<std::mutex> ls(ix->stats_mu);
