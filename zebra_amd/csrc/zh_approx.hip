@@ -579,9 +579,6 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
 #ifndef ZH_MFMA_EXP
 #define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores, 5 no tile loop
 #endif
-#ifndef ZH_MFMA_PRIO
-#define ZH_MFMA_PRIO 0   // A/B: s_setprio by phase (1: preamble high, tile loop low; 2: the reverse)
-#endif
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
 #endif
@@ -638,9 +635,6 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
     const uint64_t r0 = row_begin + wave * RW;
     if (r0 >= row_end) return;
-#if ZH_MFMA_PRIO
-    __builtin_amdgcn_s_setprio(ZH_MFMA_PRIO == 1 ? 3 : 0);   // A/B: 1 = the preamble's dependent chains issue ahead of other waves' tile loops, 2 = the reverse
-#endif
     SP(const uint64_t sp0 = clock64();)
     const uint32_t nr = (uint32_t)(row_end - r0 < RW ? row_end - r0 : RW);
     const uint32_t n_ent = nr * T;
@@ -830,9 +824,6 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
         uint32_t bA = col_b(0, g8), bB = col_b(0, 8 + g8);
         u32x4v ra[2 * CL], rb[2 * CL];
         issue(bA, bB, 0, ra);
-#if ZH_MFMA_PRIO
-        __builtin_amdgcn_s_setprio(ZH_MFMA_PRIO == 1 ? 0 : 3);
-#endif
         SP(__builtin_amdgcn_s_waitcnt(0); const uint64_t sp4 = clock64();)
         f32x4v *al = acc_lds[wid];
         for (uint32_t t = 0; t < nt; t++) {
