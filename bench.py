@@ -84,7 +84,12 @@ WORKLOADS = {
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
 OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg4_one_of_8_shards", "cfg4", 8, 12), ("cfg2", "cfg2", 1, 40),
                  ("cfg5_one_of_8_shards", "cfg5", 8, 12), ("reference_default_options", "refdefault", 1, 12), ("scale64m_n1", "scale64m", 1, 6),
-                 ("cfg1_single_query", "cfg1", 1, 60)]  # (configs[0]: the reference's own CPU-runnable case; what matters is latency_ms.p50_blocking_single_batch)
+                 ("cfg1_single_query", "cfg1", 1, 60),  # (configs[0]: the reference's own CPU-runnable case; what matters is latency_ms.p50_blocking_single_batch)
+                 # north_star's ">= 70 % of HBM on the candidate distance sweep" on a driver-run line: the bench line's workload through the f32
+                 # LEAF-MAJOR sweep (zh_set_sweep_mode(1): sweep_kernel<768>, HBM-bound, SURVEY s8(d)'s bytes are what it moves) beside the faster
+                 # L2-bound matrix-core scan that is the default ("deliberate deviations")
+                 ("cfg3_leaf_major_f32", "cfg3", 1, 6)]
+OTHER_SWEEP_MODE = {"cfg3_leaf_major_f32": "leaf"}
 
 
 def rank_env(base, rank, world, port):
@@ -285,7 +290,7 @@ class Env:
 
 
 def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_override=None, rows_override=None,
-                 batch_override=None, kind_override=None, window_override=None):
+                 batch_override=None, kind_override=None, window_override=None, sweep_override=None):
     """Build rank `rank`'s shard of an S-way sharding of workload `name` on this GPU, time `steps` batches, and return
     the result fields.  exchange: a ShardGroup is created (world ranks when S == world > 1, else ONE rank) and every
     batch goes through zh_shard_search_* (local search + all-gather + merge)."""
@@ -309,7 +314,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     t_setup = time.perf_counter()
     ix = za.LSHIndex(d, za.LSHIndexOptions(M_shard, T), seed=SEED_INDEX + rank, device=env.local_rank, id_base=first_row,
                      reserve_rows=rows_local)
-    ix.set_sweep_mode(args.sweep_mode)
+    ix.set_sweep_mode(sweep_override or args.sweep_mode)
     ix.append_synthetic(rows_local, seed=SEED_ROWS, first_row=first_row, kind=wl["kind"])
     t_fill = time.perf_counter() - t_setup
     ix.build()
@@ -997,7 +1002,7 @@ def compact_line(full, limit=LINE_LIMIT):
     optional = []  # (key, value), most important first
     optional.append(("stage_ms_per_batch", full.get("stage_ms_per_batch")))
     lat = full.get("latency_ms") or {}
-    optional.append(("latency_ms", _pick(lat, ("p50_window_submit_to_results", "p50_window_submit_to_host", "p50_blocking_single_batch", "batches_per_window", "windows_in_flight")) or None))
+    optional.append(("latency_ms", _pick(lat, ("p50_window_submit_to_results", "p50_window_submit_to_host_incl_slot_reuse", "p50_blocking_single_batch", "batches_per_window", "windows_in_flight")) or None))
     k = (full.get("config") or {}).get("top_k")
     rc = full.get("recall") or {}
     rsum = {"clustered": _pick(rc.get("informative") or {}, (f"recall_at_{k}", "planted_neighbour_hit_rate", "queries_per_s")),
@@ -1108,7 +1113,7 @@ def main():
             is_cos = WORKLOADS[wname]["metric"] == "cosine" and not args.no_recall
             in_place = is_cos and wname == "scale64m"  # (64M rows are not built twice: the last timed configuration, its scan the VALU kernel)
             r, ix2, g2, _, _ = run_workload(env, wname, shards, 0, steps, 2, exchange=False, recall=(True if in_place else ("planted" if is_cos else False)),
-                                            window_override=win[0] if win else None)
+                                            window_override=win[0] if win else None, sweep_override=OTHER_SWEEP_MODE.get(key))
             ix2.close()
             del ix2
             torch.cuda.empty_cache()

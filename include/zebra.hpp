@@ -109,8 +109,8 @@ ZEBRA_SIMPLE_METRIC(L4Distance, ZH_L4)
 ZEBRA_SIMPLE_METRIC(HammingDistance, ZH_HAMMING)
 #undef ZEBRA_SIMPLE_METRIC
 template <std::size_t N>
-struct MinkowskiDistance {  // distance.rs:160-174
-    int power = 2;
+struct MinkowskiDistance {  // distance.rs:160-174; #[derive(Default)] -> power 0, any i32 is legal
+    int power = 0;
     int device = -1;
     static constexpr int metric = ZH_MINKOWSKI;
     int mode() const { return power; }
@@ -119,8 +119,8 @@ struct MinkowskiDistance {  // distance.rs:160-174
     }
 };
 template <std::size_t N>
-struct PNormDistance {  // distance.rs:176-190
-    int power = 2;
+struct PNormDistance {  // distance.rs:176-190; #[derive(Default)] -> power 0, any i32 is legal
+    int power = 0;
     int device = -1;
     static constexpr int metric = ZH_PNORM;
     int mode() const { return power; }

@@ -83,7 +83,9 @@ typedef enum zh_metric {
     ZH_MINKOWSKI = 10,  /* MinkowskiDistance { power }  distance.rs:160-174 */
     ZH_PNORM = 11       /* PNormDistance { power }      distance.rs:176-190 */
 } zh_metric;
-#define ZH_MAX_POWER 64 /* MinkowskiDistance / PNormDistance power must be in 1..64 */
+/* `power` is the struct's i32 field and every value is served, as in the reference: the DEFAULT-constructed metric
+ * (`Met::default()`, core.rs:115,146; #[derive(Default)], distance.rs:160-165,176-181) has power 0 -- p-norm(0) = d,
+ * Minkowski(0) = d^(1/0) = +inf (1 at d = 1) --, negative powers go through powi's reciprocal and pow's IEEE cases. */
 
 /* distance.rs:23-25 applies `1.0 - c` to simsimd's cosine, which is already a distance, so the
  * reference key is the bit pattern of the cosine SIMILARITY.  PARITY reproduces that literally;

@@ -228,7 +228,7 @@ static inline float powi_f32(float a, int b) { /* compiler-rt __powisf2: what Ru
     return recip ? 1.0f / r : r;
 }
 
-static inline double root_p(double s, int p) { /* s^(1/p), p >= 1, deterministic (only + * / on f64) */
+static inline double root_p(double s, int p) { /* s^(1/p), 1 <= p <= 64, deterministic (only + * / on f64) */
     if (!(s > 0.0) || s == (double)INFINITY || p == 1) return s; /* 0, NaN, inf pass through */
     if (p == 2) return sqrt(s);
     uint64_t u;
@@ -244,6 +244,45 @@ static inline double root_p(double s, int p) { /* s^(1/p), p >= 1, deterministic
         y = ((double)(p - 1) * y + s / yp) / (double)p;
     }
     return y;
+}
+
+/* s^(1/p) for p > 64 (Newton's basin shrinks like 1/p): exp(ln(s) / p) from fixed f64 series -- only + * / and
+ * int <-> double conversions, so that CPU and GPU agree bit for bit.  s finite, > 0, a widened f32. */
+static inline double root_big(double s, double p) {
+    uint64_t u;
+    memcpy(&u, &s, 8);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    memcpy(&m, &u, 8);                                  /* m in [1, 2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z; /* ln m = 2 atanh z, |z| <= 0.1716 */
+    double t = 0.0;
+    for (int k = 25; k >= 1; k -= 2) t = t * z2 + 1.0 / (double)k;
+    const double LN2 = 0.6931471805599453;
+    const double x = ((double)e * LN2 + 2.0 * z * t) / p;   /* |x| <= 104 / 65 */
+    const double xs = x / LN2;
+    const int n = (int)(xs < 0.0 ? xs - 0.5 : xs + 0.5);
+    const double r = x - (double)n * LN2;               /* |r| <= 0.35 */
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k <= 20; k++) { term = term * r / (double)k; sum = sum + term; }
+    return ldexp(sum, n);
+}
+
+/* `sum.powf(1.0 / p as f32)` of distances::vectors::minkowski for ANY i32 p (MinkowskiDistance derives Default:
+ * power 0, distance.rs:160-165; negative powers are legal).  IEEE pow: p = 0 -> exponent +inf: NaN -> NaN, s > 1 -> +inf,
+ * s == 1 -> 1, s < 1 -> 0; p < 0: pow(0, neg) = +inf, pow(+inf, neg) = 0, else 1 / s^(1/|p|). */
+static inline double root_any(double s, int p) {
+    if (s != s) return s;
+    if (p == 0) return s > 1.0 ? (double)INFINITY : (s == 1.0 ? 1.0 : 0.0);
+    const int64_t ap = p < 0 ? -(int64_t)p : (int64_t)p;
+    double r;
+    if (!(s > 0.0) || s == (double)INFINITY || ap == 1) r = s;
+    else r = ap <= 64 ? root_p(s, (int)ap) : root_big(s, (double)ap);
+    if (p > 0) return r;
+    if (r == 0.0) return (double)INFINITY;
+    if (r == (double)INFINITY) return 0.0;
+    return 1.0 / r;
 }
 
 static inline uint32_t bits32(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
@@ -295,7 +334,7 @@ static uint64_t key_generic(int metric, int power, zo_pairsum s) {
     case ZO_L3: f = (float)root_p((double)s.s0, 3); break;
     case ZO_L4: f = sqrtf(sqrtf(s.s0)); break;
     case ZO_HAMMING: return (uint64_t)s.s0;
-    case ZO_MINKOWSKI: f = (float)root_p((double)s.s0, power); break;
+    case ZO_MINKOWSKI: f = (float)root_any((double)s.s0, power); break;
     default: f = s.s0; break; /* CHEBYSHEV, CANBERRA, MANHATTAN, PNORM */
     }
     return (uint64_t)bits32(f);

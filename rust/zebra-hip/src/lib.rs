@@ -143,12 +143,15 @@ pub mod ffi {
     }
 }
 
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(ffi::zh_last_error()) }.to_string_lossy().into_owned()
+}
+
 fn check(rc: c_int) -> anyhow::Result<()> {
     if rc == 0 {
         return Ok(());
     }
-    let msg = unsafe { CStr::from_ptr(ffi::zh_last_error()) }.to_string_lossy().into_owned();
-    Err(anyhow::anyhow!("zebra_hip error {rc}: {msg}"))
+    Err(anyhow::anyhow!("zebra_hip error {rc}: {}", last_error()))
 }
 
 /// Owns the device-side index.  `LSHIndex` is `Clone` in the reference (lsh.rs:144): clones share it.
@@ -184,8 +187,12 @@ macro_rules! simple_metric {
         impl<const N: usize> Metric<Embedding<N>> for $name<N> {
             type Unit = DistanceUnit;
             fn distance(&self, a: &Embedding<N>, b: &Embedding<N>) -> DistanceUnit {
+                // `Metric::distance` has no error channel (distance.rs:19-21): a failing device call must not read as key 0
                 let mut key = 0u64;
-                let _ = unsafe { ffi::zh_distance_pair($code, 0, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                let rc = unsafe { ffi::zh_distance_pair($code, 0, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                if rc != 0 {
+                    panic!("zh_distance_pair({}): {}", stringify!($name), last_error());
+                }
                 key
             }
         }
@@ -229,8 +236,13 @@ macro_rules! power_metric {
         impl<const N: usize> Metric<Embedding<N>> for $name<N> {
             type Unit = DistanceUnit;
             fn distance(&self, a: &Embedding<N>, b: &Embedding<N>) -> DistanceUnit {
+                // every i32 power is served (the derived Default is 0); what can still fail is the device, and
+                // `Metric::distance` has no error channel: fail loudly instead of returning key 0 for every pair
                 let mut key = 0u64;
-                let _ = unsafe { ffi::zh_distance_pair($code, self.power, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                let rc = unsafe { ffi::zh_distance_pair($code, self.power, a.as_ptr(), b.as_ptr(), N, &mut key, -1) };
+                if rc != 0 {
+                    panic!("zh_distance_pair({}, power {}): {}", stringify!($name), self.power, last_error());
+                }
                 key
             }
         }

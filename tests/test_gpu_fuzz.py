@@ -13,7 +13,7 @@ from oracle import zebra_oracle as zo  # noqa: E402
 
 
 def _metrics(za, rng):
-    p = int(rng.integers(1, 9))
+    p = int(rng.integers(-4, 9))  # any i32 is a legal power; 0 is the derived Default (distance.rs:160-165)
     return [(za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
             (za.CosineDistance(False), zo.COSINE, zo.CORRECTED), (za.ChebyshevDistance(), zo.CHEBYSHEV, 0),
             (za.CanberraDistance(), zo.CANBERRA, 0), (za.BrayCurtisDistance(), zo.BRAY_CURTIS, 0),

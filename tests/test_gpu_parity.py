@@ -52,6 +52,14 @@ def more_metrics(za):
             ("pnorm2", za.PNormDistance(2), zo.PNORM, 2), ("pnorm5", za.PNormDistance(5), zo.PNORM, 5)]
 
 
+def any_power_metrics(za):
+    """`power` is an i32 and the reference's derived Default is 0 (distance.rs:160-165,176-181; core.rs:115,146)"""
+    out = [("minkowski_default", za.MinkowskiDistance(), zo.MINKOWSKI, 0), ("pnorm_default", za.PNormDistance(), zo.PNORM, 0)]
+    for p in (-2, -1, -3, 64, 65, 66, 127, 1000, -65, 2**31 - 1, -2**31):
+        out += [("minkowski%d" % p, za.MinkowskiDistance(p), zo.MINKOWSKI, p), ("pnorm%d" % p, za.PNormDistance(p), zo.PNORM, p)]
+    return out
+
+
 # ------------------------------------------------------- src/distance.rs:51-98,116-190 (f2)
 @pytest.mark.parametrize("d", [3, 100, 128, 384, 768, 1000])
 def test_distances_crate_metric_keys_bit_exact(za, d):
@@ -64,10 +72,59 @@ def test_distances_crate_metric_keys_bit_exact(za, d):
             got, want = m.distance_batch(X, q), zo.distance_batch(om, p, X, q)
             same = (got == want) | (np.isnan(got.astype(np.uint32).view(np.float32)) & np.isnan(want.astype(np.uint32).view(np.float32)))
             assert same.all(), (name, d, scale, got[~same][:3], want[~same][:3])
-    with pytest.raises(za.ZhError):
-        za.MinkowskiDistance(0).distance_batch(X, q)
-    with pytest.raises(za.ZhError):
-        za.PNormDistance(65).distance_batch(X, q)
+
+
+def _same_f32_keys(got, want):
+    return (got == want) | (np.isnan(got.astype(np.uint32).view(np.float32)) & np.isnan(want.astype(np.uint32).view(np.float32)))
+
+
+@pytest.mark.parametrize("d", [1, 3, 128, 384, 1000])
+def test_power_metrics_any_i32_power_bit_exact(za, d):
+    """powers {0 (the reference's Default), negative, past 64, the i32 extremes}: keys bit-equal to the oracle, nothing refused"""
+    rng = np.random.default_rng(100 + d)
+    for lo, hi in ((0.5, 1.6), (0.3, 0.95), (0.0, 3.0)):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        X = (q + rng.uniform(lo, hi, (70, d)).astype(np.float32) * rng.choice([-1.0, 1.0], (70, d)).astype(np.float32)).astype(np.float32)
+        X[3] = q            # every |a - b| = 0: powi(0, negative) = inf
+        X[4, 0] = np.nan
+        X[5, 0] = np.inf
+        for name, m, om, p in any_power_metrics(za):
+            got, want = m.distance_batch(X, q), zo.distance_batch(om, p, X, q)
+            same = _same_f32_keys(got, want)
+            assert same.all(), (name, d, lo, got[~same][:3], want[~same][:3])
+    assert za.MinkowskiDistance().power == 0 and za.PNormDistance().power == 0
+    assert (za.PNormDistance().distance_batch(X, q).astype(np.uint32).view(np.float32) == d).all()
+
+
+def test_database_with_the_default_constructed_power_metric_and_top_k_zero(za):
+    """Database::new builds the metric with Met::default() (core.rs:115,146) -> MinkowskiDistance { power: 0 }: every key is
+    +inf (d > 1), so the (key, id) order decides; LSHIndex::search with top_k = 0 is Ok(vec![]) (lsh.rs:544-565)"""
+    n, d, M, T, k, B = 3000, 24, 40, 5, 7, 9
+    X = zo.synth_rows(n, d)
+    Q = zo.synth_queries(B, d, n)
+    f = zo.Forest.build(X, M, T)
+    for cls, om in ((za.MinkowskiDistance, zo.MINKOWSKI), (za.PNormDistance, zo.PNORM)):
+        db = za.Database(d, cls, za.LSHIndexOptions(M, T))  # the class itself: default-constructed, as Met::default()
+        assert db.metric.power == 0
+        db.insert_records(X, [b"doc%d" % i for i in range(n)])
+        oi, ok, oc = f.search_batch(Q, k, om, 0)
+        got = db.query_vectors(Q, k)
+        for b in range(B):
+            assert sorted(got[b]) == sorted(int(i) for i in oi[b, :oc[b]])
+            assert all(got[b][i] == b"doc%d" % i for i in got[b])
+        ids, keys, counts = db.index.search_batch(Q, k, db.metric)
+        assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()
+        for p in (-2, 65):
+            ids, keys, counts = db.index.search_batch(Q, k, cls(p))
+            oi, ok, oc = f.search_batch(Q, k, om, p)
+            assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all(), p
+        # top_k = 0: rc 0, no neighbours, through every entry point
+        ids, keys, counts = db.index.search_batch(Q, 0, db.metric)
+        assert ids.shape == (B, 0) and keys.shape == (B, 0) and (counts == 0).all()
+        assert db.index.search(Q[0], 0, za.L2SquaredDistance()) == []
+        assert db.query_vectors(Q, 0) == {b: {} for b in range(B)}
+        assert f.search_batch(Q, 0, zo.L2SQ)[2].tolist() == [0] * B
+        db.index.close()
 
 
 @pytest.mark.parametrize("n,d,M,T,k,B", [(6000, 128, 200, 6, 10, 20), (3000, 384, 64, 4, 10, 12), (2500, 50, 40, 3, 7, 9)])

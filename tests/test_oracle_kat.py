@@ -370,6 +370,51 @@ def test_distances_crate_metrics_vs_float64(d):
     assert abs(k(zo.CANBERRA) - (3 / 5 + 4 / 8 + 5 / 11)) < 1e-6 and abs(k(zo.BRAY_CURTIS) - 12 / 24) < 1e-7
 
 
+def test_power_metrics_take_any_i32_power():
+    """MinkowskiDistance / PNormDistance { power: i32 } derive Default (distance.rs:160-165,176-181) and Database::new / open
+    construct `Met::default()` (core.rs:115,146): power 0 is the reference's DEFAULT, and negative powers are legal.
+    distances::vectors::minkowski_p(p) = sum |a-b|.powi(p); minkowski(p) = that .powf(1 / p)."""
+    f = lambda key: float(np.uint32(key).view(np.float32))  # noqa: E731
+    a, b = [1, 2, 3], [4, 6, 8]  # |a-b| = 3, 4, 5
+    # power 0: powi(x, 0) = 1 for every x incl. 0 and NaN -> p-norm = d; Minkowski = d^(1/0) = d^inf = +inf, 1 at d = 1, 0 at d = 0
+    assert f(zo.distance(zo.PNORM, 0, a, b)) == 3.0 and f(zo.distance(zo.MINKOWSKI, 0, a, b)) == np.inf
+    assert f(zo.distance(zo.PNORM, 0, [7.0], [7.0])) == 1.0 and f(zo.distance(zo.MINKOWSKI, 0, [7.0], [7.0])) == 1.0
+    assert f(zo.distance(zo.PNORM, 0, [np.nan, 1], [0, 1])) == 2.0
+    for d in (4, 100, 384, 768, 1000):
+        X = np.random.default_rng(d).standard_normal((5, d)).astype(np.float32)
+        assert (zo.distance_batch(zo.PNORM, 0, X, X[0]).astype(np.uint32).view(np.float32) == d).all()
+        assert np.isposinf(zo.distance_batch(zo.MINKOWSKI, 0, X, X[0]).astype(np.uint32).view(np.float32)).all()
+    # negative powers: powi through the reciprocal; pow(s, 1/p) = 1 / s^(1/|p|); an element with a == b is 1/0 = inf -> sum inf -> 0
+    assert f(zo.distance(zo.PNORM, -1, a, b)) == np.float32(np.float32(1) / 3 + np.float32(1) / 4 + np.float32(1) / 5)
+    assert abs(f(zo.distance(zo.MINKOWSKI, -1, a, b)) - 1 / (1 / 3 + 1 / 4 + 1 / 5)) < 1e-6
+    assert abs(f(zo.distance(zo.MINKOWSKI, -2, a, b)) - (1 / 9 + 1 / 16 + 1 / 25) ** -0.5) < 1e-6
+    assert f(zo.distance(zo.PNORM, -2, [1, 2], [1, 5])) == np.inf and f(zo.distance(zo.MINKOWSKI, -2, [1, 2], [1, 5])) == 0.0
+    assert f(zo.distance(zo.MINKOWSKI, -3, [np.inf, 2], [1, 5])) == 3.0  # powi(inf, -3) = 0: (0 + 3^-3)^(-1/3) = 3
+    assert np.isnan(f(zo.distance(zo.MINKOWSKI, -3, [np.nan, 2], [1, 5]))) and np.isnan(f(zo.distance(zo.MINKOWSKI, 70, [np.nan, 2], [1, 5])))
+    # powers past the Newton range (root by exp(ln(s) / p), fixed f64 series) against float64 pow, and the i32 extremes
+    rng = np.random.default_rng(5)
+    checked = {}
+    for d in (4, 100, 768):
+        for lo, hi in ((0.5, 1.6), (0.3, 0.95), (1.05, 1.3)):  # |a-b| in [lo, hi]: powi stays inside f32 for |p| <= 127
+            ad32 = rng.uniform(lo, hi, (20, d)).astype(np.float32)
+            q = rng.uniform(-1, 1, d).astype(np.float32)
+            X = (q + ad32 * rng.choice([-1.0, 1.0], (20, d)).astype(np.float32)).astype(np.float32)
+            ad = np.abs(X.astype(np.float64) - q.astype(np.float64))
+            for p in (65, 66, 100, 127, 1000, -65, -3, -7, 64, -64, -127):
+                got = zo.distance_batch(zo.MINKOWSKI, p, X, q).astype(np.uint32).view(np.float32).astype(np.float64)
+                with np.errstate(all="ignore"):
+                    s = (ad ** p).sum(1)
+                    ok = np.isfinite(s) & (s > 1e-30) & (s < 1e30) & ((ad ** p).max(1) < 1e37)
+                    want = s ** (1.0 / p)
+                checked[p] = checked.get(p, 0) + int(ok.sum())
+                np.testing.assert_allclose(got[ok], want[ok], rtol=2e-5, err_msg=str((d, lo, hi, p)))
+    assert all(checked[p] >= 60 for p in (65, 66, 100, 127, -65, -3, -7, 64, -64, -127)), checked
+    for p in (2**31 - 1, -2**31, 2**30, -2**31 + 1):
+        k = zo.distance(zo.MINKOWSKI, p, [1.0, 2.0], [2.0, 4.0])  # |a-b| = 1, 2: 2^p overflows (or vanishes); 1^p = 1
+        assert f(k) in (np.inf, 1.0, 0.0) or abs(f(k) - 2.0) < 1e-5 or abs(f(k) - 1.0) < 1e-5
+        assert f(zo.distance(zo.PNORM, p, [1.0, 3.0], [2.0, 4.0])) == 2.0  # 1^p + 1^p
+
+
 def test_search_with_a_distances_crate_metric():
     X = zo.synth_rows(3000, 32)
     f = zo.Forest.build(X, 64, 5)

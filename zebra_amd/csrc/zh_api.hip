@@ -2371,8 +2371,7 @@ static int search_locked(zh_index *ix, const float *dQ, size_t B, size_t k, int 
 static int check_metric(int metric, int mode) {
     if (metric < ZH_COSINE || metric > ZH_PNORM) return fail(ZH_EINVAL, "unknown metric %d", metric);
     if (metric == ZH_COSINE && mode != ZH_COSINE_PARITY && mode != ZH_COSINE_CORRECTED) return fail(ZH_EINVAL, "unknown cosine mode %d", mode);
-    if ((metric == ZH_MINKOWSKI || metric == ZH_PNORM) && (mode < 1 || mode > ZH_MAX_POWER))
-        return fail(ZH_ELIMIT, "power %d outside 1..%d", mode, ZH_MAX_POWER);
+    // ZH_MINKOWSKI / ZH_PNORM: `mode` is the struct's i32 power and every value is legal (distance.rs:160-190; Default = 0)
     return ZH_OK;
 }
 

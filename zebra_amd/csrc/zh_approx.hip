@@ -1287,6 +1287,215 @@ __global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__rest
     }
 }
 
+// ---- round 6: the same sweep with a LEAN instruction stream for the common chunk.  The two kernels above spend ~270 instructions of a wave on
+// a 16-row tile (ids -> ds_bpermute -> 64-bit addresses, sixteen dependent v_dot2 + a butterfly for |x^|^2, per-lane group look-ups through
+// __shfl, up to four predicated 64-bit-address stores): at four waves per SIMD the issue slots, not HBM, set the pace (0.54 of 8 TB/s, DESIGN.md
+// s9).  A leaf is thousands of rows and a chunk is 64: all but ~1 chunk in 70 lie inside ONE (leaf, <= 4 queries) group, and for those everything
+// that is per-row bookkeeping above is wave-uniform:
+//   * the group's record sits in scalar registers; A's row m is query slot m >> 2 of THE group, so lane (c, h)'s first accumulator is slot h
+//     against stored row c: ONE store instruction per tile (h < gsize), its address the lane's per-chunk base + an immediate;
+//   * the chunk's ids are loaded in the order lane (h, c) = flat row 4 c + h: instruction i of tile t wants row 4 (4 t + i) + h -- the same
+//     16-lane row, lane 4 t + i: a DPP row_newbcast, no LDS crossbar;
+//   * |x^|^2 is the DIAGONAL of the tile's Gram matrix: four more MFMAs with the B fragments as both operands (the A and B layouts of
+//     v_mfma_f32_16x16x32_f16 coincide) on a matrix pipe that has nothing else to do, three selects and one ds_bpermute;
+//   * the four K-steps chain through one accumulator.
+// ~45 instructions per tile.  A chunk that crosses a group boundary (or the launch's last, short one) runs the general per-lane form of the
+// kernel above, one chunk at a time.  Same raw pairs up to the summation order inside the matrix pipe (covered by zh_approx_bound's MFMA term,
+// tests/test_gpu_intervals.py) -- the results behind them are bit-identical by construction as before.
+template <int N>
+__device__ __forceinline__ uint32_t row_newbcast(uint32_t v) {  // every lane: the value of lane N of its own 16-lane row (DPP, no LDS)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);  // (bound_ctrl: no `old` operand to initialise)
+}
+// the four row-load instructions of tile T of a chunk whose ids the lanes hold as lane (h, c) = flat row 4 c + h: instruction i = rows 4 (4 T + i) + h
+template <int T>
+__device__ __forceinline__ void issue_lean_tile(const u32x4v *__restrict__ Xh, uint32_t ids, uint32_t c16, u32x4v (&R)[4]) {
+    R[0] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 0>(ids) * 16 + c16);
+    R[1] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 1>(ids) * 16 + c16);
+    R[2] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 2>(ids) * 16 + c16);
+    R[3] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 3>(ids) * 16 + c16);
+}
+#ifndef ZH_S128L_WAVES
+#define ZH_S128L_WAVES 4   // waves per SIMD the register allocation is held to (A/B)
+#endif
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZH_S128L_WAVES, ZH_S128L_WAVES)))
+void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
+                                                              const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                                                              uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                                                              const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                                                              uint64_t *__restrict__ iv) {
+    __shared__ u32x4v rows_lds[4][16 * 16];  // per wave: ONE tile = 16 rows x 16 pieces of 16 bytes, piece p of row R at R * 16 + (p ^ R)
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r_first = row_begin + wave * (64 * CH);
+    if (r_first >= R_grouped) return;
+    u32x4v *tl = rows_lds[wid];
+    f16x8 Aq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t a_fast_g = 0xFFFFFFFFu;   // fast form: the group whose queries A holds (row m = slot m >> 2)
+    uint32_t a_g0 = 0xFFFFFFFFu;       // general form: A holds groups a_g0 .. a_g0 + 3 (row m = slot m & 3 of group a_g0 + (m >> 2))
+    const float inv2 = inv * inv;
+    const uint32_t diag_src = (((c16 >> 2) << 4) | c16) << 2;  // ds_bpermute address of lane (c16, c16 >> 2): where G[c16][c16] lives
+    const bool c_odd = (c16 & 1u) != 0, c_up = (c16 & 2u) != 0;  // which of a lane's four Gram entries sits on the diagonal: register c16 & 3
+    u32x4v R[4];
+
+    // ---------------- the general form: one chunk, per-lane groups (the body of sweep128h_kernel, without a look at the next chunk) ----------------
+    auto general_chunk = [&](uint64_t r0, uint32_t cnt) {
+        uint32_t my_g, my_id, my_within;
+        resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
+        a_fast_g = 0xFFFFFFFFu;
+        uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};
+        auto issue_tile = [&](uint32_t t) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t fr = 16u * t + 4u * i + h;
+                const uint32_t id = (uint32_t)__shfl((int)my_id, (int)(fr < cnt ? fr : cnt - 1));
+                R[i] = __builtin_nontemporal_load(Xh + (size_t)id * 16 + c16);
+            }
+        };
+        issue_tile(0);
+        const uint32_t ntile = (cnt + 15) / 16;
+#pragma unroll 1
+        for (uint32_t t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + h;
+                tl[rr * 16 + (c16 ^ rr)] = R[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t fr = 16 * t + c16;
+            const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
+            const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
+            if (rg != c_rg) {
+                const uint4 *gq = reinterpret_cast<const uint4 *>(groups + rg);
+                const uint4 g0 = gq[0], k01 = gq[2], k23 = gq[3];
+                c_rg = rg;
+                c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;
+                c_hi = (k01.y & 15u) | ((k01.w & 15u) << 4) | ((k23.y & 15u) << 8) | ((k23.w & 15u) << 12) | (g0.z << 16);
+            }
+            if (t + 1 < ntile) issue_tile(t + 1);
+            f16x8 Bf[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t last = 16 * t + 15 < cnt ? 16 * t + 15 : cnt - 1;
+            const uint32_t g_first = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)(16 * t));
+            const uint32_t g_last = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)last);
+            f32x4v gram = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; st++) gram = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[st], Bf[st], gram, 0, 0, 0);
+            const float dg_lo = c_odd ? gram[1] : gram[0], dg_hi = c_odd ? gram[3] : gram[2], dg = c_up ? dg_hi : dg_lo;
+            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)diag_src, __float_as_int(dg)));
+            for (uint32_t gp = g_first; gp <= g_last; gp += 4) {
+                if (gp != a_g0) {
+                    a_g0 = gp;
+                    const uint32_t grp = gp + (c16 >> 2);
+                    const bool on = grp < n_groups && (c16 & 3u) < groups[grp < n_groups ? grp : 0].gsize;
+                    const uint32_t b = on ? groups[grp].b[c16 & 3u] : 0u;
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                        Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+                f32x4v dsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 4; st++) dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], dsum, 0, 0, 0);
+                if (fr < cnt && rg == gp + h) {
+                    const uint32_t a2b = __float_as_uint(a2 * inv2);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((uint32_t)i < (c_hi >> 16))
+                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv),
+                                                        iv + ((((uint64_t)((c_hi >> (4 * i)) & 15u)) << 32) | c_lo[i]) + rw);
+                }
+            }
+        }
+    };
+
+    // ---------------- the chunks of this wave ----------------
+    bool carried = false;          // the fast form left the NEXT chunk's first tile travelling in R and its ids in `ids`
+    uint32_t ids = 0;              // fast form: lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
+    uint32_t g = 0, within0 = 0;   // fast form: the chunk's group and its first row's position in the group (wave-uniform)
+    for (int c = 0; c < CH; c++) {
+        const uint64_t r0 = r_first + 64ull * c;
+        if (r0 >= R_grouped) break;
+        const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
+        bool fast = carried;
+        if (!carried && waveGroup && cnt == 64) {
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)waveGroup[r0 >> 6]);
+            const uint64_t off = groupRowOff[g];
+            const uint64_t nxt = (uint64_t)g + 1 < n_groups ? groupRowOff[g + 1] : ~0ull;
+            fast = nxt >= r0 + 64;
+            within0 = (uint32_t)(r0 - off);
+        }
+        if (!fast) { general_chunk(r0, cnt); carried = false; continue; }
+        const ZhGroup *gr = groups + g;
+        const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
+        if (!carried) {
+            const uint32_t w = within0 + 4u * c16 + h;
+            ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+            issue_lean_tile<0>(Xh, ids, c16, R);
+        }
+        if (g != a_fast_g) {  // (wave-uniform) A's row m = query slot m >> 2 of group g, zero past gsize
+            a_fast_g = g; a_g0 = 0xFFFFFFFFu;
+            const bool on = (c16 >> 2) < gsize;
+            const uint32_t b = on ? gr->b[c16 >> 2] : 0u;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        // where this lane's results of the chunk go: slot h's key slice, position within0 + 16 t + c16
+        uint64_t *const dst = iv + gr->key_off[h] + within0 + c16;
+        // the next chunk: entirely inside the same group?  Then its ids are requested now and its first tile behind this chunk's last one
+        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
+        uint32_t nxt_ids = 0;
+        if (next_fast) {
+            const uint32_t w = within0 + 64u + 4u * c16 + h;
+            nxt_ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+        }
+        auto tile = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + h;
+                tl[rr * 16 + (c16 ^ rr)] = R[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (t < 3) issue_lean_tile<(t + 1) & 3>(Xh, ids, c16, R);
+            else if (next_fast) issue_lean_tile<0>(Xh, nxt_ids, c16, R);
+            f16x8 Bf[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4v dsum = {0.f, 0.f, 0.f, 0.f}, gram = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], dsum, 0, 0, 0);
+                gram = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[st], Bf[st], gram, 0, 0, 0);
+            }
+            const float dg_lo = c_odd ? gram[1] : gram[0], dg_hi = c_odd ? gram[3] : gram[2], dg = c_up ? dg_hi : dg_lo;
+            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)diag_src, __float_as_int(dg)));
+            if (h < gsize)
+                __builtin_nontemporal_store(((uint64_t)__float_as_uint(a2 * inv2) << 32) | __float_as_uint(dsum[0] * inv), dst + 16 * t);
+        };
+        tile(std::integral_constant<int, 0>{});
+        tile(std::integral_constant<int, 1>{});
+        tile(std::integral_constant<int, 2>{});
+        tile(std::integral_constant<int, 3>{});
+        carried = next_fast;
+        if (next_fast) { ids = nxt_ids; within0 += 64; }
+    }
+}
+
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
@@ -1298,8 +1507,13 @@ hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, cons
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
         // ZH_S128H_DMA=1 (read per launch: tests switch it): the LDS-DMA kernel, two tiles in flight per wave -- measured EQUAL to the register-staged
         // one (1.528-1.533 against 1.504-1.523 ms per launch on one box, profiles/r05_ab_sweep128h_dma.txt): the sweep is not bound by what a wave has in flight
-        const char *dma_e = getenv("ZH_S128H_DMA");
-        if (!(dma_e && dma_e[0] == '1'))
+        // ZH_S128H_KERNEL (read per launch: tests switch it): unset / "lean" = the round-6 kernel; "r5" = the round-5 register-staged kernel
+        const char *dma_e = getenv("ZH_S128H_DMA"), *kern_e = getenv("ZH_S128H_KERNEL");
+        const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r';
+        if (!dma && !r5)
+            hipLaunchKernelGGL((sweep128h_lean_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                               dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
+        else if (!dma)
             hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                                dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
         else

@@ -86,7 +86,7 @@ __device__ __forceinline__ float powi_f32(float a, int b) {  // compiler-rt __po
     return recip ? 1.0f / r : r;
 }
 
-// s^(1/p), p >= 1: fixed Newton iteration in f64 (only + * /), bit-identical to the oracle's root_p
+// s^(1/p), 1 <= p <= 64: fixed Newton iteration in f64 (only + * /), bit-identical to the oracle's root_p
 __device__ __forceinline__ double root_p(double s, int p) {
     if (!(s > 0.0) || s == (double)INFINITY || p == 1) return s;
     if (p == 2) return sqrt(s);
@@ -103,6 +103,40 @@ __device__ __forceinline__ double root_p(double s, int p) {
     return y;
 }
 
+// s^(1/p), p > 64: exp(ln(s) / p) from fixed f64 series (the oracle's root_big, operation for operation)
+__device__ __forceinline__ double root_big(double s, double p) {
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
+    double t = 0.0;
+    for (int k = 25; k >= 1; k -= 2) t = t * z2 + 1.0 / (double)k;
+    const double LN2 = 0.6931471805599453;
+    const double x = ((double)e * LN2 + 2.0 * z * t) / p;
+    const double xs = x / LN2;
+    const int n = (int)(xs < 0.0 ? xs - 0.5 : xs + 0.5);
+    const double r = x - (double)n * LN2;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k <= 20; k++) { term = term * r / (double)k; sum = sum + term; }
+    return ldexp(sum, n);
+}
+
+// distances::vectors::minkowski's `sum.powf(1 / p)` for ANY i32 p (distance.rs:160-174; Default is power 0): the oracle's root_any
+__device__ __forceinline__ double root_any(double s, int p) {
+    if (s != s) return s;
+    if (p == 0) return s > 1.0 ? (double)INFINITY : (s == 1.0 ? 1.0 : 0.0);
+    const long long ap = p < 0 ? -(long long)p : (long long)p;
+    double r;
+    if (!(s > 0.0) || s == (double)INFINITY || ap == 1) r = s;
+    else r = ap <= 64 ? root_p(s, (int)ap) : root_big(s, (double)ap);
+    if (p > 0) return r;
+    if (r == 0.0) return (double)INFINITY;
+    if (r == (double)INFINITY) return 0.0;
+    return 1.0 / r;
+}
+
 // sums -> DistanceUnit for every metric; s0/s1 are the canonical sums, qq the query norm (cosine)
 __device__ __forceinline__ uint64_t key_of(int metric, int param, float s0, float s1, float qq) {
     float f;
@@ -113,7 +147,7 @@ __device__ __forceinline__ uint64_t key_of(int metric, int param, float s0, floa
     case ZH_L3: f = (float)root_p((double)s0, 3); break;
     case ZH_L4: f = sqrtf(sqrtf(s0)); break;
     case ZH_HAMMING: return (uint64_t)s0;
-    case ZH_MINKOWSKI: f = (float)root_p((double)s0, param); break;
+    case ZH_MINKOWSKI: f = (float)root_any((double)s0, param); break;
     default: f = s0; break;  // CHEBYSHEV, CANBERRA, MANHATTAN, PNORM
     }
     return (uint64_t)__float_as_uint(f);

@@ -104,19 +104,20 @@ class HammingDistance(_Metric):
 
 
 class MinkowskiDistance(_Metric):
-    """src/distance.rs:160-174; `power` is the struct's field"""
+    """src/distance.rs:160-174; `power` is the struct's i32 field (#[derive(Default)]: 0, what `Met::default()` of
+    core.rs:115,146 constructs; any i32 is legal)"""
     metric = _ffi.MINKOWSKI
 
-    def __init__(self, power, device=-1):
+    def __init__(self, power=0, device=-1):
         super().__init__(device)
         self.power = self.mode = int(power)
 
 
 class PNormDistance(_Metric):
-    """src/distance.rs:176-190"""
+    """src/distance.rs:176-190; default power 0 as the reference's derived Default"""
     metric = _ffi.PNORM
 
-    def __init__(self, power, device=-1):
+    def __init__(self, power=0, device=-1):
         super().__init__(device)
         self.power = self.mode = int(power)
 
@@ -474,7 +475,8 @@ class Database:
     files and the embedding model are out of scope)."""
 
     def __init__(self, dim, metric, index_options=None, **index_kwargs):
-        self.metric = metric
+        # a metric CLASS is default-constructed, as Database::new / open do with `Met::default()` (core.rs:115,146)
+        self.metric = metric() if isinstance(metric, type) else metric
         self.index = LSHIndex(dim, index_options, **index_kwargs)  # pub field `index`, core.rs:62
         self._documents = {}
 
