@@ -187,17 +187,19 @@ LEAF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dma", [False, True])
+@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])
 @pytest.mark.parametrize("n,M,T,k,B,kind", LEAF_CASES)
-def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, B, kind, dma):
+def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, B, kind, variant):
     """d = 128, leaf by leaf at half width on the matrix cores (sweep128h_kernel, zh_set_sweep_mode 6): an fp16 copy of the rows under one
     scale, the queries of up to four groups as the A operand, 16 stored rows as B; same intervals, same stages behind it.  dma: the variant
     whose row tiles travel straight into LDS (sweep128h_dma_kernel, ZH_S128H_DMA=1: two tiles in flight per wave, explicit waits)"""
     d = 128
-    if dma:
-        monkeypatch.setenv("ZH_S128H_DMA", "1")
-    else:
-        monkeypatch.delenv("ZH_S128H_DMA", raising=False)
+    # lean: sweep128h_lean_kernel + sweep128h_boundary_kernel (round 6, the default); r5: sweep128h_kernel; dma: sweep128h_dma_kernel
+    for var, val in (("ZH_S128H_DMA", "1" if variant == "dma" else None), ("ZH_S128H_KERNEL", "r5" if variant == "r5" else None)):
+        if val:
+            monkeypatch.setenv(var, val)
+        else:
+            monkeypatch.delenv(var, raising=False)
     X = zo.synth_rows(n, d, kind=kind)
     Q = zo.synth_queries(B, d, n, kind=kind)
     f = zo.Forest.build(X, M, T)

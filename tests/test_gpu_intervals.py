@@ -242,15 +242,17 @@ def test_valu_scan_intervals_contain_the_key(za, torch, d):
     ix.close()
 
 
-@pytest.mark.parametrize("dma", [False, True])
+@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])
 @pytest.mark.parametrize("kind", [0, 1])
-def test_leaf_major_half_width_intervals_contain_the_key(za, torch, monkeypatch, kind, dma):
+def test_leaf_major_half_width_intervals_contain_the_key(za, torch, monkeypatch, kind, variant):
     """sweep128h_kernel (d = 128, zh_set_sweep_mode 6): a row-major fp16 copy under ONE table scale (rows it does not serve: NaNs -> the exact path);
     dma: sweep128h_dma_kernel (ZH_S128H_DMA=1), the same tiles through LDS-DMA"""
-    if dma:
-        monkeypatch.setenv("ZH_S128H_DMA", "1")
-    else:
-        monkeypatch.delenv("ZH_S128H_DMA", raising=False)
+    # lean: sweep128h_lean_kernel + sweep128h_boundary_kernel (round 6, the default); r5: sweep128h_kernel; dma: sweep128h_dma_kernel
+    for var, val in (("ZH_S128H_DMA", "1" if variant == "dma" else None), ("ZH_S128H_KERNEL", "r5" if variant == "r5" else None)):
+        if val:
+            monkeypatch.setenv(var, val)
+        else:
+            monkeypatch.delenv(var, raising=False)
     d, n, M, T, k, B = 128, 8000, 600, 6, 10, 48
     rng = np.random.default_rng(77 + kind)
     X = zo.synth_rows(n, d, kind=kind)

@@ -1309,21 +1309,42 @@ __device__ __forceinline__ uint32_t row_newbcast(uint32_t v) {  // every lane: t
 // the four row-load instructions of tile T of a chunk whose ids the lanes hold as lane (h, c) = flat row 4 c + h: instruction i = rows 4 (4 T + i) + h
 template <int T>
 __device__ __forceinline__ void issue_lean_tile(const u32x4v *__restrict__ Xh, uint32_t ids, uint32_t c16, u32x4v (&R)[4]) {
+#if defined(ZH_S128L_EXP) && ZH_S128L_EXP == 3  // plain (temporal) row loads
+    R[0] = Xh[(size_t)row_newbcast<4 * T + 0>(ids) * 16 + c16];
+    R[1] = Xh[(size_t)row_newbcast<4 * T + 1>(ids) * 16 + c16];
+    R[2] = Xh[(size_t)row_newbcast<4 * T + 2>(ids) * 16 + c16];
+    R[3] = Xh[(size_t)row_newbcast<4 * T + 3>(ids) * 16 + c16];
+#else
     R[0] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 0>(ids) * 16 + c16);
     R[1] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 1>(ids) * 16 + c16);
     R[2] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 2>(ids) * 16 + c16);
     R[3] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 3>(ids) * 16 + c16);
+#endif
 }
+// Is the full chunk of flat rows r0 .. r0 + 63 inside ONE group?  (r0 a multiple of 64.)  THE predicate that splits a launch's chunks between
+// sweep128h_lean_kernel (true) and sweep128h_boundary_kernel (false): every chunk is scored by exactly one of them.
+__device__ __forceinline__ bool lean_chunk(uint64_t r0, uint32_t cnt, const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                           const uint32_t *__restrict__ waveGroup, uint32_t &g, uint32_t &within0) {
+    if (!waveGroup || cnt != 64) return false;
+    g = waveGroup[r0 >> 6];
+    const uint64_t off = groupRowOff[g];
+    const uint64_t nxt = (uint64_t)g + 1 < n_groups ? groupRowOff[g + 1] : ~0ull;
+    within0 = (uint32_t)(r0 - off);
+    return nxt >= r0 + 64;
+}
+#ifndef ZH_S128L_EXP
+#define ZH_S128L_EXP 0     // timing experiments on the lean kernel (profiles/r06_sweep128h_experiments.txt); 0 = the shipped form
+#endif
 #ifndef ZH_S128L_WAVES
-#define ZH_S128L_WAVES 4   // waves per SIMD the register allocation is held to (A/B)
+#define ZH_S128L_WAVES 5   // waves per SIMD the register allocation is held to (A/B)
 #endif
 template <int CH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZH_S128L_WAVES, ZH_S128L_WAVES)))
 void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
-                                                              const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
-                                                              uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
-                                                              const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
-                                                              uint64_t *__restrict__ iv) {
+                           const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                           uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                           const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                           uint64_t *__restrict__ iv) {
     __shared__ u32x4v rows_lds[4][16 * 16];  // per wave: ONE tile = 16 rows x 16 pieces of 16 bytes, piece p of row R at R * 16 + (p ^ R)
     const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1334,18 +1355,153 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
     f16x8 Aq[4];
 #pragma unroll
     for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t a_fast_g = 0xFFFFFFFFu;   // fast form: the group whose queries A holds (row m = slot m >> 2)
-    uint32_t a_g0 = 0xFFFFFFFFu;       // general form: A holds groups a_g0 .. a_g0 + 3 (row m = slot m & 3 of group a_g0 + (m >> 2))
+    uint32_t a_g = 0xFFFFFFFFu;   // the group whose queries A holds: row m = slot m & 3, zero past gsize
     const float inv2 = inv * inv;
     const uint32_t diag_src = (((c16 >> 2) << 4) | c16) << 2;  // ds_bpermute address of lane (c16, c16 >> 2): where G[c16][c16] lives
     const bool c_odd = (c16 & 1u) != 0, c_up = (c16 & 2u) != 0;  // which of a lane's four Gram entries sits on the diagonal: register c16 & 3
     u32x4v R[4];
+    bool carried = false;          // the previous chunk left THIS chunk's first tile travelling in R and its ids in `ids`
+    uint32_t ids = 0;              // lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
+    uint32_t g = 0, within0 = 0;   // the chunk's group and its first row's position in the group (wave-uniform)
+    for (int c = 0; c < CH; c++) {
+        const uint64_t r0 = r_first + 64ull * c;
+        if (r0 >= R_grouped) break;
+        if (!carried) {
+            uint32_t g_v, w_v;
+            const bool fast = lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
+            if (!fast) continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_v);
+            within0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_v);
+        }
+        const ZhGroup *gr = groups + g;
+        const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
+        if (!carried) {
+            const uint32_t w = within0 + 4u * c16 + h;
+            ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+            issue_lean_tile<0>(Xh, ids, c16, R);
+        }
+        if (g != a_g) {  // (wave-uniform) A's row m = query slot m & 3 of group g, zero past gsize
+            a_g = g;
+            const bool on = (c16 & 3u) < gsize;
+            const uint32_t b = on ? gr->b[c16 & 3u] : 0u;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        // the next chunk: entirely inside the same group?  Then its ids are requested now and its first tile behind this chunk's last one
+        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
+        uint32_t nxt_ids = 0;
+        if (next_fast) {
+            const uint32_t w = within0 + 64u + 4u * c16 + h;
+            nxt_ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+        }
+        // Every lane (c16, h) of a tile holds stored row c16 against ALL four slots (accumulator j = slot j, whatever h): the lanes of 16-lane row
+        // h keep tile h's, so that after the chunk's four tiles lane l holds flat row l of the chunk -- ONE 512-byte run per slot and chunk
+        // instead of a 128-byte run per slot and tile (small scattered writes among the row reads cost HBM more than their bytes:
+        // profiles/r06_sweep128h_experiments.txt)
+        float res[4] = {0.f, 0.f, 0.f, 0.f}, res_a2 = 0.f;
+        auto tile = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + h;
+                tl[rr * 16 + (c16 ^ rr)] = R[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (t < 3) issue_lean_tile<(t + 1) & 3>(Xh, ids, c16, R);
+            else if (next_fast) issue_lean_tile<0>(Xh, nxt_ids, c16, R);
+            f16x8 Bf[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4v dsum = {0.f, 0.f, 0.f, 0.f}, gram = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], dsum, 0, 0, 0);
+                gram = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[st], Bf[st], gram, 0, 0, 0);
+            }
+            const float dg_lo = c_odd ? gram[1] : gram[0], dg_hi = c_odd ? gram[3] : gram[2], dg = c_up ? dg_hi : dg_lo;
+            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)diag_src, __float_as_int(dg)));
+            const bool keep = h == (uint32_t)t;
+#pragma unroll
+            for (int j = 0; j < 4; j++) res[j] = keep ? dsum[j] : res[j];
+            res_a2 = keep ? a2 : res_a2;
+        };
+        tile(std::integral_constant<int, 0>{});
+        tile(std::integral_constant<int, 1>{});
+        tile(std::integral_constant<int, 2>{});
+        tile(std::integral_constant<int, 3>{});
+        {
+            const uint32_t a2b = __float_as_uint(res_a2 * inv2);
+            uint64_t *const dst = iv + within0 + lane;  // slot j's results of the chunk: its key slice, positions within0 .. within0 + 63
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)j < gsize) {
+                    const uint64_t v = ((uint64_t)a2b << 32) | __float_as_uint(res[j] * inv);
+#if ZH_S128L_EXP == 1    // timing experiment (results invalid): no result stores
+                    if (res_a2 == 123456.789f) dst[gr->key_off[j]] = v;
+#elif ZH_S128L_EXP == 7  // timing experiment (results invalid): every run starts on a 128-byte line
+                    __builtin_nontemporal_store(v, iv + ((gr->key_off[j] + within0) & ~15ull) + lane);
+#elif ZH_S128L_EXP == 8  // timing experiment (results invalid): the runs land in 512 KiB that stay in the L2s
+                    __builtin_nontemporal_store(v, iv + (wave & 1023u) * 64 + lane);
+#elif ZH_S128L_EXP == 2  // plain (write-back) stores
+                    dst[gr->key_off[j]] = v;
+#else
+                    __builtin_nontemporal_store(v, dst + gr->key_off[j]);
+#endif
+                }
+        }
+        carried = next_fast;
+        if (next_fast) { ids = nxt_ids; within0 += 64; }
+    }
+}
 
-    // ---------------- the general form: one chunk, per-lane groups (the body of sweep128h_kernel, without a look at the next chunk) ----------------
-    auto general_chunk = [&](uint64_t r0, uint32_t cnt) {
+// The chunks lean_chunk() turns down -- a group boundary inside the 64 rows, or the launch's short last chunk: ~1 in 70 with leaves of thousands of
+// rows -- in the general per-lane form of sweep128h_kernel, one chunk at a time.  A wave looks at 64 chunks (a lane each: two loads) and
+// works through the ones that are its business; |x^|^2 from the Gram diagonal here too.
+__global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
+                                                                  const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                                                                  uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                                                                  const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                                                                  uint64_t *__restrict__ iv) {
+    __shared__ u32x4v rows_lds[4][16 * 16];
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t n_chunks = (R_grouped - row_begin + 63) >> 6;
+    if (wave * 64 >= n_chunks) return;
+    uint64_t todo;
+    {
+        const uint64_t ci = wave * 64 + lane;
+        bool mine = false;
+        if (ci < n_chunks) {
+            const uint64_t r0 = row_begin + (ci << 6);
+            uint32_t g_v, w_v;
+            mine = !lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
+        }
+        todo = __ballot(mine);
+    }
+    if (!todo) return;
+    u32x4v *tl = rows_lds[wid];
+    const float inv2 = inv * inv;
+    const uint32_t diag_src = (((c16 >> 2) << 4) | c16) << 2;
+    const bool c_odd = (c16 & 1u) != 0, c_up = (c16 & 2u) != 0;
+    f16x8 Aq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t a_g0 = 0xFFFFFFFFu;  // A holds groups a_g0 .. a_g0 + 3: row m = slot m & 3 of group a_g0 + (m >> 2)
+    u32x4v R[4];
+    while (todo) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t r0 = row_begin + ((wave * 64 + bit) << 6);
+        const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
         uint32_t my_g, my_id, my_within;
         resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
-        a_fast_g = 0xFFFFFFFFu;
         uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};
         auto issue_tile = [&](uint32_t t) {
 #pragma unroll
@@ -1373,7 +1529,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
                 const uint4 *gq = reinterpret_cast<const uint4 *>(groups + rg);
                 const uint4 g0 = gq[0], k01 = gq[2], k23 = gq[3];
                 c_rg = rg;
-                c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;
+                c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;  // (key slices are < 2^36: the four high nibbles and gsize share a word)
                 c_hi = (k01.y & 15u) | ((k01.w & 15u) << 4) | ((k23.y & 15u) << 8) | ((k23.w & 15u) << 12) | (g0.z << 16);
             }
             if (t + 1 < ntile) issue_tile(t + 1);
@@ -1415,111 +1571,47 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
                 }
             }
         }
-    };
-
-    // ---------------- the chunks of this wave ----------------
-    bool carried = false;          // the fast form left the NEXT chunk's first tile travelling in R and its ids in `ids`
-    uint32_t ids = 0;              // fast form: lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
-    uint32_t g = 0, within0 = 0;   // fast form: the chunk's group and its first row's position in the group (wave-uniform)
-    for (int c = 0; c < CH; c++) {
-        const uint64_t r0 = r_first + 64ull * c;
-        if (r0 >= R_grouped) break;
-        const uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
-        bool fast = carried;
-        if (!carried && waveGroup && cnt == 64) {
-            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)waveGroup[r0 >> 6]);
-            const uint64_t off = groupRowOff[g];
-            const uint64_t nxt = (uint64_t)g + 1 < n_groups ? groupRowOff[g + 1] : ~0ull;
-            fast = nxt >= r0 + 64;
-            within0 = (uint32_t)(r0 - off);
-        }
-        if (!fast) { general_chunk(r0, cnt); carried = false; continue; }
-        const ZhGroup *gr = groups + g;
-        const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
-        if (!carried) {
-            const uint32_t w = within0 + 4u * c16 + h;
-            ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
-            issue_lean_tile<0>(Xh, ids, c16, R);
-        }
-        if (g != a_fast_g) {  // (wave-uniform) A's row m = query slot m >> 2 of group g, zero past gsize
-            a_fast_g = g; a_g0 = 0xFFFFFFFFu;
-            const bool on = (c16 >> 2) < gsize;
-            const uint32_t b = on ? gr->b[c16 >> 2] : 0u;
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
-                Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-        // where this lane's results of the chunk go: slot h's key slice, position within0 + 16 t + c16
-        uint64_t *const dst = iv + gr->key_off[h] + within0 + c16;
-        // the next chunk: entirely inside the same group?  Then its ids are requested now and its first tile behind this chunk's last one
-        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
-        uint32_t nxt_ids = 0;
-        if (next_fast) {
-            const uint32_t w = within0 + 64u + 4u * c16 + h;
-            nxt_ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
-        }
-        auto tile = [&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t rr = 4u * i + h;
-                tl[rr * 16 + (c16 ^ rr)] = R[i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if constexpr (t < 3) issue_lean_tile<(t + 1) & 3>(Xh, ids, c16, R);
-            else if (next_fast) issue_lean_tile<0>(Xh, nxt_ids, c16, R);
-            f16x8 Bf[4];
-#pragma unroll
-            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            f32x4v dsum = {0.f, 0.f, 0.f, 0.f}, gram = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], dsum, 0, 0, 0);
-                gram = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[st], Bf[st], gram, 0, 0, 0);
-            }
-            const float dg_lo = c_odd ? gram[1] : gram[0], dg_hi = c_odd ? gram[3] : gram[2], dg = c_up ? dg_hi : dg_lo;
-            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)diag_src, __float_as_int(dg)));
-            if (h < gsize)
-                __builtin_nontemporal_store(((uint64_t)__float_as_uint(a2 * inv2) << 32) | __float_as_uint(dsum[0] * inv), dst + 16 * t);
-        };
-        tile(std::integral_constant<int, 0>{});
-        tile(std::integral_constant<int, 1>{});
-        tile(std::integral_constant<int, 2>{});
-        tile(std::integral_constant<int, 3>{});
-        carried = next_fast;
-        if (next_fast) { ids = nxt_ids; within0 += 64; }
     }
 }
 
+#ifndef ZH_S128L_CH
+#define ZH_S128L_CH 4   // 64-row chunks per wave of the lean kernel (A/B)
+#endif
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
     constexpr int CH = 4;
     const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+    // ZH_S128H_KERNEL (read per call: tests switch it): unset / "lean" = the round-6 kernels; "r5" = the round-5 register-staged kernel;
+    // ZH_S128H_DMA=1: the LDS-DMA kernel, two tiles in flight per wave -- measured EQUAL to the register-staged one (1.528-1.533 against
+    // 1.504-1.523 ms per launch on one box, profiles/r05_ab_sweep128h_dma.txt)
+    const char *dma_e = getenv("ZH_S128H_DMA"), *kern_e = getenv("ZH_S128H_KERNEL");
+    const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r', lean = !dma && !r5;
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         const uint64_t w = (r_end - r + 64 * CH - 1) / (64 * CH), blocks = (w + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        // ZH_S128H_DMA=1 (read per launch: tests switch it): the LDS-DMA kernel, two tiles in flight per wave -- measured EQUAL to the register-staged
-        // one (1.528-1.533 against 1.504-1.523 ms per launch on one box, profiles/r05_ab_sweep128h_dma.txt): the sweep is not bound by what a wave has in flight
-        // ZH_S128H_KERNEL (read per launch: tests switch it): unset / "lean" = the round-6 kernel; "r5" = the round-5 register-staged kernel
-        const char *dma_e = getenv("ZH_S128H_DMA"), *kern_e = getenv("ZH_S128H_KERNEL");
-        const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r';
-        if (!dma && !r5)
-            hipLaunchKernelGGL((sweep128h_lean_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
-                               dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
-        else if (!dma)
+        if (lean) {
+            const uint64_t wl = (r_end - r + 64 * ZH_S128L_CH - 1) / (64 * ZH_S128L_CH);
+            hipLaunchKernelGGL((sweep128h_lean_kernel<ZH_S128L_CH>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv,
+                               dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
+        } else if (!dma)
             hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                                dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
         else
             hipLaunchKernelGGL((sweep128h_dma_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                                dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
     }
+#if ZH_S128L_EXP != 5    // (5: timing experiment without the boundary kernel, results invalid)
+    if (lean) {
+        // the chunks that cross a group boundary, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
+        // looks at 64 chunks.  Chunk boundaries are absolute (every launch above starts on a multiple of 256 rows), so both kernels see the same chunks
+        const uint64_t bw = ((R_grouped + 63) / 64 + 63) / 64, bb = (bw + 3) / 4;
+        if (bb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(sweep128h_boundary_kernel, dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                           dGroupRowOff, n_groups, dWaveGroup, dLeafIds, (uint64_t)0, R_grouped, dIv);
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -1525,9 +1525,13 @@ __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__
                                                         uint64_t *__restrict__ keys, const uint32_t *__restrict__ run_if) {
     static_assert(KIND == K_L2 || KIND == K_COS, "the half-wave sweep covers the two simsimd-path kinds");
     if (run_if && *run_if == 0) return;  // (the redo behind a half-width sweep whose lists did not run over: zh_approx.hip)
+    // A PREDICATED launch (run_if) is a small grid whose blocks stride over the work: when the predicate is zero -- all but never -- a few
+    // thousand waves look at it and leave, instead of one wave per 256 rows (0.1 ms per 25M-row launch, 8 % of the half-width sweep it stands
+    // behind: profiles/r06_sweep128h_experiments.txt).  An ordinary launch has a block per unit and runs the body once.
+    for (uint64_t blk_i = blockIdx.x;; blk_i += gridDim.x) {
     const uint32_t lane = threadIdx.x & 63, hl = lane & 31;
     const bool up = lane >= 32;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = blk_i * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint64_t r0 = row_begin + wave * (64 * CH);
     if (r0 >= R_grouped) return;
     uint32_t cnt = (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64);
@@ -1625,6 +1629,8 @@ __global__ __launch_bounds__(256) void sweep128_kernel(const float *__restrict__
         } else
             resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within, &my_off, &my_len);
     }
+    if (!run_if) return;
+    }
 }
 
 uint64_t zh_sweep_rows_per_launch(uint32_t d) {
@@ -1652,7 +1658,8 @@ static hipError_t launch_sweep_g(const SweepArgs &a) {
     // One batch is issued as several launches of ~ZH_SWEEP_LAUNCH_BYTES each (about 2 ms of HBM time): a single
     // 18-ms dispatch keeps its dispatch pipe busy until its last workgroup is issued, and kernels of other
     // queues that share the pipe (the next batch's hash / walk, RCCL) would wait that long.
-    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(a.d);
+    // (a PREDICATED sweep -- the redo behind a half-width sweep, all but never run -- is ONE launch of a small striding grid for the whole batch)
+    const uint64_t rows_per_launch = a.dRunIf ? (a.R_grouped + 255) / 256 * 256 : zh_sweep_rows_per_launch(a.d);
     for (uint64_t r = 0; r < a.R_grouped; r += rows_per_launch) {
         uint64_t r_end = r + rows_per_launch < a.R_grouped ? r + rows_per_launch : a.R_grouped;
         uint64_t waves = (r_end - r + 63) / 64;
@@ -1663,8 +1670,8 @@ static hipError_t launch_sweep_g(const SweepArgs &a) {
             if (v128 > 0) {
                 // ZH_SWEEP128_CHUNKS (A/B): 64-row chunks per wave, 1 = the round-2 kernel's shape
                 static const int ch128 = [] { const char *e = getenv("ZH_SWEEP128_CHUNKS"); return e ? atoi(e) : 4; }();
-#define ZH_S128(RG_, CH_) do { const uint64_t w_ = (r_end - r + 64 * CH_ - 1) / (64 * CH_);                                          \
-                               hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true, CH_>), dim3((uint32_t)((w_ + 3) / 4)), blk, 0, a.s, a.dX, a.dQ, a.dQQ, \
+#define ZH_S128(RG_, CH_) do { const uint64_t w_ = (r_end - r + 64 * CH_ - 1) / (64 * CH_), b_ = (w_ + 3) / 4;                        \
+                               hipLaunchKernelGGL((sweep128_kernel<KIND, G, RG_, true, CH_>), dim3((uint32_t)(a.dRunIf && b_ > 2048 ? 2048 : b_)), blk, 0, a.s, a.dX, a.dQ, a.dQQ, \
                                                   a.dGroups, a.dGroupRowOff, a.n_groups, a.dWaveGroup, a.dLeafIds, r, r_end, a.metric, a.param, a.dKeys, a.dRunIf); } while (0)
                 if (ch128 == 1) ZH_S128(8, 1);
                 else if (ch128 == 8) ZH_S128(8, 8);
