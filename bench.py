@@ -582,10 +582,15 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     if not scan and d == 128:
         kname = "sweep128_kernel<%d, ...>" % kind  # the half-wave kernel of the 512-byte rows
     leaf_half = half and st.get("approx_scan", 0) == 3  # d = 128, leaf by leaf from the fp16 copy of the rows (sweep128h_kernel)
+    fused = leaf_half and st.get("approx_fused", 0) == 1
     if leaf_half:
-        kname = "sweep128h_kernel<4>"
-        bytes_alg = 2.0 * d * rows_per_launch * uniq_frac + 12.0 * rows_per_launch + 2.0 * d * B / launches_per_batch
-        bytes_nosharing = (2.0 * d + 12.0) * rows_per_launch
+        # round 6: sweep128h_lean_kernel (+ sweep128h_boundary_kernel for the chunks that cross a leaf group).  FUSED (long leaves, top_k <= 64): the
+        # intervals, the bounds and the queries' candidate lists are made inside the sweep -- no 8-byte result per scored row is written (or read
+        # back by a select pass), so the algorithmic bytes per scored row are the row (2 d, once per distinct leaf group) and its 4-byte leaf id
+        per_row = 4.0 if fused else 12.0
+        kname = "sweep128h_lean_kernel<16, KINDA> (fused: intervals + bounds + lists in the sweep)" if fused else "sweep128h_lean_kernel<4, -1>"
+        bytes_alg = 2.0 * d * rows_per_launch * uniq_frac + per_row * rows_per_launch + 2.0 * d * B / launches_per_batch
+        bytes_nosharing = (2.0 * d + per_row) * rows_per_launch
     elif half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
         if st.get("approx_scan", 0) == 2:

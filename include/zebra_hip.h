@@ -179,6 +179,8 @@ typedef struct zh_stats_t {
     uint64_t scan_order_share_permille; /* ... (adjacent rows, tree) combinations in the same leaf under the kept order, per thousand */
     uint64_t row_copy_bytes;         /* device memory the index holds for fp16 copies of its stored rows (the half-width sweeps: zh_set_sweep_mode);
                                      * 0 until a batch has used one, and with modes 1 / 2 / 5 */
+    uint64_t approx_fused;           /* 1: approx_scan 3 and the most recent batch's sweep was FUSED -- intervals, bounds and the queries' candidate
+                                     * lists inside the sweep kernel (no raw pairs written, no select pass; round 6) */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -14,6 +14,18 @@ pytestmark = pytest.mark.gpu
 from oracle import zebra_oracle as zo  # noqa: E402  (the checker)
 
 
+def set_s128h_variant(monkeypatch, variant):
+    """fused: sweep128h_lean_kernel<CH, KINDA> + sweep128h_boundary_kernel<KINDA> with intervals, bounds and the queries' lists inside the sweep
+    (round 6; chosen by the library for long leaves, forced here: ZH_S128H_FUSED=1; top_k <= 64); lean: the same kernels writing raw pairs for
+    select_tau_kernel (ZH_S128H_FUSED=0); r5: sweep128h_kernel (ZH_S128H_KERNEL=r5); dma: sweep128h_dma_kernel (ZH_S128H_DMA=1)"""
+    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"}}[variant]
+    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA"):
+        if var in env:
+            monkeypatch.setenv(var, env[var])
+        else:
+            monkeypatch.delenv(var, raising=False)
+
+
 @pytest.fixture(scope="module")
 def za():
     import zebra_amd
@@ -187,19 +199,14 @@ LEAF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])
+@pytest.mark.parametrize("variant", ["fused", "lean", "r5", "dma"])
 @pytest.mark.parametrize("n,M,T,k,B,kind", LEAF_CASES)
 def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, B, kind, variant):
     """d = 128, leaf by leaf at half width on the matrix cores (sweep128h_kernel, zh_set_sweep_mode 6): an fp16 copy of the rows under one
     scale, the queries of up to four groups as the A operand, 16 stored rows as B; same intervals, same stages behind it.  dma: the variant
     whose row tiles travel straight into LDS (sweep128h_dma_kernel, ZH_S128H_DMA=1: two tiles in flight per wave, explicit waits)"""
     d = 128
-    # lean: sweep128h_lean_kernel + sweep128h_boundary_kernel (round 6, the default); r5: sweep128h_kernel; dma: sweep128h_dma_kernel
-    for var, val in (("ZH_S128H_DMA", "1" if variant == "dma" else None), ("ZH_S128H_KERNEL", "r5" if variant == "r5" else None)):
-        if val:
-            monkeypatch.setenv(var, val)
-        else:
-            monkeypatch.delenv(var, raising=False)
+    set_s128h_variant(monkeypatch, variant)
     X = zo.synth_rows(n, d, kind=kind)
     Q = zo.synth_queries(B, d, n, kind=kind)
     f = zo.Forest.build(X, M, T)
@@ -211,12 +218,15 @@ def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, 
         st = check(ix, f, Q, k, m, om, omode)
         assert st["approx_scan"] == 3 and st["table_scan"] == 0, (om, omode, st)
         assert st["approx_fallbacks_accum"] == 0, st
+        assert st["approx_fused"] == (1 if variant == "fused" and k <= 64 else 0), st
     ix.close()
 
 
-def test_leaf_major_half_width_adversarial_rows_appends_and_overflow(za, monkeypatch):
+@pytest.mark.parametrize("variant", ["fused", "lean"])
+def test_leaf_major_half_width_adversarial_rows_appends_and_overflow(za, monkeypatch, variant):
     """rows that do not survive the table's common scale (tiny, huge, non-finite: stored as NaNs -> the exact path), ties, appended rows on a
     larger scale (the copy is re-made), and lists that run over (redone by the f32 leaf-major sweep on the device)"""
+    set_s128h_variant(monkeypatch, variant)
     rng = np.random.default_rng(11)
     n, d, M, T, k, B = 6000, 128, 800, 6, 20, 48
     X = zo.synth_rows(2 * n, d, kind=0)

@@ -208,6 +208,10 @@ def test_fuzz_half_width_scan(seed):
     ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
     ix.add(X)
     assert zo.canonical_forest(ix.get_forest(), d) == zo.canonical_forest(f.arrays(), d), (d, n, M, T)
+    if seed % 2:  # d = 128 leaf by leaf: every other case FUSED (intervals, bounds and lists inside the sweep; the library picks it for long leaves only)
+        os.environ["ZH_S128H_FUSED"] = "1"
+    else:
+        os.environ.pop("ZH_S128H_FUSED", None)
     ix.set_sweep_mode("approx-valu" if seed % 3 == 2 else ("leaf-half" if d == 128 and seed % 3 == 1 else "approx"))  # (every third case: the VALU kernel on the
     # f32 rows instead of the matrix cores; d = 128, every third: leaf by leaf at half width)
     ix.set_hash_mode("dense")
@@ -221,4 +225,55 @@ def test_fuzz_half_width_scan(seed):
         for b in range(B):
             c = int(oc[b])
             assert (keys[b, :c] == ok[b, :c]).all() and (ids[b, :c] == oi[b, :c]).all(), (seed, d, n, M, T, k, om, omode, b)
+    ix.close()
+    os.environ.pop("ZH_S128H_FUSED", None)
+
+
+_ffirst, _fcount = (int(x) for x in os.environ.get("ZH_FUZZ_FUSED_SEEDS", "0:14").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_ffirst, _ffirst + _fcount))
+def test_fuzz_fused_leaf_sweep(seed, monkeypatch):
+    """d = 128, leaf by leaf at half width with the FUSED sweep forced (ZH_S128H_FUSED=1: intervals, per-chunk bounds and the queries' lists inside
+    sweep128h_lean_kernel / sweep128h_boundary_kernel; the library itself picks it for long leaves only): leaves from a handful of rows (every chunk
+    a boundary chunk, backup visits -> the exact path) to the whole table (hundreds of chunks per visit, many queries per leaf), top_k up to 64,
+    ties, duplicates, all four simsimd-path keys, windows of several queries per leaf.  ZH_FUZZ_FUSED_SEEDS=first:count soaks."""
+    import zebra_amd as za
+    monkeypatch.setenv("ZH_S128H_FUSED", "1")
+    rng = np.random.default_rng(99000 + seed)
+    d = 128
+    n = int(rng.integers(500, 30000))
+    M = int(rng.choice([8, 30, 100, 400, 1500, 6000, 40000]))
+    T = int(rng.choice([1, 4, 8, 15]))
+    k = int(rng.choice([1, 3, 10, 20, 64]))
+    B = int(rng.integers(1, 200))
+    kind = int(rng.choice([0, 1, 1, 2]))
+    X = zo.synth_rows(n, d, seed=seed, kind=kind)
+    Q = zo.synth_queries(B, d, n, seed_rows=seed, kind=kind)
+    if rng.random() < 0.4:
+        X[rng.integers(0, n, 16)] = X[0]
+    if rng.random() < 0.3:
+        X = np.round(X).astype(np.float32)
+        Q = np.round(Q).astype(np.float32)
+    if rng.random() < 0.3:
+        Q[0] = X[int(rng.integers(0, n))]
+    if rng.random() < 0.2:
+        Q[B - 1] = 0.0
+    f = zo.Forest.build(X, M, T, seed=seed)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), seed=seed)
+    ix.add(X)
+    ix.set_sweep_mode("leaf-half")
+    ix.set_hash_mode("dense")
+    fused = 0
+    for m, om, omode in ((za.L2SquaredDistance(), zo.L2SQ, 0), (za.L2Distance(), zo.L2, 0), (za.CosineDistance(True), zo.COSINE, zo.PARITY),
+                         (za.CosineDistance(False), zo.COSINE, zo.CORRECTED)):
+        ids, keys, counts = ix.search_batch(Q, k, m)
+        st = ix.stats()
+        fused += st["approx_fused"]
+        oi, ok, oc = f.search_batch(Q, k, om, omode)
+        assert (counts == oc).all(), (seed, n, M, T, k, B, om, omode)
+        for b in range(B):
+            c = int(oc[b])
+            assert (keys[b, :c] == ok[b, :c]).all() and (ids[b, :c] == oi[b, :c]).all(), (seed, n, M, T, k, B, om, omode, b, st)
+    assert fused >= 1 or ix.stats()["approx_scan"] != 3, (seed, ix.stats())
     ix.close()

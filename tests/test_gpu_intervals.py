@@ -18,6 +18,18 @@ pytestmark = pytest.mark.gpu
 
 from oracle import zebra_oracle as zo  # noqa: E402  (the checker)
 
+
+def set_s128h_variant(monkeypatch, variant):
+    """fused: sweep128h_lean_kernel<CH, KINDA> + sweep128h_boundary_kernel<KINDA> with intervals, bounds and the queries' lists inside the sweep
+    (round 6; chosen by the library for long leaves, forced here: ZH_S128H_FUSED=1; top_k <= 64); lean: the same kernels writing raw pairs for
+    select_tau_kernel (ZH_S128H_FUSED=0); r5: sweep128h_kernel (ZH_S128H_KERNEL=r5); dma: sweep128h_dma_kernel (ZH_S128H_DMA=1)"""
+    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"}}[variant]
+    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA"):
+        if var in env:
+            monkeypatch.setenv(var, env[var])
+        else:
+            monkeypatch.delenv(var, raising=False)
+
 U = 2.0 ** -24
 
 
@@ -242,17 +254,12 @@ def test_valu_scan_intervals_contain_the_key(za, torch, d):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])
+@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])  # (the fused sweep writes no raw pairs: zh_debug_keep_raw keeps it off)
 @pytest.mark.parametrize("kind", [0, 1])
 def test_leaf_major_half_width_intervals_contain_the_key(za, torch, monkeypatch, kind, variant):
     """sweep128h_kernel (d = 128, zh_set_sweep_mode 6): a row-major fp16 copy under ONE table scale (rows it does not serve: NaNs -> the exact path);
     dma: sweep128h_dma_kernel (ZH_S128H_DMA=1), the same tiles through LDS-DMA"""
-    # lean: sweep128h_lean_kernel + sweep128h_boundary_kernel (round 6, the default); r5: sweep128h_kernel; dma: sweep128h_dma_kernel
-    for var, val in (("ZH_S128H_DMA", "1" if variant == "dma" else None), ("ZH_S128H_KERNEL", "r5" if variant == "r5" else None)):
-        if val:
-            monkeypatch.setenv(var, val)
-        else:
-            monkeypatch.delenv(var, raising=False)
+    set_s128h_variant(monkeypatch, variant)
     d, n, M, T, k, B = 128, 8000, 600, 6, 10, 48
     rng = np.random.default_rng(77 + kind)
     X = zo.synth_rows(n, d, kind=kind)

@@ -140,6 +140,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     // ... with half-width queries (zh_approx.hip): intervals from the scan, the reference's keys for the few rows they cannot
     // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
+    bool approx_fused = false;  // (approx_leaf, round 6: intervals, bounds and lists inside the sweep kernel)
     bool approx = false, approx_mfma = false, approx_leaf = false;  // (approx_leaf: the d = 128 leaf-major sweep at half width, sweep128h_kernel)
     uint32_t *h_ap = nullptr;
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
@@ -1880,7 +1881,7 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
     c->nwin = nwin; c->bwin = bwin;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
-    c->approx = false; c->approx_leaf = false; c->approx_mfma = false;
+    c->approx = false; c->approx_leaf = false; c->approx_mfma = false; c->approx_fused = false;
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
@@ -2185,9 +2186,21 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     hipStream_t hs = heavy ? heavy : s;
     if (hs != s) { HIPCHK(hipEventRecord(c->ev_emit, s)); HIPCHK(hipStreamWaitEvent(hs, c->ev_emit, 0)); }
     HIPCHK(hipEventRecord(c->ev_sw0, hs));
+    // d = 128 leaf by leaf at half width: FUSED (intervals, bounds and the queries' lists inside the sweep: no raw pairs, no select pass) when the
+    // leaves are long -- a bound is derived per 64-row chunk that lies inside one leaf group, and the lists must hold what the first waves of a visit
+    // hand on before any bound has spread -- and top_k fits a chunk.  ZH_S128H_FUSED=0 / 1 (read per batch: tests) forbids / forces it;
+    // zh_debug_keep_raw wants the raw pairs
+    c->approx_fused = false;
+    if (c->approx_leaf && k <= 64 && !ix->debug_keep_raw) {
+        const char *fe = getenv("ZH_S128H_FUSED"), *ke = getenv("ZH_S128H_KERNEL"), *de = getenv("ZH_S128H_DMA");
+        const bool lean = !(ke && ke[0] == 'r') && !(de && de[0] == '1');
+        c->approx_fused = lean && (fe ? fe[0] == '1' : tot.rows >= 1024 * std::max<uint64_t>(tot.visits, 1));
+    }
+    const int kinda = c->metric != ZH_COSINE ? 0 : (c->mode == ZH_COSINE_PARITY ? 2 : 1);
     if (c->approx_leaf)
         HIPCHK(zh_launch_sweep128h(ix->row_half128.p, c->wQh.p, ldexpf(1.f, ix->h128_ex - 14), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(),
-                                   tot.groups, c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->wKeys.as<uint64_t>(), hs));
+                                   tot.groups, c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->wKeys.as<uint64_t>(), hs,
+                                   c->approx_fused ? &ap : nullptr, kinda, (uint32_t)k, zh_approx_bound(c->metric, d, 2)));
     else if (c->approx)
         HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, mfma ? scan_row_leaf : ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
                                      c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group, c->metric, c->mode, hs));
@@ -2212,7 +2225,8 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
             HIPCHK(hipMemcpyAsync(c->wRaw.p, c->wKeys.p, tot.rows * 8, hipMemcpyDeviceToDevice, s));
             c->dbg_raw = true;
         }
-        HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, c->metric, c->mode, d, s));
+        if (c->approx_fused) HIPCHK(zh_launch_exact_register(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, ap, s));
+        else HIPCHK(zh_launch_select_interval(c->wVisits.as<ZhVisit>(), tot.visits, (uint32_t)k, f.leaf_ids, ap, c->metric, c->mode, d, s));
         HIPCHK(hipEventRecord(c->ev[4], s));
         HIPCHK(zh_launch_final_interval(c->wVisits.as<ZhVisit>(), ix->X.as<float>(), d, c->dQ, c->wQQ.as<float>(), (uint32_t)B, (uint32_t)k,
                                         f.leaf_ids, c->metric, c->mode, ix->opt.id_base, ap, dOutIds, dOutKeys, dOutCounts, ix->max_leaf_len, s));
@@ -2300,6 +2314,7 @@ int ctx_wait(zh_search_ctx *c) {
     st.table_scan = c->scan && !pf ? 1 : 0;
     const bool apx = c->approx && !pf;
     st.approx_scan = apx ? (c->approx_leaf ? 3 : (c->approx_mfma ? 2 : 1)) : 0;
+    st.approx_fused = apx && c->approx_leaf && c->approx_fused ? 1 : 0;
     st.approx_exact_visits = apx ? c->h_ap[0] : 0;
     st.approx_survivors = apx ? c->h_ap[3] : 0;
     st.approx_list_entries = apx ? c->h_ap[4] : 0;

@@ -1302,6 +1302,91 @@ __global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__rest
 // ~45 instructions per tile.  A chunk that crosses a group boundary (or the launch's last, short one) runs the general per-lane form of the
 // kernel above, one chunk at a time.  Same raw pairs up to the summation order inside the matrix pipe (covered by zh_approx_bound's MFMA term,
 // tests/test_gpu_intervals.py) -- the results behind them are bit-identical by construction as before.
+// ---- the fused sweep (round 6).  The stores of the raw pairs -- 3 % of the sweep's bytes -- cost the lean kernel a fifth of its time (0.99 ms per
+// 25M-row launch without them = the bare gather's 6.7 TB/s, 1.23-1.30 with; profiles/r06_sweep128h_experiments.txt), and select_tau_kernel /
+// select_emit_kernel then read them all back (7 ms per window of a cfg5 shard) to keep ~60 per query.  Fused, a chunk's 64 results never leave the
+// wave: per slot (= a visit of the leaf by one query, lsh.rs:290-330)
+//   * the interval of every row (approx_interval: the arithmetic select_tau_kernel applies to the raw pair, same operands, same bits);
+//   * a visit that takes top_k rows of a longer leaf: the wave keeps the top_k SMALLEST hi of the visit's rows it has seen so far (sorted, lane i
+//     the i-th; merged chunk by chunk: topk_merge).  The top_k-th of them is a bound: top_k distinct rows of one leaf have keys at or below it,
+//     hence (each is a candidate or beaten by top_k candidates of its leaf) so have top_k candidates of the query.  atomicMin into the query's
+//     qtau, which every visit of the query reads.  (A bound from one 64-row chunk -- the first form of this kernel -- is the chunk's 16 % quantile
+//     at top_k = 10, and the minimum over chunks tightens slowly: 3900 list entries per query on a cfg5 shard.  The bound only ever certifies what
+//     select_tau_kernel's per-visit tau certifies, from a subset of the visit's rows);
+//   * rows whose lo exceeds the bound are beaten by top_k candidates and can be in no final top_k: everything else joins the query's list
+//     (one atomicAdd per slot and chunk).  Which superset of the survivors the list holds depends on the order the waves ran in; the answer does
+//     not: final_survivors / final_exact / final_topk rank the list's rows by their canonical keys, and a row that is not among its leaf's top_k is
+//     beaten in the list by top_k rows that are;
+//   * a visit that takes the whole leaf (lsh.rs:300-306): rows at or below the query's bound; a visit that takes FEWER than top_k rows of a longer
+//     leaf: membership matters -- its intervals go to iv, where exact_visit_kernel expects them (exact_register_kernel lists the visit).
+// `take` is the group record's byte (join_group): top_k <= 64 < 255 in this form.
+
+// topv: lane i < kk holds the i-th smallest value seen so far (ascending; 0xFFFFFFFF = none yet), lanes >= kk 0xFFFFFFFF.  Merges the 64 values `v`
+// (one per lane) into it; `scratch`: 64 words of wave-private LDS.  Ranks in the union (old before new on ties, lower lane first): only values below
+// the current kk-th can enter, so the loops are as long as the chunk has such values (a handful once the wave has seen a few hundred rows).
+__device__ __forceinline__ void topk_merge(uint32_t &topv, uint32_t v, uint32_t kk, uint32_t lane, uint32_t *scratch) {
+    const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)topv, (int)(kk - 1));
+    const bool isnew = v < bound;
+    const uint64_t nm = __ballot(isnew);
+    if (!nm) return;  // (wave-uniform)
+    uint32_t r_old = lane, r_new = 0;
+    for (uint64_t m = nm; m; m &= m - 1) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+        r_old += x < topv ? 1u : 0u;
+        r_new += (x < v || (x == v && l < lane)) ? 1u : 0u;
+    }
+    for (uint32_t i = 0; i < kk; i++) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)topv, (int)i);
+        r_new += o <= v ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kk && r_old < kk) scratch[r_old] = topv;
+    if (isnew && r_new < kk) scratch[r_new] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    topv = lane < kk ? scratch[lane] : 0xFFFFFFFFu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KINDA>
+__device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint32_t lane, uint32_t bq, uint32_t take, uint32_t glen, uint32_t k_top,
+                                           float Kc, const ZhApprox &ap, uint64_t *__restrict__ iv_slot, uint32_t &topv, uint32_t *scratch) {
+    if (take == 0) return;  // (wave-uniform)
+    const float4 qm = ap.qmeta[bq];
+    const uint64_t w = approx_interval<KINDA>(s, a2, qm, Kc, ap.row_rho, ap.rho_norm);
+    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    if (take < glen && take < k_top) {  // the exact path's visit
+        __builtin_nontemporal_store(w, iv_slot);
+        return;
+    }
+    uint32_t tau = __hip_atomic_load(&ap.qtau[bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau);
+    if (take < glen) {  // top_k rows of a longer leaf
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)topv, (int)(take - 1));
+        topk_merge(topv, hi, take, lane, scratch);
+        const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)topv, (int)(take - 1));
+        if (mine < before && mine < tau && lane == 0) atomicMin(&ap.qtau[bq], mine);
+        if (mine < tau) tau = mine;
+    }
+    const uint64_t m = __ballot(lo <= tau);
+    if (!m) return;
+    const uint32_t M = (uint32_t)__builtin_popcountll(m);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ap.qcount[bq], M);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + M > ap.capq) {
+        if (lane == 0) atomicOr(&ap.ctl[1], 1u);
+        return;
+    }
+    if (lo <= tau) {
+        const size_t o = (size_t)bq * ap.capq + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        ap.list_lo[o] = lo; ap.list_hi[o] = hi; ap.list_id[o] = id;
+    }
+}
+
 template <int N>
 __device__ __forceinline__ uint32_t row_newbcast(uint32_t v) {  // every lane: the value of lane N of its own 16-lane row (DPP, no LDS)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);  // (bound_ctrl: no `old` operand to initialise)
@@ -1338,13 +1423,14 @@ __device__ __forceinline__ bool lean_chunk(uint64_t r0, uint32_t cnt, const uint
 #ifndef ZH_S128L_WAVES
 #define ZH_S128L_WAVES 5   // waves per SIMD the register allocation is held to (A/B)
 #endif
-template <int CH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZH_S128L_WAVES, ZH_S128L_WAVES)))
+// FUSE >= 0 (= approx_interval's KINDA): the FUSED form -- see "the fused sweep" below; FUSE < 0: raw pairs to iv for select_tau_kernel
+template <int CH, int FUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE >= 0 ? 4 : ZH_S128L_WAVES, FUSE >= 0 ? 4 : ZH_S128L_WAVES)))
 void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
                            const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
                            uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
                            const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
-                           uint64_t *__restrict__ iv) {
+                           uint64_t *__restrict__ iv, ZhApprox ap, uint32_t k_top, float Kc) {
     __shared__ u32x4v rows_lds[4][16 * 16];  // per wave: ONE tile = 16 rows x 16 pieces of 16 bytes, piece p of row R at R * 16 + (p ^ R)
     const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1360,6 +1446,10 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
     const uint32_t diag_src = (((c16 >> 2) << 4) | c16) << 2;  // ds_bpermute address of lane (c16, c16 >> 2): where G[c16][c16] lives
     const bool c_odd = (c16 & 1u) != 0, c_up = (c16 & 2u) != 0;  // which of a lane's four Gram entries sits on the diagonal: register c16 & 3
     u32x4v R[4];
+    // fused form: per slot, the top_k smallest hi of the visit's rows this wave has seen (lane i the i-th; reset when the group changes), and where
+    // flat row `lane` of a chunk finds its id (lane (h, c16) holds row 4 c16 + h)
+    uint32_t topv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const uint32_t nat_src = (((lane & 3u) << 4) | (lane >> 2)) << 2;
     bool carried = false;          // the previous chunk left THIS chunk's first tile travelling in R and its ids in `ids`
     uint32_t ids = 0;              // lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
     uint32_t g = 0, within0 = 0;   // the chunk's group and its first row's position in the group (wave-uniform)
@@ -1382,6 +1472,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
         }
         if (g != a_g) {  // (wave-uniform) A's row m = query slot m & 3 of group g, zero past gsize
             a_g = g;
+            topv[0] = topv[1] = topv[2] = topv[3] = 0xFFFFFFFFu;
             const bool on = (c16 & 3u) < gsize;
             const uint32_t b = on ? gr->b[c16 & 3u] : 0u;
 #pragma unroll
@@ -1435,7 +1526,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
         tile(std::integral_constant<int, 1>{});
         tile(std::integral_constant<int, 2>{});
         tile(std::integral_constant<int, 3>{});
-        {
+        if constexpr (FUSE < 0) {
             const uint32_t a2b = __float_as_uint(res_a2 * inv2);
             uint64_t *const dst = iv + within0 + lane;  // slot j's results of the chunk: its key slice, positions within0 .. within0 + 63
 #pragma unroll
@@ -1444,16 +1535,27 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
                     const uint64_t v = ((uint64_t)a2b << 32) | __float_as_uint(res[j] * inv);
 #if ZH_S128L_EXP == 1    // timing experiment (results invalid): no result stores
                     if (res_a2 == 123456.789f) dst[gr->key_off[j]] = v;
+#elif ZH_S128L_EXP == 2  // plain (write-back) stores
+                    dst[gr->key_off[j]] = v;
 #elif ZH_S128L_EXP == 7  // timing experiment (results invalid): every run starts on a 128-byte line
                     __builtin_nontemporal_store(v, iv + ((gr->key_off[j] + within0) & ~15ull) + lane);
 #elif ZH_S128L_EXP == 8  // timing experiment (results invalid): the runs land in 512 KiB that stay in the L2s
                     __builtin_nontemporal_store(v, iv + (wave & 1023u) * 64 + lane);
-#elif ZH_S128L_EXP == 2  // plain (write-back) stores
-                    dst[gr->key_off[j]] = v;
 #else
                     __builtin_nontemporal_store(v, dst + gr->key_off[j]);
 #endif
                 }
+        } else {
+            // ---- the fused sweep: lane l holds flat row l of the chunk against every slot.  Per slot: the interval (select_tau_kernel's arithmetic), the
+            // visit's bound, the rows it cannot rule out straight into the query's list -- nothing else leaves the wave
+            const uint32_t idn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)nat_src, (int)ids);
+            const float a2s = res_a2 * inv2;
+            const uint32_t take4 = gr->take4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)j < gsize)
+                    fused_slot<FUSE>(res[j] * inv, a2s, idn, lane, gr->b[j], (take4 >> (8 * j)) & 255u, glen, k_top, Kc, ap,
+                                     iv + gr->key_off[j] + within0 + lane, topv[j], reinterpret_cast<uint32_t *>(tl));  // (the tile buffer is idle here: the next tile waits in R)
         }
         carried = next_fast;
         if (next_fast) { ids = nxt_ids; within0 += 64; }
@@ -1463,11 +1565,12 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
 // The chunks lean_chunk() turns down -- a group boundary inside the 64 rows, or the launch's short last chunk: ~1 in 70 with leaves of thousands of
 // rows -- in the general per-lane form of sweep128h_kernel, one chunk at a time.  A wave looks at 64 chunks (a lane each: two loads) and
 // works through the ones that are its business; |x^|^2 from the Gram diagonal here too.
+template <int FUSE>
 __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
                                                                   const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
                                                                   uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
                                                                   const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
-                                                                  uint64_t *__restrict__ iv) {
+                                                                  uint64_t *__restrict__ iv, ZhApprox ap, uint32_t k_top, float Kc) {
     __shared__ u32x4v rows_lds[4][16 * 16];
     const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1503,6 +1606,7 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
         uint32_t my_g, my_id, my_within;
         resolve_flat_rows(r0, cnt, lane, groups, groupRowOff, n_groups, waveGroup, leaf_ids, my_g, my_id, my_within);
         uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};
+        uint32_t c_b[4] = {0, 0, 0, 0}, c_take4 = 0, c_len = 0;  // fused form: the rest of the lane's group record
         auto issue_tile = [&](uint32_t t) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -1525,12 +1629,18 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
             const uint32_t fr = 16 * t + c16;
             const uint32_t rg = (uint32_t)__shfl((int)my_g, (int)(fr < cnt ? fr : cnt - 1));
             const uint32_t rw = (uint32_t)__shfl((int)my_within, (int)(fr < cnt ? fr : cnt - 1));
+            const uint32_t rid = (uint32_t)__shfl((int)my_id, (int)(fr < cnt ? fr : cnt - 1));
             if (rg != c_rg) {
                 const uint4 *gq = reinterpret_cast<const uint4 *>(groups + rg);
                 const uint4 g0 = gq[0], k01 = gq[2], k23 = gq[3];
                 c_rg = rg;
                 c_lo[0] = k01.x; c_lo[1] = k01.z; c_lo[2] = k23.x; c_lo[3] = k23.z;  // (key slices are < 2^36: the four high nibbles and gsize share a word)
                 c_hi = (k01.y & 15u) | ((k01.w & 15u) << 4) | ((k23.y & 15u) << 8) | ((k23.w & 15u) << 12) | (g0.z << 16);
+                if constexpr (FUSE >= 0) {
+                    const uint4 gb = gq[1];
+                    c_b[0] = gb.x; c_b[1] = gb.y; c_b[2] = gb.z; c_b[3] = gb.w;
+                    c_take4 = g0.w; c_len = g0.y;
+                }
             }
             if (t + 1 < ntile) issue_tile(t + 1);
             f16x8 Bf[4];
@@ -1565,53 +1675,115 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
                     const uint32_t a2b = __float_as_uint(a2 * inv2);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if ((uint32_t)i < (c_hi >> 16))
-                            __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv),
-                                                        iv + ((((uint64_t)((c_hi >> (4 * i)) & 15u)) << 32) | c_lo[i]) + rw);
+                        if ((uint32_t)i < (c_hi >> 16)) {
+                            uint64_t *const slot = iv + ((((uint64_t)((c_hi >> (4 * i)) & 15u)) << 32) | c_lo[i]) + rw;
+                            if constexpr (FUSE < 0) {
+                                __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(dsum[i] * inv), slot);
+                            } else {
+                                // fused form, a lane at a time (these chunks are ~1 in 70): the interval; the exact path's visits keep theirs in iv;
+                                // everything else joins its query's list unless the query's bound rules it out (no bound is derived here)
+                                const uint32_t take = (c_take4 >> (8 * i)) & 255u, bq = c_b[i];
+                                if (take) {
+                                    const uint64_t w = approx_interval<FUSE>(dsum[i] * inv, a2 * inv2, ap.qmeta[bq], Kc, ap.row_rho, ap.rho_norm);
+                                    if (take < c_len && take < k_top) __builtin_nontemporal_store(w, slot);
+                                    else if ((uint32_t)w <= __hip_atomic_load(&ap.qtau[bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                        const uint32_t pos = atomicAdd(&ap.qcount[bq], 1u);
+                                        if (pos >= ap.capq) atomicOr(&ap.ctl[1], 1u);
+                                        else {
+                                            const size_t o = (size_t)bq * ap.capq + pos;
+                                            ap.list_lo[o] = (uint32_t)w; ap.list_hi[o] = (uint32_t)(w >> 32); ap.list_id[o] = rid;
+                                        }
+                                    }
+                                }
+                            }
+                        }
                 }
             }
         }
     }
 }
 
+// the visits of the exact path -- fewer than top_k rows of a longer leaf -- as select_tau_kernel lists them (the fused sweep has no pass over the visits)
+__global__ __launch_bounds__(256) void exact_register_kernel(const ZhVisit *__restrict__ visits, uint64_t n_visits, uint32_t k_top, ZhApprox ap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_visits) return;
+    const ZhVisit v = visits[i];
+    if (!(v.take && v.take < v.len && v.take < k_top)) return;
+    const uint32_t slot = atomicAdd(&ap.ctl[0], 1u);
+    const uint32_t eb = atomicAdd(&ap.ctl[2], v.len);
+    if (slot >= ap.ex_cap) atomicOr(&ap.ctl[1], 4u);
+    else if ((uint64_t)eb + v.len > ap.ex_rows_cap) { atomicOr(&ap.ctl[1], 8u); ap.ex_visits[slot] = make_uint2(0xFFFFFFFFu, 0u); }
+    else ap.ex_visits[slot] = make_uint2((uint32_t)i, eb);
+    ap.tauv[i] = 0u;
+}
+hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, ZhApprox ap, hipStream_t s) {
+    if (!n_visits) return hipSuccess;
+    if (n_visits > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(exact_register_kernel, dim3((uint32_t)((n_visits + 255) / 256)), dim3(256), 0, s, dVisits, n_visits, k, ap);
+    return hipGetLastError();
+}
+
 #ifndef ZH_S128L_CH
 #define ZH_S128L_CH 4   // 64-row chunks per wave of the lean kernel (A/B)
 #endif
+#ifndef ZH_S128F_CH
+#define ZH_S128F_CH 16  // ... of its fused form: a wave's bound comes from the rows IT has seen (64 chunks = the top_k / 1024 quantile at best)
+#endif
+template <int FUSE>
+static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
+                                  const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, const ZhApprox &ap,
+                                  uint32_t k_top, float Kc, hipStream_t s) {
+    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+    for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
+        const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
+        constexpr int CHL = FUSE >= 0 ? ZH_S128F_CH : ZH_S128L_CH;
+        const uint64_t wl = (r_end - r + 64 * CHL - 1) / (64 * CHL);
+        hipLaunchKernelGGL((sweep128h_lean_kernel<CHL, FUSE>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh,
+                           (const u32x4v *)dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv, ap, k_top, Kc);
+    }
+#if ZH_S128L_EXP != 5    // (5: timing experiment without the boundary kernel, results invalid)
+    // the chunks that cross a group boundary, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
+    // looks at 64 chunks.  Chunk boundaries are absolute (every launch above starts on a multiple of 256 rows), so both kernels see the same chunks
+    const uint64_t bw = ((R_grouped + 63) / 64 + 63) / 64, bb = (bw + 3) / 4;
+    hipLaunchKernelGGL((sweep128h_boundary_kernel<FUSE>), dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+                       dGroupRowOff, n_groups, dWaveGroup, dLeafIds, (uint64_t)0, R_grouped, dIv, ap, k_top, Kc);
+#endif
+}
+// fuse: null = the raw pairs go to dIv for select_tau_kernel / select_emit_kernel; else the FUSED sweep (intervals, bounds and the queries' lists
+// inside the sweep; exact_register_kernel instead of the select pass): `fuse_kinda` = approx_interval's kind, k_top <= 64
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s) {
+                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s,
+                               const ZhApprox *fuse, int fuse_kinda, uint32_t k_top, float Kc) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
     constexpr int CH = 4;
     const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+    if ((R_grouped + 16383) / 16384 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     // ZH_S128H_KERNEL (read per call: tests switch it): unset / "lean" = the round-6 kernels; "r5" = the round-5 register-staged kernel;
     // ZH_S128H_DMA=1: the LDS-DMA kernel, two tiles in flight per wave -- measured EQUAL to the register-staged one (1.528-1.533 against
     // 1.504-1.523 ms per launch on one box, profiles/r05_ab_sweep128h_dma.txt)
     const char *dma_e = getenv("ZH_S128H_DMA"), *kern_e = getenv("ZH_S128H_KERNEL");
-    const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r', lean = !dma && !r5;
+    const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r';
+    if (fuse) {
+        if (!dWaveGroup || k_top == 0 || k_top > 64) return hipErrorInvalidValue;
+        if (fuse_kinda == 0) launch_sweep128h_lean<0>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
+        else if (fuse_kinda == 1) launch_sweep128h_lean<1>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
+        else launch_sweep128h_lean<2>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
+        return hipGetLastError();
+    }
+    if (!dma && !r5) {
+        launch_sweep128h_lean<-1>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, ZhApprox{}, 0u, 0.f, s);
+        return hipGetLastError();
+    }
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         const uint64_t w = (r_end - r + 64 * CH - 1) / (64 * CH), blocks = (w + 3) / 4;
-        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        if (lean) {
-            const uint64_t wl = (r_end - r + 64 * ZH_S128L_CH - 1) / (64 * ZH_S128L_CH);
-            hipLaunchKernelGGL((sweep128h_lean_kernel<ZH_S128L_CH>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv,
-                               dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
-        } else if (!dma)
+        if (!dma)
             hipLaunchKernelGGL((sweep128h_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                                dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
         else
             hipLaunchKernelGGL((sweep128h_dma_kernel<CH>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                                dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv);
     }
-#if ZH_S128L_EXP != 5    // (5: timing experiment without the boundary kernel, results invalid)
-    if (lean) {
-        // the chunks that cross a group boundary, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
-        // looks at 64 chunks.  Chunk boundaries are absolute (every launch above starts on a multiple of 256 rows), so both kernels see the same chunks
-        const uint64_t bw = ((R_grouped + 63) / 64 + 63) / 64, bb = (bw + 3) / 4;
-        if (bb > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(sweep128h_boundary_kernel, dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
-                           dGroupRowOff, n_groups, dWaveGroup, dLeafIds, (uint64_t)0, R_grouped, dIv);
-    }
-#endif
     return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@ struct ZhVisit {
 // per index by zh_group_size): the leaf's rows cross HBM once per group instead of once per query.
 #define ZH_GROUP_MAX 4
 struct ZhGroup {
-    uint32_t leaf_off, len, gsize, pad;
+    uint32_t leaf_off, len, gsize;
+    uint32_t take4;  // byte j = min(take of member j, 255) (join_group)
     uint32_t b[ZH_GROUP_MAX];
     uint64_t key_off[ZH_GROUP_MAX];  // the member visits' row_off (slice of the key scratch)
 };
@@ -268,7 +269,10 @@ hipError_t zh_launch_qhalf(const float *dQ, uint32_t B, uint32_t d, void *dQh, f
 hipError_t zh_launch_absmax(const float *dX, uint64_t n, uint32_t *dOut, hipStream_t s);
 hipError_t zh_launch_row_half128(const float *dX, uint64_t row0, uint64_t n_rows, float sigma, void *dXh, uint32_t *dRhoMax, hipStream_t s);
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
-                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s);
+                               const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s,
+                               const ZhApprox *fuse = nullptr, int fuse_kinda = 0, uint32_t k_top = 0, float Kc = 0.f);
+// (fused sweep) the exact path's visits, as select_tau_kernel lists them
+hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, ZhApprox ap, hipStream_t s);
 hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
                                  const uint32_t *dVisitBits, const uint4 *dNodeVisit, const ZhGroup *dGroups, uint32_t group, int metric,
                                  int mode, hipStream_t s);

@@ -257,8 +257,11 @@ __device__ __forceinline__ void join_group(const uint32_t GRP, const ZhVisit &v,
     ZhGroup *G = groups + g;
     G->b[slot] = v.b;
     G->key_off[slot] = v.row_off;
+    // what the member visit takes of the leaf (lsh.rs:300-330), capped at 255, a byte per slot (each slot writes its own: the slots of a group
+    // arrive in any order): the fused half-width sweep (zh_approx.hip, round 6) tells from it which visits rank top_k rows of a longer leaf
+    reinterpret_cast<uint8_t *>(&G->take4)[slot] = (uint8_t)(v.take < 255u ? v.take : 255u);
     if (slot == 0) {
-        G->leaf_off = v.leaf_off; G->len = v.len; G->gsize = rest < GRP ? rest : GRP; G->pad = 0;
+        G->leaf_off = v.leaf_off; G->len = v.len; G->gsize = rest < GRP ? rest : GRP;
         groupRowOff[g] = groupRowBase[v.node] + (uint64_t)gl * v.len;
     }
 }
@@ -2313,7 +2316,7 @@ hipError_t zh_launch_scan_sweep(const float *dX, uint32_t d, uint64_t n_rows, co
 
 // n contiguous rows against one query: a single synthetic group, ids = row numbers
 __global__ void one_group_kernel(ZhGroup *g, uint64_t *rowoff, uint64_t n) {
-    g->leaf_off = 0; g->len = (uint32_t)n; g->gsize = 1; g->pad = 0;
+    g->leaf_off = 0; g->len = (uint32_t)n; g->gsize = 1; g->take4 = 0;
     for (int m = 0; m < ZH_GROUP_MAX; m++) { g->b[m] = 0; g->key_off[m] = 0; }
     rowoff[0] = 0;
 }
