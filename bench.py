@@ -1002,6 +1002,9 @@ def compact_line(full, limit=LINE_LIMIT):
     line["config"] = cfg
     line["roofline"] = roof
     line["cpu_baseline"] = cpu
+    # the same workload by an index created AFTER other work churned device memory in this process (the recall run of the bench line's own
+    # rows, which follows torch's brute-force GEMMs and every other configuration): the "order effect" of DESIGN.md s9, beside `value`
+    line["value_index_created_late_in_process"] = ((full.get("other_configs") or {}).get("recall_iid") or {}).get("queries_per_s_this_gpu")
     line["host_buffers_qps"] = full.get("host_buffers_qps")
     line["host_buffers_queries_per_call"] = (full.get("host_buffers") or {}).get("queries_per_call")
     optional = []  # (key, value), most important first

@@ -16,6 +16,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "zh_internal.h"
@@ -59,6 +60,80 @@ extern "C" const char *zh_version(void) { return "zebra-hip 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------------------------------
 // growable device buffer
 // ------------------------------------------------------------------------------------------------
+// Device memory for the library's buffers.  Default: hipMalloc.  ZH_VMM=1 (read once; an experiment for the "order effect", DESIGN.md s9: an index
+// whose buffers are allocated after another library has churned device memory scans 25-40 % slower): allocations of 2 MiB and more are made through
+// the virtual-memory API instead -- an address range reserved, physical memory created in chunks of ZH_VMM_CHUNK_MB (default 256) and mapped -- so
+// that what backs a buffer is a handful of large physical allocations whatever state hipMalloc's pool is in.
+struct VmmRec { size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; std::vector<size_t> sizes; };
+static std::mutex g_vmm_mu;
+static std::unordered_map<void *, VmmRec> g_vmm;
+static int vmm_mode() {
+    static const int m = [] { const char *e = getenv("ZH_VMM"); return e ? atoi(e) : 0; }();
+    return m;
+}
+static hipError_t zh_dev_alloc(void **out, size_t bytes) {
+    if (vmm_mode() <= 0 || bytes < (size_t(2) << 20)) return hipMalloc(out, bytes);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended)) != hipSuccess || gran == 0) return hipMalloc(out, bytes);
+    static const size_t chunk_mb = [] { const char *c = getenv("ZH_VMM_CHUNK_MB"); return (size_t)(c ? atoi(c) : 256); }();
+    const size_t chunk = std::max<size_t>(gran, (chunk_mb << 20) / gran * gran);
+    const size_t total = (bytes + gran - 1) / gran * gran;
+    void *va = nullptr;
+    if ((e = hipMemAddressReserve(&va, total, gran, nullptr, 0)) != hipSuccess) return e;
+    VmmRec rec;
+    rec.size = total;
+    size_t off = 0;
+    while (off < total) {
+        const size_t sz = std::min(chunk, total - off);
+        hipMemGenericAllocationHandle_t h;
+        if ((e = hipMemCreate(&h, sz, &prop, 0)) != hipSuccess) break;
+        if ((e = hipMemMap((char *)va + off, sz, 0, h, 0)) != hipSuccess) { hipMemRelease(h); break; }
+        rec.handles.push_back(h); rec.sizes.push_back(sz);
+        off += sz;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, total, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        size_t o2 = 0;
+        for (size_t i = 0; i < rec.handles.size(); i++) { hipMemUnmap((char *)va + o2, rec.sizes[i]); hipMemRelease(rec.handles[i]); o2 += rec.sizes[i]; }
+        hipMemAddressFree(va, total);
+        (void)hipGetLastError();
+        return e;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_vmm.emplace(va, std::move(rec));
+    }
+    *out = va;
+    return hipSuccess;
+}
+static void zh_dev_free(void *p) {
+    if (!p) return;
+    VmmRec rec;
+    bool mine = false;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        auto it = g_vmm.find(p);
+        if (it != g_vmm.end()) { rec = std::move(it->second); g_vmm.erase(it); mine = true; }
+    }
+    if (!mine) { hipFree(p); return; }
+    hipDeviceSynchronize();  // (hipFree's guarantee: nothing in flight still uses the range)
+    size_t off = 0;
+    for (size_t i = 0; i < rec.handles.size(); i++) { hipMemUnmap((char *)p + off, rec.sizes[i]); hipMemRelease(rec.handles[i]); off += rec.sizes[i]; }
+    hipMemAddressFree(p, rec.size);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -76,32 +151,32 @@ struct DevBuf {
         if (bytes <= cap) return ZH_OK;
         if (defer) bytes += bytes / 8;
         if (defer && old_bytes + cap > (size_t(2) << 30)) {
-            for (void *o : old) hipFree(o);
+            for (void *o : old) zh_dev_free(o);
             old.clear();
             old_bytes = 0;
         }
         size_t ncap = std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~size_t(255);
         void *np = nullptr;
-        hipError_t e = hipMalloc(&np, ncap);
+        hipError_t e = zh_dev_alloc(&np, ncap);
         if (e != hipSuccess) {
             ncap = (bytes + 255) & ~size_t(255);
-            e = hipMalloc(&np, ncap);
+            e = zh_dev_alloc(&np, ncap);
         }
         if (e != hipSuccess) return fail(ZH_ENOMEM, "hipMalloc(%zu bytes): %s", ncap, hipGetErrorString(e));
         if (keep && p && cap) {
             e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) { hipFree(np); return fail(ZH_EHIP, "grow copy: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) { zh_dev_free(np); return fail(ZH_EHIP, "grow copy: %s", hipGetErrorString(e)); }
         }
-        if (p) { if (defer) { old.push_back(p); old_bytes += cap; } else hipFree(p); }
+        if (p) { if (defer) { old.push_back(p); old_bytes += cap; } else zh_dev_free(p); }
         p = np;
         cap = ncap;
         return ZH_OK;
     }
     void release() {
-        if (p) hipFree(p);
-        for (void *o : old) hipFree(o);
+        if (p) zh_dev_free(p);
+        for (void *o : old) zh_dev_free(o);
         old.clear();
         old_bytes = 0;
         p = nullptr;
@@ -423,6 +498,13 @@ static void free_forest(zh_index *ix) {
     ix->n_blocks = 0; ix->blocks_valid = false;
     ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
+    {
+        // the matrix-core scan's row order was measured on THIS forest's leaves: the next half-width batch re-makes the copy in the new forest's
+        // order, and an order given up for lack of room gets another chance
+        std::lock_guard<std::mutex> lb(ix->blk_mu);
+        if (ix->perm_rows || ix->order_keys) ix->scale_gen = 0;
+        ix->row_order_off = false;
+    }
     ix->plane_samples.release(); ix->samples_valid = false;
     ix->plane_hab.release(); ix->hab_planes = 0; ix->hab_rows = 0; ix->hab_gen = 0;
     ix->n_nodes = ix->n_planes = ix->n_trees = 0;
@@ -482,7 +564,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->row_hn2.release(); ix->row_norm.release();
     std::lock_guard<std::mutex> lb(ix->blk_mu);  // (the fp16 copies' state is blk_mu's: zh_stats reads it under that lock)
     ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
-    ix->perm_rows = 0; ix->perm_gen++; ix->scan_perm.release(); ix->row_leaf_p.release();
+    ix->perm_rows = 0; ix->perm_gen++; ix->scan_perm.release(); ix->row_leaf_p.release(); ix->row_order_off = false;  // (a new table gets a new chance at the scan's row order)
     ix->h128_rows = 0; ix->h128_gen = 0; ix->h128_rho = 0.f; ix->row_half128.release(); ix->h128_failed = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
     ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
@@ -1244,7 +1326,7 @@ extern "C" int zh_stats(zh_index *ix, zh_stats_t *out) {
         *out = ix->stats;
     }
     std::lock_guard<std::mutex> lk(ix->blk_mu);  // (the copies are made and dropped under it)
-    out->row_copy_bytes = ix->row_half.cap + ix->row_meta.cap + ix->row_half128.cap;
+    out->row_copy_bytes = ix->row_half.cap + ix->row_meta.cap + ix->row_half128.cap + ix->scan_perm.cap + ix->row_leaf_p.cap;  // (+ the scan's row order and its view of row -> leaf)
     out->scan_order_keys = ix->perm_rows ? ix->order_keys : 0;
     out->scan_order_share_permille = (uint64_t)(ix->order_worth * 1000.0 + 0.5);
     return ZH_OK;
@@ -1535,12 +1617,26 @@ static int build_scan_perm(zh_index *ix) {
     if (best_keys) ix->perm_rows = ix->n_rows;
     return ZH_OK;
 }
+// The scan's inputs (row_half / row_meta, row_leaf_p, row_half128) are rewritten IN PLACE when rows were appended, the forest changed or the row
+// order is given up.  blk_mu orders the host threads that do it, not the GPU work of other contexts: a scan another pipelined context queued on the
+// shared sweep stream (or its own) before this batch got here would read half-rewritten tiles.  Rewrites are rare (the first batch after an add /
+// a rebuild): wait for everything the device has queued, then rewrite.  
+static int quiesce_before_rewrite() {
+    HIPCHK(hipDeviceSynchronize());
+    return ZH_OK;
+}
 // the row -> leaf table in the scan's row order (under blk_mu; row_leaf must be valid)
 static int ensure_row_leaf_p(zh_index *ix) {
     if (!ix->perm_rows) return ZH_OK;
     if (ix->row_leaf_p_gen == ix->row_leaf_gen && ix->row_leaf_p_perm == ix->perm_gen) return ZH_OK;
     const uint32_t T = ix->n_trees;
-    int rc = ix->row_leaf_p.ensure(std::max<uint64_t>(ix->n_rows * T, 1) * sizeof(uint2));
+    // the same headroom rule as the copies themselves: a sixteenth of the device stays free for the batches' scratch
+    const uint64_t want_p = std::max<uint64_t>(ix->n_rows * T, 1) * sizeof(uint2);
+    size_t mem_free = 0, mem_total = 0;
+    if (want_p > ix->row_leaf_p.cap && (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < want_p + mem_total / 16)) { ix->perm_rows = 0; return ZH_OK; }
+    int rc = quiesce_before_rewrite();
+    if (rc) return rc;
+    rc = ix->row_leaf_p.ensure(want_p);
     if (rc) { ix->perm_rows = 0; return ZH_OK; }  // (no room: the scan reads the table in id order -- but its tiles are in tree-0 order: the copy is remade)
     hipError_t e = zh_launch_permute_row_leaf(ix->row_leaf.as<uint2>(), ix->scan_perm.as<uint32_t>(), ix->perm_rows, ix->n_rows, T, ix->row_leaf_p.as<uint2>(), ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
@@ -1570,7 +1666,14 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
         return ZH_OK;
     }
     uint64_t from = ix->scale_rows;
-    if (ix->scale_gen != ix->rows_gen || from > ix->n_rows) {
+    {
+        const int rcq = quiesce_before_rewrite();
+        if (rcq) return rcq;
+    }
+    // rows appended since the order was made keep position = id and share no tile with their leaf mates: once they are a quarter of the table
+    // the copy is made again, in an order measured on all of it
+    const bool stale_order = ix->perm_rows && ix->n_rows - ix->perm_rows > ix->perm_rows / 4;
+    if (ix->scale_gen != ix->rows_gen || from > ix->n_rows || stale_order) {
         from = 0;
         HIPCHK(hipMemsetAsync(ix->row_rho_dev.p, 0, 4, ix->stream));
     }
@@ -1606,6 +1709,10 @@ static int ensure_row_half128(zh_index *ix, bool *ok) {
         return ZH_OK;
     }
     uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows) ? ix->h128_rows.load() : 0;
+    {
+        const int rcq = quiesce_before_rewrite();
+        if (rcq) return rcq;
+    }
     uint32_t *dmax = ix->row_rho_dev.as<uint32_t>() + 1;
     for (int pass = 0; pass < 2; pass++) {
         uint32_t mbits = 0;

@@ -582,7 +582,9 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
 #endif
-// -DZH_SCAN_GUARD (diagnostic builds, never shipped): every index the matrix-core scan derives from its inputs is checked before it is used as an address;
+// -DZH_SCAN_GUARD (diagnostic builds, never shipped): every index the matrix-core scan derives from its inputs is checked before it is used as an address
+// -- global (bits 1, 2: a query past the batch, a key slot past the scratch) and, round 6, LDS (4 / 8: a regrouped record past the list / a column
+// past the wave's columns; 16: a probe that does not end; 32: the pair list; 64: the column table; 128: a pair whose query pass 1 did not number);
 // a violation sets a bit of ctl[7] (printed by zh_search_wait) instead of faulting: 1 a query id >= the batch, 2 a key slot >= the scratch, 4 a list
 // position past the wave's list, 8 a column >= the wave's columns, 16 a probe sequence that does not end
 #ifdef ZH_SCAN_GUARD
@@ -650,7 +652,7 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
 #pragma unroll
     for (int j = 0; j < ZH_SCAN_NE; j++) {
         const uint32_t e = lane + 64u * j, c = eC[j];
-        if (c && listed) {
+        if (c && listed && ZH_GUARD(off[j] + c <= (uint32_t)ZH_APX_CAP && e / T < 16u, 32u)) {  // (LDS: the wave's pair list)
             const uint32_t rl = e / T, gb = eGb[j];
             list[off[j]] = pack(rl, eB0[j], eK0[j] + eWithin[j]);
             for (uint32_t sidx = 1; sidx < c; sidx++) {
@@ -760,8 +762,10 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
             const unsigned long long lm = __ballot(leader);
             if (leader) {
                 const uint32_t col = nd + (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull));
-                tab[hs] = (key << 9) | col;
-                colq[col] = b;
+                if (ZH_GUARD(col < (uint32_t)ZH_APX_CAP && hs < 1024u, 64u)) {  // (LDS: the column table, the columns' queries)
+                    tab[hs] = (key << 9) | col;
+                    colq[col] = b;
+                }
             }
             nd += (uint32_t)__builtin_popcountll(lm);
         }
@@ -775,7 +779,9 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
                 const uint32_t b = (uint32_t)(rec >> 36) & 0xFFFFFFu, key = b + 1u;
                 uint32_t hs = hash_of(b), w = tab[hs];
                 for (uint32_t tries = 0; (w >> 9) != key && ZH_GUARD(tries < 1024u, 16u); tries++) { (void)tries; hs = (hs + 1u) & 1023u; w = tab[hs]; }
-                const uint32_t col = w & 0x1FFu, pos = atomicAdd(&tstart[1 + (col >> 4)], 1u);
+                const uint32_t col = w & 0x1FFu;
+                if (!ZH_GUARD((w >> 9) == key && col < nd, 128u)) continue;  // (a pair whose query is not in the table: pass 1 numbers every query)
+                const uint32_t pos = atomicAdd(&tstart[1 + (col >> 4)], 1u);
                 list[pi] = (rec & ~(0xFFFFFFull << 36)) | ((uint64_t)(col | (pos << 9)) << 36);
             }
         }
