@@ -11,7 +11,7 @@ for k,v in j["other_configs"].items():
     print("   ", k, round(v["queries_per_s_this_gpu"]), "qps  launch_ms", round(r.get("launch_ms",0),3), r.get("kernel"))'
 out=gpurun_out/order_effect_vmm.txt
 : > $out
-for vmm in 0 1 0 1; do
+for vmm in 1 0 1; do
   for order in cfg2,cfg4_one_of_8_shards cfg4_one_of_8_shards,cfg2; do
     echo "== ZH_VMM=$vmm  main cfg3, then $order (no recall runs)" | tee -a $out
     ZH_VMM=$vmm timeout -k 10 400 python bench.py --steps 4 --warmup 2 --cpu-seconds 0 --no-recall --only-other $order 2>gpurun_out/order.err | python3 -c "$fmt" 2>&1 | tee -a $out || tail -3 gpurun_out/order.err | tee -a $out

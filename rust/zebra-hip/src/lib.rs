@@ -140,6 +140,7 @@ pub mod ffi {
         pub fn zh_ref_tree_encode(forest: *const c_void /* zh_forest_view */, dim: u32, tree: u32, uuids: *const u8, n_rows: u64,
                                   out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
         pub fn zh_last_error() -> *const c_char;
+        pub fn zh_trim_device_memory() -> c_int;
     }
 }
 

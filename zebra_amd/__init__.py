@@ -15,4 +15,4 @@ from ._ffi import COSINE, COSINE_CORRECTED, COSINE_PARITY, L2, L2SQ, MAX_TOPK, Z
 from .index import (BrayCurtisDistance, CanberraDistance, ChebyshevDistance, CosineDistance, Database,  # noqa: F401
                     HammingDistance, L2Distance, L2SquaredDistance, L3Distance, L4Distance, LSHIndex, LSHIndexOptions,
                     ManhattanDistance, MinkowskiDistance, PNormDistance, ShardContext, ShardGroup, merge_topk_device, merge_topk_packed_device,
-                    packed_result_words, shard_unique_id, synth_queries_device)
+                    packed_result_words, shard_unique_id, synth_queries_device, trim_device_memory)

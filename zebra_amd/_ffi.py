@@ -153,6 +153,7 @@ SYMBOLS = [
     ("zh_set_hash_mode", _i, [_vp, _i]),
     ("zh_last_error", C.c_char_p, []),
     ("zh_version", C.c_char_p, []),
+    ("zh_trim_device_memory", _i, []),
 ]
 
 _lib = None

@@ -71,7 +71,117 @@ static int vmm_mode() {
     static const int m = [] { const char *e = getenv("ZH_VMM"); return e ? atoi(e) : 0; }();
     return m;
 }
+// ---- the block cache (round 6; the "order effect"), OPT-IN: ZH_POOL=1.  How a buffer is MAPPED decides how fast the matrix-core scan
+// runs over it: the same cfg3 launch takes 3.2 ms on hipMalloc'd buffers of a fresh process and on ranges of the virtual-memory API aligned to 2 MiB
+// and backed by 256-MiB chunks, 3.7 ms on ranges aligned to 4 KiB, 3.4-4.8 on ranges made of 2-MiB chunks (profiles/r06_order_effect.txt; ZH_VMM above
+// is that experiment) -- and 3.6-3.8 on the hipMalloc'd buffers of the second / third index a process creates.  With the cache, large blocks are not
+// handed back to the driver when an index or a context lets go of them: they wait here, keyed by size, and the next buffer of a fitting size takes
+// one (what a framework's caching allocator does); hipMalloc is asked only for what no cached block serves, and when it fails the cache is emptied
+// and it is asked again.  Measured: the late index's launch 3.77 -> 3.59 ms (cfg4 shard), 0.99 -> 0.93 (cfg2) -- a twentieth, not the effect: buffers
+// that are NEW late in a process are slow whether or not anything was freed before them.  Off by default (held memory is invisible to other
+// libraries' allocators); zh_trim_device_memory() empties it; blocks below 32 MiB are not kept.
+struct PoolBlock { void *p; size_t cap; int dev; };
+static std::mutex g_pool_mu;
+static std::vector<PoolBlock> g_pool;
+static std::unordered_map<void *, size_t> g_pool_caps;  // every live block of 32 MiB and more this library allocated: its capacity
+static size_t g_pool_bytes = 0;
+static bool pool_on() {
+    static const bool on = [] { const char *e = getenv("ZH_POOL"); return e && e[0] == '1'; }();
+    return on;
+}
+static const size_t POOL_MIN = size_t(32) << 20;
+static void zh_dev_free_raw(void *p);
+static size_t pool_cached_bytes(int dev) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t n = 0;
+    for (const PoolBlock &b : g_pool) if (b.dev == dev) n += b.cap;
+    return n;
+}
+static void pool_trim() {
+    std::vector<PoolBlock> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        gone.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const PoolBlock &b : gone) {
+        { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_caps.erase(b.p); }
+        (void)hipSetDevice(b.dev);
+        zh_dev_free_raw(b.p);
+    }
+    (void)hipSetDevice(cur);
+}
+// free device memory as the library's own headroom rules should see it: what the driver reports plus what the block cache would give back
+static hipError_t zh_mem_info(size_t *mem_free, size_t *mem_total) {
+    hipError_t e = hipMemGetInfo(mem_free, mem_total);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) *mem_free += pool_cached_bytes(dev);
+    return hipSuccess;
+}
+static hipError_t zh_dev_alloc_raw(void **out, size_t bytes);
 static hipError_t zh_dev_alloc(void **out, size_t bytes) {
+    if (pool_on() && bytes >= POOL_MIN) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            size_t best = (size_t)-1;
+            for (size_t i = 0; i < g_pool.size(); i++)  // best fit, at most half as much again as asked for
+                if (g_pool[i].dev == dev && g_pool[i].cap >= bytes && g_pool[i].cap <= bytes + bytes / 2 && (best == (size_t)-1 || g_pool[i].cap < g_pool[best].cap)) best = i;
+            if (best != (size_t)-1) {
+                *out = g_pool[best].p;
+                g_pool_bytes -= g_pool[best].cap;
+                g_pool[best] = g_pool.back();
+                g_pool.pop_back();
+            } else
+                *out = nullptr;
+        }
+        if (*out) {
+            // hipFree would have waited for everything queued on the device before the block could be handed out again: so does a hit (rare: an
+            // index or a context being set up)
+            (void)hipDeviceSynchronize();
+            return hipSuccess;
+        }
+        hipError_t e = zh_dev_alloc_raw(out, bytes);
+        if (e != hipSuccess) {  // out of memory with blocks in the cache: give them back and ask again
+            (void)hipGetLastError();
+            pool_trim();
+            e = zh_dev_alloc_raw(out, bytes);
+        }
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_pool_caps[*out] = bytes;
+        }
+        return e;
+    }
+    hipError_t e = zh_dev_alloc_raw(out, bytes);
+    if (e != hipSuccess && pool_on() && g_pool_bytes) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = zh_dev_alloc_raw(out, bytes);
+    }
+    return e;
+}
+static void zh_dev_free_raw(void *p);
+static void zh_dev_free(void *p) {
+    if (!p) return;
+    if (pool_on()) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_caps.find(p);
+        if (it != g_pool_caps.end()) {  // (a block of this library's, 32 MiB or more: it stays mapped; nothing reads it once a later user's work is queued behind this call in host order -- hipFree's own rule for the caller)
+            g_pool.push_back(PoolBlock{p, it->second, dev});
+            g_pool_bytes += it->second;
+            return;
+        }
+    }
+    zh_dev_free_raw(p);
+}
+static hipError_t zh_dev_alloc_raw(void **out, size_t bytes) {
     if (vmm_mode() <= 0 || bytes < (size_t(2) << 20)) return hipMalloc(out, bytes);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -83,6 +193,10 @@ static hipError_t zh_dev_alloc(void **out, size_t bytes) {
     size_t gran = 0;
     if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended)) != hipSuccess || gran == 0) return hipMalloc(out, bytes);
     static const size_t chunk_mb = [] { const char *c = getenv("ZH_VMM_CHUNK_MB"); return (size_t)(c ? atoi(c) : 256); }();
+    // the reported granularity is 4 KiB on this platform (profiles/micro/vmm_probe.hip): the range's ALIGNMENT and the chunks' sizes are what let the
+    // page tables use large fragments -- ZH_VMM_ALIGN_MB (default 2; 0 = the reported granularity, for the experiment's control)
+    static const size_t align_mb = [] { const char *c = getenv("ZH_VMM_ALIGN_MB"); return (size_t)(c ? atoi(c) : 2); }();
+    if (align_mb) gran = std::max<size_t>(gran, align_mb << 20);
     const size_t chunk = std::max<size_t>(gran, (chunk_mb << 20) / gran * gran);
     const size_t total = (bytes + gran - 1) / gran * gran;
     void *va = nullptr;
@@ -118,7 +232,7 @@ static hipError_t zh_dev_alloc(void **out, size_t bytes) {
     *out = va;
     return hipSuccess;
 }
-static void zh_dev_free(void *p) {
+static void zh_dev_free_raw(void *p) {
     if (!p) return;
     VmmRec rec;
     bool mine = false;
@@ -1585,7 +1699,7 @@ static int build_scan_perm(zh_index *ix) {
     ix->order_keys = 0;
     if (forced == 0 || ix->row_order_off || !ix->row_leaf_valid || ix->row_leaf_rows != ix->n_rows || ix->n_rows < 32 || ix->n_rows > 0x7FFFFFF0ull) return ZH_OK;
     size_t mem_free = 0, mem_total = 0;  // the sort's scratch: ~28 bytes per row, released before the copy is made
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < ix->n_rows * 48 + mem_total / 16) return ZH_OK;
+    if (zh_mem_info(&mem_free, &mem_total) != hipSuccess || mem_free < ix->n_rows * 48 + mem_total / 16) return ZH_OK;
     DevBuf cand, dsum;
     if (ix->scan_perm.ensure(ix->n_rows * 4) || cand.ensure(ix->n_rows * 4) || dsum.ensure(8)) { cand.release(); dsum.release(); return ZH_OK; }
     const uint2 *rl = ix->row_leaf.as<uint2>();
@@ -1633,7 +1747,7 @@ static int ensure_row_leaf_p(zh_index *ix) {
     // the same headroom rule as the copies themselves: a sixteenth of the device stays free for the batches' scratch
     const uint64_t want_p = std::max<uint64_t>(ix->n_rows * T, 1) * sizeof(uint2);
     size_t mem_free = 0, mem_total = 0;
-    if (want_p > ix->row_leaf_p.cap && (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < want_p + mem_total / 16)) { ix->perm_rows = 0; return ZH_OK; }
+    if (want_p > ix->row_leaf_p.cap && (zh_mem_info(&mem_free, &mem_total) != hipSuccess || mem_free < want_p + mem_total / 16)) { ix->perm_rows = 0; return ZH_OK; }
     int rc = quiesce_before_rewrite();
     if (rc) return rc;
     rc = ix->row_leaf_p.ensure(want_p);
@@ -1657,7 +1771,7 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
     size_t mem_free = 0, mem_total = 0;
     const uint64_t want = std::max<uint64_t>(tiles, 1) * 16 * (d * 2 + sizeof(float2));
     const bool room = want <= ix->row_half.cap + ix->row_meta.cap ||
-                      (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
+                      (zh_mem_info(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
     if (!room || ix->row_half.ensure(std::max<uint64_t>(tiles, 1) * 16 * d * 2, true, ix->stream) != ZH_OK ||
         ix->row_meta.ensure(std::max<uint64_t>(tiles, 1) * 16 * sizeof(float2), true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(4) != ZH_OK) {
         ix->row_half.release(); ix->row_meta.release();
@@ -1701,7 +1815,7 @@ static int ensure_row_half128(zh_index *ix, bool *ok) {
     ix->h128_failed = false;
     size_t mem_free = 0, mem_total = 0;
     const uint64_t want = std::max<uint64_t>(ix->n_rows, 1) * 256;
-    const bool room = want <= ix->row_half128.cap || (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
+    const bool room = want <= ix->row_half128.cap || (zh_mem_info(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
     if (!room || ix->row_half128.ensure(want, true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(8) != ZH_OK) {
         ix->row_half128.release();
         ix->h128_failed = true;
@@ -2583,6 +2697,11 @@ extern "C" int zh_search_wait(zh_search_ctx *c) {
 }
 
 // ---- test / debug access (include/zebra_hip.h, "test / debug access") ----
+extern "C" int zh_trim_device_memory(void) {
+    pool_trim();
+    return ZH_OK;
+}
+
 extern "C" int zh_debug_keep_raw(zh_index *ix, int on) {
     if (!ix) return fail(ZH_EINVAL, "zh_debug_keep_raw: null index");
     std::unique_lock<std::shared_mutex> lk(ix->mu);

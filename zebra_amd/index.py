@@ -469,6 +469,11 @@ def synth_queries_device(device, d_out, n_rows, b, dim, b0=0, seed_rows=0x5EB2A0
 
 
 # ------------------------------------------------------------------------ src/database/core.rs
+def trim_device_memory():
+    """zh_trim_device_memory: hand the library's cached device blocks (32 MiB and more, kept when an index or context lets go of them) back to the driver"""
+    check(lib().zh_trim_device_memory())
+
+
 class Database:
     """Database<N, Met, Mod> restricted to the two calls on the hot path: insert_records
     (core.rs:245-254) and query_vectors (core.rs:290-313).  Documents are kept in memory (the lz4
