@@ -209,6 +209,9 @@ def parse():
                     help="batches handled as ONE internal batch (zh_search_begin_window): rows shared across the window's queries")
     ap.add_argument("--sweep-mode", choices=["auto", "leaf", "scan", "approx", "approx-valu", "leaf-half"], default="auto",
                     help="zh_set_sweep_mode: leaf by leaf, table scan, or chosen per batch by the library (default)")
+    ap.add_argument("--corrected-key", action="store_true",
+                    help="debug / A-B: cosine workloads timed with the CORRECTED key (cosine distance) instead of the reference's literal one "
+                         "(distance.rs:23-25: similarity): same cost per pair, far shorter candidate lists on long leaves")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="on ONE GPU: run rank 0's shard of an N-rank job, exchange on a one-rank RCCL communicator")
     ap.add_argument("--debug-normal-priority-sweeps", action="store_true", help="A/B: sweeps on a normal-priority stream (N = 1)")
@@ -307,7 +310,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     first_row, rows_local = sharding.shard_rows(wl["rows"], S, rank)
     M_shard = sharding.per_shard_max_node_size(wl["M"], S, wl["k"]) if S > 1 else wl["M"]
     d, T, k, B = wl["dim"], wl["T"], wl["k"], wl["batch"]
-    metric = make_metric(za, wl["metric"], parity=True)
+    metric = make_metric(za, wl["metric"], parity=not args.corrected_key)
     n_total = wl["rows"]
 
     # ---- setup (untimed): synthetic rows on the device, GPU forest build ------------------------------------------
@@ -595,6 +598,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
         if st.get("approx_scan", 0) == 2:
             kname = "scan_mfma_kernel<%d>" % d  # the same scan on the matrix cores, from the index's fp16 copy of the stored rows
+            if st.get("row_copy_bytes", 0) < rows_local * d:  # no room for the copy (2 d bytes per row): the scan converts the f32 rows itself
+                kname = "scan_mfma_kernel<%d, f32 rows converted in the scan>" % d
     s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
               "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
@@ -642,6 +647,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         qb = 2.0 * d if half else 4.0 * d  # bytes of one query as the scan reads it: fp16 copy (round 4) or f32
         mfma = half and st.get("approx_scan", 0) == 2  # ... on the matrix cores, from the index's fp16 copy of the stored rows
         rb = 2.0 * d + 8.0 if mfma else 4.0 * d        # bytes of one stored row as the scan reads it (fp16 copy + {|x|^2, 1 / scale})
+        if mfma and st.get("row_copy_bytes", 0) < rows_local * d:
+            rb = 4.0 * d + 8.0                         # ... the f32 rows themselves where the index keeps no copy (scan_mfma_kernel<D, true>)
         l2_bytes = qb * rows_per_launch + rb * stored
         by_design = stored * (rb + 8.0 * T) + 8.0 * rows_per_launch + qb * B / launches_per_batch
         l2_GBps = l2_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0

@@ -87,6 +87,33 @@ def test_half_width_scan_equals_oracle(za, n, d, M, T, k, B, kind, expect, mode)
     ix.close()
 
 
+@pytest.mark.parametrize("n,d,M,T,k,B,kind,expect", [c for c in CASES if c[1] in (256, 384, 512, 768, 1024) and c[7]])
+def test_matrix_core_scan_on_f32_rows_equals_oracle(za, monkeypatch, n, d, M, T, k, B, kind, expect):
+    """no room for the fp16 copy of the table (64M x 768 on one GPU; here: ZH_ROW_HALF_META_ONLY=1): the same matrix-core scan, the wave converting
+    its 16 f32 rows itself (scan_mfma_kernel<d, true>) -- per-row scales and norms are all the index keeps (8 bytes per row)"""
+    monkeypatch.setenv("ZH_ROW_HALF_META_ONLY", "1")
+    X = zo.synth_rows(n, d, kind=kind)
+    Q = zo.synth_queries(B, d, n, kind=kind)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("approx")
+    ix.set_hash_mode("dense")
+    for m, om, omode in all_metrics(za):
+        st = check(ix, f, Q, k, m, om, omode)
+        assert st["approx_scan"] == scan_code("approx", d, T), (om, omode, st)
+        assert st["approx_fallbacks_accum"] == 0, st
+        if st["approx_scan"] == 2:
+            assert 0 < st["row_copy_bytes"] < n * d, st  # (no copy: 2 d bytes per row would be more)
+    # rows appended afterwards: scales and norms follow
+    X2 = zo.synth_rows(n + 500, d, kind=kind)[n:] * np.float32(8.0)
+    ix.append(X2)
+    f2 = zo.Forest.build(np.concatenate([X, X2]), M, T)
+    ix.set_forest(f2.arrays())
+    check(ix, f2, Q, k, za.L2Distance(), zo.L2, 0, "appended")
+    ix.close()
+
+
 @pytest.mark.parametrize("mode", ["approx", "approx-valu"])
 def test_exact_visits_are_exercised(za, mode):
     """leaves shorter than top_k send the walk to backup subtrees with n < top_k (lsh.rs:340-345): those visits must hand over

@@ -208,9 +208,16 @@ def build(za, X, d, M, T, mode):
     return ix, f
 
 
+@pytest.mark.parametrize("rows", ["copy", "f32"])
 @pytest.mark.parametrize("d", [256, 384, 512, 768, 1024])
-def test_matrix_core_scan_intervals_contain_the_key(za, torch, d, record_property):
-    """scan_mfma_kernel<d> (zh_set_sweep_mode 4): fp16 rows AND fp16 queries, the sum formed inside v_mfma_f32_16x16x32_f16"""
+def test_matrix_core_scan_intervals_contain_the_key(za, torch, d, rows, monkeypatch, record_property):
+    """scan_mfma_kernel<d> (zh_set_sweep_mode 4): fp16 rows AND fp16 queries, the sum formed inside v_mfma_f32_16x16x32_f16.  rows = f32
+    (ZH_ROW_HALF_META_ONLY=1; what an index does whose fp16 copy does not fit): scan_mfma_kernel<d, true> converts the f32 rows itself, with the
+    per-row scales of the copy -- same operand bits, same intervals"""
+    if rows == "f32":
+        monkeypatch.setenv("ZH_ROW_HALF_META_ONLY", "1")
+    else:
+        monkeypatch.delenv("ZH_ROW_HALF_META_ONLY", raising=False)
     rng = np.random.default_rng(d)
     n, M, T, k, B = 5000, 400, 8, 10, 40
     X = special_rows(zo.synth_rows(n, d), d, rng)
@@ -220,6 +227,8 @@ def test_matrix_core_scan_intervals_contain_the_key(za, torch, d, record_propert
         ids, keys, counts = run_batch(torch, ix, Q, k, m)
         info, pairs, qmeta = ix.debug_scan_pairs()
         assert info["approx_scan"] == 2 and info["queries"] == B and info["top_k"] == k, info
+        copy_bytes = ix.stats()["row_copy_bytes"]
+        assert (copy_bytes < n * d) == (rows == "f32"), (rows, copy_bytes)  # (the copy itself is 2 d bytes per row; scales and norms alone 8)
         r = check_containment(X, Q, info, pairs, qmeta, f"scan_mfma_kernel<{d}> {name}")
         w, a = check_rounding_model(X, Q, info, pairs, qmeta, d, f"scan_mfma_kernel<{d}> {name}")
         print(f"scan_mfma_kernel<{d}> {name}: {r['pairs']} pairs, {r['unsure']} uncertain, median half-width {r['median_rel_halfwidth']:.2e} of the value; "

@@ -329,6 +329,7 @@ struct zh_search_ctx {
     bool scan = false;  // the batch in flight was swept by the table scan (rows streamed once) instead of leaf by leaf
     // ... with half-width queries (zh_approx.hip): intervals from the scan, the reference's keys for the few rows they cannot
     // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
+    bool approx_f32rows = false;  // (approx_mfma without an fp16 copy of the table: scan_mfma_kernel<D, true>)
     bool approx_fused = false;  // (approx_leaf, round 6: intervals, bounds and lists inside the sweep kernel)
     bool approx = false, approx_mfma = false, approx_leaf = false;  // (approx_leaf: the d = 128 leaf-major sweep at half width, sweep128h_kernel)
     uint32_t *h_ap = nullptr;
@@ -446,6 +447,9 @@ struct zh_index {
     // after the first such batch -- or one whose lists came close -- the per-query lists get 8192 slots instead of 4096 (a final
     // kernel with twice the LDS); after the second the index keeps the f32 scan until its trees change
     std::atomic<uint32_t> approx_strikes{0};
+    // the matrix-core scan on f32 rows (no fp16 copy) rounds the rows as well: wider intervals, longer lists.  Lists that run over at 8192 slots send the
+    // index back to the VALU half-width scan (which rounds the queries only) instead of all the way to the f32 scan
+    std::atomic<bool> mfma_f32_off{false};
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
@@ -610,7 +614,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
-    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0;
+    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     {
         // the matrix-core scan's row order was measured on THIS forest's leaves: the next half-width batch re-makes the copy in the new forest's
@@ -785,7 +789,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
-    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0;
+    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false;
     ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->batches_since_change = 0;
     ix->max_leaf_len = 0;
@@ -1772,7 +1776,35 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
     const uint64_t want = std::max<uint64_t>(tiles, 1) * 16 * (d * 2 + sizeof(float2));
     const bool room = want <= ix->row_half.cap + ix->row_meta.cap ||
                       (zh_mem_info(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
-    if (!room || ix->row_half.ensure(std::max<uint64_t>(tiles, 1) * 16 * d * 2, true, ix->stream) != ZH_OK ||
+    // No room for the copy (64M x 768 on one GPU: 196 GB of rows + 98 GB), or ZH_ROW_HALF_META_ONLY=1 (tests; read per call): the per-row scales and
+    // norms alone (8 bytes per row) -- scan_mfma_kernel<D, true> then converts the f32 rows itself, to the bits the copy would hold (round 6: the
+    // same matrix-core scan at every N of the series)
+    const char *mo_e = getenv("ZH_ROW_HALF_META_ONLY");
+    const bool meta_only = !room || (mo_e && mo_e[0] == '1');
+    if (meta_only) {
+        const uint64_t want_meta = std::max<uint64_t>(tiles, 1) * 16 * sizeof(float2);
+        const bool room_meta = want_meta <= ix->row_meta.cap || (zh_mem_info(&mem_free, &mem_total) == hipSuccess && mem_free >= want_meta + mem_total / 16);
+        ix->row_half.release();
+        if (!room_meta || ix->row_meta.ensure(want_meta, false, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(4) != ZH_OK) {
+            ix->row_meta.release();
+            ix->row_half_failed = true;
+            ix->scale_rows = ix->n_rows; ix->scale_gen = ix->rows_gen;
+            return ZH_OK;
+        }
+        int rcq = quiesce_before_rewrite();
+        if (rcq) return rcq;
+        ix->perm_rows = 0; ix->perm_gen++; ix->order_keys = 0;  // (the f32 rows are in id order)
+        HIPCHK(hipMemsetAsync(ix->row_rho_dev.p, 0, 4, ix->stream));
+        HIPCHK(zh_launch_row_half(ix->X.as<float>(), 0, ix->n_rows, (uint32_t)d, nullptr, ix->row_meta.as<float2>(), ix->row_rho_dev.as<uint32_t>(), nullptr, 0, ix->stream));
+        float rho_m = 0.f;
+        HIPCHK(hipMemcpyAsync(&rho_m, ix->row_rho_dev.p, 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        ix->row_rho = rho_m;
+        ix->scale_rows = ix->n_rows; ix->scale_gen = ix->rows_gen;
+        *ok = true;
+        return ZH_OK;
+    }
+    if (ix->row_half.ensure(std::max<uint64_t>(tiles, 1) * 16 * d * 2, true, ix->stream) != ZH_OK ||
         ix->row_meta.ensure(std::max<uint64_t>(tiles, 1) * 16 * sizeof(float2), true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(4) != ZH_OK) {
         ix->row_half.release(); ix->row_meta.release();
         ix->row_half_failed = true;
@@ -1865,7 +1897,7 @@ static bool use_approx(const zh_index *ix, const ZhTotals &tot, size_t B, size_t
 // (+50 % of the row table; ensure_row_half): mode 5 / ZH_NO_MFMA=1 keep the VALU kernel, which reads the f32 rows.
 static bool mfma_wanted(const zh_index *ix) {
     static const bool off = getenv("ZH_NO_MFMA") != nullptr;
-    return !off && ix->sweep_mode != 5 && zh_scan_mfma_supported(ix->opt.dim, ix->n_trees) &&
+    return !off && ix->sweep_mode != 5 && zh_scan_mfma_supported(ix->opt.dim, ix->n_trees) && !ix->mfma_f32_off &&
            !(ix->row_half_failed && ix->scale_gen == ix->rows_gen && ix->scale_rows == ix->n_rows);
 }
 static bool choose_scan(const zh_index *ix, const ZhTotals &tot, int metric, size_t B, size_t k) {
@@ -2371,6 +2403,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         }
     }
     c->approx_mfma = mfma;
+    c->approx_f32rows = mfma && ix->row_half.p == nullptr;
     if (c->approx) {
         // per query: what final_interval_kernel's sort holds (48 KB per query of HBM).  A visit hands on the rows its intervals cannot
         // rule out: a few more than `take` -- or dozens more where the keys are dense around the cut: the parity cosine key on iid
@@ -2393,7 +2426,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         ap.ex_keys = c->wApExKeys.as<uint64_t>(); ap.ex_ckeys = ap.ex_keys + ex_rows; ap.ex_cids = reinterpret_cast<uint32_t *>(ap.ex_ckeys + ex_rows);
         ap.ex_rows_cap = ex_rows; ap.ctl = c->wApCtl.as<uint32_t>();
         ap.n_queries = (uint32_t)B; ap.iv_cap = tot.rows;
-        ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;
+        ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;  // (row_half null with mfma: the scan converts the f32 rows itself)
         ap.row_rho = mfma ? ix->row_rho : 0.f;
         if (c->approx_leaf) { ap.mfma = 2u; ap.row_rho = ap.rho_norm = ix->h128_rho; }
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
@@ -2545,7 +2578,8 @@ int ctx_wait(zh_search_ctx *c) {
     if (apx && c->h_ap[1]) {
         st.approx_fallbacks_accum++;
         st.approx_last_overflow = c->h_ap[1];
-        ix->approx_strikes.fetch_add(1);
+        if (c->approx_mfma && c->approx_f32rows && ix->approx_strikes.load() >= 1) ix->mfma_f32_off = true;  // (8192-slot lists ran over: the VALU scan next)
+        else ix->approx_strikes.fetch_add(1);
     } else if (apx && (uint64_t)c->h_ap[4] > (uint64_t)c->B * (ix->approx_strikes.load() ? 5600 : 2800))  // lists 70 % full on average: some query's will run over
         ix->approx_strikes.fetch_add(1);
     st.prefiltered = pf ? 1 : 0;

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void row_half_kernel(const float *__restrict__
             s2 = __builtin_fmaf(v, v, s2);
             d2 = __builtin_fmaf(df, df, d2);
             const uint32_t st = e >> 5, w = e & 31, hh = (w & 15) >> 2, j = (w & 3) + ((w >> 4) << 2);
-            tile[((size_t)st * 64 + hh * 16) * 8 + j] = hv;
+            if (Xh) tile[((size_t)st * 64 + hh * 16) * 8 + j] = hv;  // (Xh null: the per-row scales, norms and the rounding error only -- the scan converts the f32 rows itself)
         }
         s2 = wave_sum_canonical(s2);
         d2 = wave_sum_canonical(d2);
@@ -577,7 +577,7 @@ hipError_t zh_launch_permute_row_leaf(const uint2 *dRowLeaf, const uint32_t *dPe
 }
 
 #ifndef ZH_MFMA_EXP
-#define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores, 5 no tile loop
+#define ZH_MFMA_EXP 0   // timing experiments of scan_mfma_kernel (diagnostic builds, results invalid): 1 no MFMA, 2 queries from L1, 3 no LDS staging writes, 4 no result stores, 5 no tile loop, 6 result stores into an L2-resident region
 #endif
 #ifndef ZH_MFMA_CL
 #define ZH_MFMA_CL 0   // A/B: 128-byte query lines per column and chunk (0: by dimension)
@@ -609,9 +609,9 @@ extern "C" __attribute__((visibility("default"))) int zh_debug_scan_prof(uint64_
 #ifndef ZH_MFMA_WAVES
 #define ZH_MFMA_WAVES 3   // A/B: 2 = the compiler's choice at d = 768
 #endif
-template <int D>
+template <int D, bool F32ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D > 768 ? 2 : ZH_MFMA_WAVES, D > 768 ? 2 : ZH_MFMA_WAVES)))
-void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ rowMeta,
+void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float *__restrict__ Xf, const float2 *__restrict__ rowMeta,
                                                          const uint4 *__restrict__ Qh, const uint2 *__restrict__ rowLeaf, uint32_t T,
                                                          uint32_t RW, const uint32_t *__restrict__ visitBits,
                                                          const uint4 *__restrict__ nodeVisit, const ZhGroup *__restrict__ groups,
@@ -664,14 +664,65 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
     SP(__builtin_amdgcn_s_waitcnt(0); const uint64_t sp2 = clock64();)
     // ---- the wave's 16 rows: their fp16 copy, already in the A operand's order (row_half_kernel): D / 32 coalesced 1-KiB loads ----
     f16x8 A[NS];
-    {
+    if constexpr (!F32ROWS) {
         const u32x4v *tp = Xh + (size_t)(r0 >> 4) * (NS * 64) + lane;
 #pragma unroll
         for (int st = 0; st < NS; st++) A[st] = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(tp + 64 * st));
         if (lane < 16) row_meta[wid][lane] = rowMeta[r0 + (lane < nr ? lane : 0u)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        // ---- no fp16 copy of the table (it does not fit beside the rows: 64M x 768 on one GPU): the wave converts its 16 f32 rows itself, with the
+        // per-row scale row_half_kernel would use (rowMeta, made without the copy) and the same rounding -- the operand is bit for bit the copy's tile.
+        // 64 elements of every row at a time: four load instructions (lane (g, p): 16 bytes of row 4 i + g -- four 256-byte runs each), one 4-KiB
+        // LDS image (the column pass's table, idle until then; pieces XOR-swizzled by row as in sweep128h_kernel), read back as the A operand's
+        // k order: lane (c, h), step s: elements 32 s + 4 h .. + 3 and 32 s + 16 + 4 h .. + 3 of row c.
+        if (lane < 16) row_meta[wid][lane] = rowMeta[r0 + (lane < nr ? lane : 0u)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float inv_c = row_meta[wid][c16].y;            // 1 / sigma of row c16 (NaN: unusable -> zeros, as the copy)
+        const bool usable_c = inv_c - inv_c == 0.f;
+        const float sigma_c = usable_c ? 1.0f / inv_c : 0.f; // (a power of two: exact)
+        f32x4v *xt = reinterpret_cast<f32x4v *>(tile_list[wid]);
+        const f32x4v *X4 = reinterpret_cast<const f32x4v *>(Xf);
+        const uint32_t g4 = lane >> 4, p16 = lane & 15;
+        auto cvt8 = [&](const f32x4v lo, const f32x4v hi) {
+            f16x8 o;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                o[t] = usable_c ? f16_no_subnormal(lo[t] * sigma_c) : (_Float16)0.f;
+                o[4 + t] = usable_c ? f16_no_subnormal(hi[t] * sigma_c) : (_Float16)0.f;
+            }
+            return o;
+        };
+        f32x4v Rr[4];
+        auto issue_rows = [&](int kb) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + g4;
+                Rr[i] = __builtin_nontemporal_load(X4 + (size_t)(r0 + (rr < nr ? rr : nr - 1)) * (D / 4) + kb * 16 + p16);
+            }
+        };
+        issue_rows(0);
+#pragma unroll
+        for (int kb = 0; kb < D / 64; kb++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t rr = 4u * i + g4;
+                xt[rr * 16 + (p16 ^ rr)] = Rr[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (kb + 1 < D / 64) issue_rows(kb + 1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const f32x4v lo = xt[c16 * 16 + ((8u * s2 + h) ^ c16)], hi = xt[c16 * 16 + ((8u * s2 + 4u + h) ^ c16)];
+                A[2 * kb + s2] = cvt8(lo, hi);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const float2 *rmeta = row_meta[wid];
     // The query halves of a tile come in FULL 128-byte lines -- lane (g, p) = (lane >> 3, lane & 7) loads 16 bytes of column g's (then
     // column 8 + g's) query, eight lanes a line: eight tag look-ups per load instruction.  Loaded as the MFMA wants them (lane (c, h):
@@ -860,8 +911,12 @@ void scan_mfma_kernel(const u32x4v *__restrict__ Xh, const float2 *__restrict__ 
 #if ZH_MFMA_EXP == 4   // timing experiment (results invalid): one pair in 64 stores its result
                 if ((rec & 63u) == 0u)
 #endif
+#if ZH_MFMA_EXP == 6   // timing experiment (results invalid): every result store lands in 2 MiB that stay in the L2s (the stores' issue and acknowledgement without their HBM side)
+                __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + ((wave & 4095u) * 64u + lane));
+#else
                 if (ZH_GUARD((rec & 0xFFFFFFFFFull) < iv_cap, 2u))
                     __builtin_nontemporal_store(((uint64_t)__float_as_uint(rm.x) << 32) | __float_as_uint(sv * rm.y), iv + (rec & 0xFFFFFFFFFull));
+#endif
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -916,8 +971,12 @@ static hipError_t launch_scan_mfma_d(const float *dX, uint64_t n_rows, const ZhA
         const uint64_t r_end = r + rows_per_launch < n_rows ? r + rows_per_launch : n_rows;
         const uint64_t waves = (r_end - r + RW - 1) / RW, blocks = (waves + 3) / 4;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((scan_mfma_kernel<D>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)ap.row_half, ap.row_meta, (const uint4 *)ap.Qh, dRowLeaf, T, RW,
-                           dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv, ap.ctl + 5, ap.n_queries, ap.iv_cap, ap.ctl + 7);
+        if (ap.row_half)
+            hipLaunchKernelGGL((scan_mfma_kernel<D, false>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)ap.row_half, dX, ap.row_meta, (const uint4 *)ap.Qh, dRowLeaf, T, RW,
+                               dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv, ap.ctl + 5, ap.n_queries, ap.iv_cap, ap.ctl + 7);
+        else  // no fp16 copy (no room for it): the scan converts the f32 rows itself (rows in id order)
+            hipLaunchKernelGGL((scan_mfma_kernel<D, true>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4v *)nullptr, dX, ap.row_meta, (const uint4 *)ap.Qh, dRowLeaf, T, RW,
+                               dVisitBits, dNodeVisit, dGroups, group, r, r_end, ap.iv, ap.ctl + 5, ap.n_queries, ap.iv_cap, ap.ctl + 7);
     }
     return hipGetLastError();
 }
