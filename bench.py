@@ -591,7 +591,8 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # intervals, the bounds and the queries' candidate lists are made inside the sweep -- no 8-byte result per scored row is written (or read
         # back by a select pass), so the algorithmic bytes per scored row are the row (2 d, once per distinct leaf group) and its 4-byte leaf id
         per_row = 4.0 if fused else 12.0
-        kname = "sweep128h_lean_kernel<16, KINDA> (fused: intervals + bounds + lists in the sweep)" if fused else "sweep128h_lean_kernel<4, -1>"
+        kinda = 0 if wl["metric"] != "cosine" else 2  # (approx_interval's kind: 0 the L2 family, 2 the reference's literal cosine key)
+        kname = ("sweep128h_lean_kernel<16, %d>" % kinda) if fused else "sweep128h_lean_kernel<4, -1>"
         bytes_alg = 2.0 * d * rows_per_launch * uniq_frac + per_row * rows_per_launch + 2.0 * d * B / launches_per_batch
         bytes_nosharing = (2.0 * d + per_row) * rows_per_launch
     elif half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
@@ -628,6 +629,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # Leaf-major sweep: SURVEY s8(d)'s bytes ARE what the kernel moves through HBM (PMC traffic 0.99-1.01x): HBM roofline.
         roof = {"bound": "hbm", "achieved": s8d_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s8d_GBps / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": bytes_alg,
+                "sweep_mode": ("leaf by leaf at HALF WIDTH, FUSED: fp16 rows (one table scale) x fp16 queries on v_mfma_f32_16x16x32_f16; the intervals, "
+                               "a running top-k bound per visit and wave, and the queries' candidate lists are made inside the sweep -- no per-pair "
+                               "result is written, no select pass reads one back (zh_approx.hip, round 6)") if fused else
+                              ("leaf by leaf at half width: raw pairs to the key scratch, select_tau / select_emit behind" if leaf_half else
+                               "leaf by leaf, f32 rows, canonical keys"),
                 "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0,
                 # what a bare random whole-row gather into registers reaches on this chip (no arithmetic, same access shape, 64-GB
                 # table; profiles/micro/gather512.hip -> profiles/micro/r03_gather512.csv): the ceiling of a leaf-major sweep
@@ -889,7 +895,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(args, name, S, roof):
+def pmc_traffic(args, name, S, roof, prof_override=None):
     """roofline.traffic: HBM-side (fabric) bytes per sweep launch from the rocprofv3 PMC passes of THIS command -- separate --pmc
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section), collected with
     --serial-windows at the SAME --window as the timed run (kernels must not overlap for per-kernel counters) and summarised
@@ -898,6 +904,7 @@ def pmc_traffic(args, name, S, roof):
     travels with it, next to the last commit that touched the kernel sources."""
     prof_name = {("cfg3", 1): "cfg3", ("cfg2", 1): "cfg2", ("cfg4", 8): "cfg4shard", ("cfg5", 8): "cfg5shard", ("refdefault", 1): "refdefault",
                  ("scale64m", 1): "scale64m"}.get((name, S))
+    prof_name = prof_override or prof_name
     cands = [args.pmc_summary] if args.pmc_summary else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % prof_name)))
     if not cands or not prof_name or args.rows:
         return
@@ -1134,7 +1141,7 @@ def main():
             torch.cuda.empty_cache()
             if is_cos:
                 later.append((key, wname, shards, win, r if in_place else None))
-            pmc_traffic(args, wname, shards, r["roofline"])
+            pmc_traffic(args, wname, shards, r["roofline"], prof_override="cfg3leaf" if key == "cfg3_leaf_major_f32" else None)
             other[key] = {"queries_per_s_this_gpu": r["qps"], "ms_per_batch": r["ms_per_step"], "steps": r["steps"],
                           "config": r["config"], "roofline": {kk: r["roofline"][kk] for kk in
                                                               ("bound", "kernel", "achieved", "peak", "frac", "launch_ms", "bytes_per_launch", "unique_row_fraction", "launches_per_batch",

@@ -3,8 +3,8 @@
 # `--`, as MI355X_MICROARCH.md prescribes):   gpurun -- bash profiles/collect.sh r02 <commit> [configs...]
 # then, back in the container:                python profiles/summarize.py r02 <commit>
 # Every configuration is its own command, so that a kernel name in a stats file belongs to ONE workload.
-TAG=${1:-r05}; COMMIT=${2:-unknown}; shift 2
-CFGS=${@:-"cfg3 cfg2 cfg4shard cfg5shard refdefault scale64m hashbig"}
+TAG=${1:-r06}; COMMIT=${2:-unknown}; shift 2
+CFGS=${@:-"cfg3 cfg3leaf cfg2 cfg4shard cfg5shard refdefault scale64m hashbig"}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -18,6 +18,7 @@ common="--cpu-seconds 0 --no-recall --no-other-configs --profile-run"
 for c in $CFGS; do
   case $c in
     cfg3)       args="bench.py --steps 6 --warmup 2 $common" ;;
+    cfg3leaf)   args="bench.py --sweep-mode leaf --steps 4 --warmup 2 $common" ;;             # the f32 leaf-major sweep of the bench line's workload (HBM-bound)
     cfg3clu)    args="bench.py --data clustered --steps 6 --warmup 2 $common" ;;            # rows inserted cluster by cluster
     cfg3shuf)   args="bench.py --data clustered-shuffled --steps 6 --warmup 2 $common" ;;   # the same clusters, ids scattered
     cfg2)       args="bench.py --workload cfg2 --steps 20 --warmup 3 $common" ;;
