@@ -66,7 +66,9 @@ WORKLOADS = {
                  desc="10M x 768-d L2 top-100, query batch=1024, 1 MI355X (HBM-bound candidate sweep)"),
     "cfg4": dict(rows=100_000_000, dim=768, metric="cosine", k=10, batch=1024, M=32768, T=15, kind=0,
                  desc="100M x 768-d cosine top-10, batch=1024, vectors sharded across GPUs + RCCL top-k merge"),
-    "cfg5": dict(rows=1_000_000_000, dim=128, metric="l2", k=10, batch=4096, M=65536, T=15, kind=1,
+    # (window 4, round 6: the fused half-width sweep is HBM-bound on the rows it loads, and a leaf's rows are loaded once per group of <= 4 queries
+    # of the WINDOW: 0.69 row loads per scored row at four batches against 0.83 at two -- 370 k against 315 k QPS on one shard, for twice the latency)
+    "cfg5": dict(rows=1_000_000_000, dim=128, metric="l2", k=10, batch=4096, M=65536, T=15, kind=1, window=4,
                  desc="1B x 128-d SIFT-style L2 top-10, batch=4096, 8 GPUs"),
     "scale64m": dict(rows=64_000_000, dim=768, metric="cosine", k=10, batch=1024, M=32768, T=15, kind=0,
                      desc="64M x 768-d cosine top-10, batch=1024 (the metric's shape at the largest N that fits one GPU), "
