@@ -600,9 +600,9 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
     elif half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
         if st.get("approx_scan", 0) == 2:
-            kname = "scan_mfma_kernel<%d>" % d  # the same scan on the matrix cores, from the index's fp16 copy of the stored rows
-            if st.get("row_copy_bytes", 0) < rows_local * d:  # no room for the copy (2 d bytes per row): the scan converts the f32 rows itself
-                kname = "scan_mfma_kernel<%d, f32 rows converted in the scan>" % d
+            # the same scan on the matrix cores: <D, false> from the index's fp16 copy of the stored rows; <D, true> (no room for the copy, 2 d bytes per
+            # row): the scan converts the f32 rows itself
+            kname = "scan_mfma_kernel<%d, %s>" % (d, "true" if st.get("row_copy_bytes", 0) < rows_local * d else "false")
     s8d_GBps = bytes_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     common = {"kernel": kname, "launch_ms": sweep_ms, "rows_per_launch": rows_per_launch, "unique_row_fraction": uniq_frac,
               "rows_loaded_per_launch": st["swept_rows_accum"] / n_launch, "launches_per_batch": launches_per_batch,
