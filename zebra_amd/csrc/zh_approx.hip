@@ -1354,21 +1354,24 @@ __global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__rest
 
 // ---- round 6: the same sweep with a LEAN instruction stream for the common chunk.  The two kernels above spend ~270 instructions of a wave on
 // a 16-row tile (ids -> ds_bpermute -> 64-bit addresses, sixteen dependent v_dot2 + a butterfly for |x^|^2, per-lane group look-ups through
-// __shfl, up to four predicated 64-bit-address stores): at four waves per SIMD the issue slots, not HBM, set the pace (0.54 of 8 TB/s, DESIGN.md
-// s9).  A leaf is thousands of rows and a chunk is 64: all but ~1 chunk in 70 lie inside ONE (leaf, <= 4 queries) group, and for those everything
-// that is per-row bookkeeping above is wave-uniform:
-//   * the group's record sits in scalar registers; A's row m is query slot m >> 2 of THE group, so lane (c, h)'s first accumulator is slot h
-//     against stored row c: ONE store instruction per tile (h < gsize), its address the lane's per-chunk base + an immediate;
+// __shfl, up to four predicated 64-bit-address stores), which round 5 took for what holds them at 0.54 of 8 TB/s.  It is not: this kernel spends ~55
+// and, storing as they do, ran no faster -- what it bought is room for the fused form below.  A leaf is thousands of rows and a chunk
+// is 64: all but ~1 chunk in 70 lie inside ONE (leaf, <= 4 queries) group, and for those everything that is per-row bookkeeping above is wave-uniform:
+//   * the group's record sits in scalar registers; A's row m is query slot m & 3 of THE group, so every lane (c, h) holds stored row c against all
+//     four slots (accumulator j = slot j); the lanes of 16-lane row h keep tile h's, so that after a chunk's four tiles lane l holds flat row l:
+//     unfused, ONE 512-byte run of results per slot and chunk (a 128-byte run per slot and tile cost 8 % more: scattered writes among the row
+//     reads are dearer than their bytes);
 //   * the chunk's ids are loaded in the order lane (h, c) = flat row 4 c + h: instruction i of tile t wants row 4 (4 t + i) + h -- the same
 //     16-lane row, lane 4 t + i: a DPP row_newbcast, no LDS crossbar;
 //   * |x^|^2 is the DIAGONAL of the tile's Gram matrix: four more MFMAs with the B fragments as both operands (the A and B layouts of
 //     v_mfma_f32_16x16x32_f16 coincide) on a matrix pipe that has nothing else to do, three selects and one ds_bpermute;
 //   * the four K-steps chain through one accumulator.
-// ~45 instructions per tile.  A chunk that crosses a group boundary (or the launch's last, short one) runs the general per-lane form of the
-// kernel above, one chunk at a time.  Same raw pairs up to the summation order inside the matrix pipe (covered by zh_approx_bound's MFMA term,
-// tests/test_gpu_intervals.py) -- the results behind them are bit-identical by construction as before.
-// ---- the fused sweep (round 6).  The stores of the raw pairs -- 3 % of the sweep's bytes -- cost the lean kernel a fifth of its time (0.99 ms per
-// 25M-row launch without them = the bare gather's 6.7 TB/s, 1.23-1.30 with; profiles/r06_sweep128h_experiments.txt), and select_tau_kernel /
+// A chunk that crosses a group boundary (or the batch's last, short one) is sweep128h_boundary_kernel's: the general per-lane form of the kernel above,
+// one chunk at a time, one launch per batch (lean_chunk() is the predicate both kernels split the chunks by).  Same raw pairs up to the summation
+// order inside the matrix pipe (covered by zh_approx_bound's MFMA term, tests/test_gpu_intervals.py) -- the results behind them are bit-identical
+// by construction as before.
+// ---- the fused sweep (round 6).  The stores of the raw pairs -- under 4 % of the sweep's bytes -- cost the lean kernel a fifth of its time (0.99 ms per
+// 25M-row launch without them = the bare gather's 6.5 TB/s, 1.23-1.30 with; profiles/r06_sweep128h_experiments.txt), and select_tau_kernel /
 // select_emit_kernel then read them all back (7 ms per window of a cfg5 shard) to keep ~60 per query.  Fused, a chunk's 64 results never leave the
 // wave: per slot (= a visit of the leaf by one query, lsh.rs:290-330)
 //   * the interval of every row (approx_interval: the arithmetic select_tau_kernel applies to the raw pair, same operands, same bits);
