@@ -290,6 +290,31 @@ def test_leaf_major_half_width_adversarial_rows_appends_and_overflow(za, monkeyp
     ix.close()
 
 
+def test_fused_sweep_is_the_librarys_choice_for_long_leaves_and_steps_back_after_an_overflow(za, monkeypatch):
+    """leaves of thousands of rows: the library picks the FUSED half-width sweep by itself (no switch set); lists that run over send the index to the
+    unfused sweep (select_tau / select_emit: exact per-visit bounds, shorter lists) instead of the f32 sweep"""
+    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA"):
+        monkeypatch.delenv(var, raising=False)
+    n, d, M, T, k, B = 24000, 128, 5000, 4, 10, 40
+    X = zo.synth_rows(n, d, kind=1)
+    Q = zo.synth_queries(B, d, n, kind=1)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.add(X)
+    ix.set_sweep_mode("leaf-half")
+    ix.set_hash_mode("dense")
+    m, om = za.L2Distance(), zo.L2
+    st = check(ix, f, Q, k, m, om, 0, "library's choice")
+    assert st["approx_scan"] == 3 and st["approx_fused"] == 1 and st["approx_fallbacks_accum"] == 0, st
+    monkeypatch.setenv("ZH_APX_CAPS", "16,0,0")
+    st = check(ix, f, Q, k, m, om, 0, "lists run over")          # redone by the f32 sweep on the device: still the oracle's answer
+    assert st["approx_fused"] == 1 and st["approx_fallbacks_accum"] == 1, st
+    monkeypatch.delenv("ZH_APX_CAPS")
+    st = check(ix, f, Q, k, m, om, 0, "after the overflow")
+    assert st["approx_scan"] == 3 and st["approx_fused"] == 0 and st["approx_fallbacks_accum"] == 1, st
+    ix.close()
+
+
 def test_matrix_core_scan_follows_the_stored_rows(za):
     """the matrix-core scan keeps an fp16 copy of the stored rows, a scale per row and the largest relative rounding error of any row
     (row_half_kernel): all three must follow

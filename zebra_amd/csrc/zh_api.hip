@@ -450,6 +450,9 @@ struct zh_index {
     // the matrix-core scan on f32 rows (no fp16 copy) rounds the rows as well: wider intervals, longer lists.  Lists that run over at 8192 slots send the
     // index back to the VALU half-width scan (which rounds the queries only) instead of all the way to the f32 scan
     std::atomic<bool> mfma_f32_off{false};
+    // ... and a FUSED d = 128 sweep whose lists ran over (it hands on what the bounds known at the time cannot rule out: more than the select pass's exact
+    // per-visit bounds would) goes back to the unfused half-width sweep first, not to the f32 sweep
+    std::atomic<bool> fused_off{false};
     int hash_mode = 0;   // zh_set_hash_mode: 0 chosen per batch, 1 one dot product per plane, 2 row scores where the forest allows
     // the two sample rows of every plane (build_hyperplane, lsh.rs:197-225), kept for forests this library built or grew: the
     // row-score hash derives signs from them.  An injected forest (zh_index_set_forest) has arbitrary planes: not valid.
@@ -614,7 +617,7 @@ static void free_forest(zh_index *ix) {
     ix->planes.release(); ix->consts.release(); ix->leaf_ids.release();
     ix->blk_recs.release(); ix->blk_upper.release(); ix->blk_roots.release();
     ix->n_blocks = 0; ix->blocks_valid = false;
-    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false;
+    ix->leaf_meta.release(); ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false; ix->fused_off = false;
     ix->row_leaf.release(); ix->row_leaf_valid = false; ix->row_leaf_failed = false; ix->scan_unsafe = false;
     {
         // the matrix-core scan's row order was measured on THIS forest's leaves: the next half-width batch re-makes the copy in the new forest's
@@ -789,7 +792,7 @@ static int upload_nodes(zh_index *ix) {
     ix->n_nodes = (uint32_t)nn;
     ix->n_trees = (uint32_t)ix->h_roots.size();
     ix->blocks_valid = false;  // the trees changed
-    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false;
+    ix->leaf_meta_valid = false; ix->prefilter_strikes = 0; ix->approx_strikes = 0; ix->mfma_f32_off = false; ix->fused_off = false;
     ix->row_leaf_valid = false; ix->row_leaf_failed = false;
     ix->batches_since_change = 0;
     ix->max_leaf_len = 0;
@@ -2448,7 +2451,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (c->approx_leaf && k <= 64 && !ix->debug_keep_raw) {
         const char *fe = getenv("ZH_S128H_FUSED"), *ke = getenv("ZH_S128H_KERNEL"), *de = getenv("ZH_S128H_DMA");
         const bool lean = !(ke && ke[0] == 'r') && !(de && de[0] == '1');
-        c->approx_fused = lean && (fe ? fe[0] == '1' : tot.rows >= 1024 * std::max<uint64_t>(tot.visits, 1));
+        c->approx_fused = lean && (fe ? fe[0] == '1' : (!ix->fused_off && tot.rows >= 1024 * std::max<uint64_t>(tot.visits, 1)));
     }
     const int kinda = c->metric != ZH_COSINE ? 0 : (c->mode == ZH_COSINE_PARITY ? 2 : 1);
     if (c->approx_leaf)
@@ -2579,6 +2582,7 @@ int ctx_wait(zh_search_ctx *c) {
         st.approx_fallbacks_accum++;
         st.approx_last_overflow = c->h_ap[1];
         if (c->approx_mfma && c->approx_f32rows && ix->approx_strikes.load() >= 1) ix->mfma_f32_off = true;  // (8192-slot lists ran over: the VALU scan next)
+        else if (c->approx_leaf && c->approx_fused && !ix->fused_off) ix->fused_off = true;                     // (the fused sweep's lists ran over: the select pass next)
         else ix->approx_strikes.fetch_add(1);
     } else if (apx && (uint64_t)c->h_ap[4] > (uint64_t)c->B * (ix->approx_strikes.load() ? 5600 : 2800))  // lists 70 % full on average: some query's will run over
         ix->approx_strikes.fetch_add(1);
