@@ -430,7 +430,9 @@ ZH_API int zh_ref_header_encode(const zh_ref_header *header, const uint8_t *mode
  * scored pair.  lo / hi are f32 values in the scale the scan ranks in, mapped to order-preserving u32 ("sortable": bits ^ (sign ? ~0 :
  * 0x80000000)): L2 family: the canonical f32 sum of (x_i - q_i)^2; cosine, corrected key: the clipped distance 1 - cos; the reference's
  * literal key (distance.rs:23-25): key > 0 ? key : 2 - key for key = 1 - distance.  (lo, hi) = (0, ~0): nothing is certain about the pair
- * (it takes the exact path).  Not a product path: host-side copies of the whole batch's scratch. */
+ * (it takes the exact path).  Not a product path: host-side copies of the whole batch's scratch.  While zh_debug_keep_raw is on, the d = 128
+ * half-width sweep is never FUSED (a fused sweep -- zh_stats_t::approx_fused -- writes no per-pair result at all: zh_debug_scan_pairs after one
+ * returns ZH_ESTATE). */
 typedef struct zh_debug_pair {
     uint32_t row;          /* stored row (local: without id_base) */
     uint32_t query;        /* query of the batch (of the window: batch * b + i) */

@@ -2757,6 +2757,8 @@ extern "C" int zh_debug_scan_pairs(zh_index *ix, zh_search_ctx *ctx, zh_debug_sc
     if (rc) return rc;
     memset(info, 0, sizeof(*info));
     if (!c->dbg_valid) return ZH_OK;  // (approx_scan 0: the last batch was not a half-width one)
+    if (c->approx_leaf && c->approx_fused)  // (a fused sweep leaves no interval per pair anywhere: zh_debug_keep_raw keeps the sweep unfused)
+        return fail(ZH_ESTATE, "zh_debug_scan_pairs: the batch's sweep was fused (no per-pair results exist); call zh_debug_keep_raw(idx, 1) first");
     const ZhTotals tot = c->tot;
     const ZhApprox &ap = c->dbg_ap;
     info->approx_scan = c->approx_leaf ? 3 : (c->approx_mfma ? 2 : 1);
