@@ -500,7 +500,12 @@ struct zh_index {
         zh_search_ctx ctx2;
         bool init2 = false;
         hipStream_t s2 = nullptr;
-        hipEvent_t ev_d2h[2] = {nullptr, nullptr};
+        // ... and, where hash + walk of a window outweigh its sweep (the crate's default options: thousands of leaf visits per pair), a third:
+        // window w + 1 is BEGUN before window w is finished (its hash runs beside w's walk), as bench.py's look-ahead loop does (round 6)
+        zh_search_ctx ctx3;
+        bool init3 = false;
+        hipStream_t s3 = nullptr;
+        hipEvent_t ev_d2h[3] = {nullptr, nullptr, nullptr};
         DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
         void *h_stage = nullptr;  // pinned staging of a combined batch: queries in, results out (one H2D, three D2H per round)
         size_t h_stage_cap = 0;
@@ -645,7 +650,9 @@ extern "C" void zh_index_destroy(zh_index *ix) {
         for (auto &ln : ix->lanes) {
             if (ln.init) { hipSetDevice(ix->device); ln.ctx.release_all(); }
             if (ln.init2) { hipSetDevice(ix->device); ln.ctx2.release_all(); }
+            if (ln.init3) { hipSetDevice(ix->device); ln.ctx3.release_all(); }
             if (ln.s2) hipStreamDestroy(ln.s2);
+            if (ln.s3) hipStreamDestroy(ln.s3);
             for (auto &ev : ln.ev_d2h) if (ev) hipEventDestroy(ev);
             ln.wQ.release(); ln.wOutIds.release(); ln.wOutKeys.release(); ln.wOutCounts.release();
             if (ln.s) hipStreamDestroy(ln.s);
@@ -2819,7 +2826,7 @@ static size_t host_window_queries(const zh_index *ix, bool wander) {
     return d >= 512 ? 2048 : (d >= 256 ? 1024 : 4096);
 }
 // the window size for this call, or 0: the classic path (one internal batch, split only by its own limits)
-static size_t host_windows_wanted(zh_index *ix, size_t B, size_t k) {
+static size_t host_windows_wanted(zh_index *ix, size_t B, size_t k, bool *wander) {
     const bool off = getenv("ZH_NO_HOST_WINDOWS") != nullptr;  // (read per call: tests switch it)
     if (off || ix->n_trees == 0 || ix->n_rows == 0) return 0;
     double vpp;
@@ -2835,28 +2842,36 @@ static size_t host_windows_wanted(zh_index *ix, size_t B, size_t k) {
     }
     const size_t wq = host_window_queries(ix, vpp > 4.0);
     if (B < 2 * wq && B < wq + wq / 2) return 0;
+    *wander = vpp > 4.0;
     return wq;
 }
 // returns ZH_OK with every result in the caller's buffers, or an error after which BOTH contexts are idle and nothing is in flight (the caller
 // then runs the classic path: a window that passes a per-batch limit is not an error of the call)
-static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
+static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, bool ahead, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
                                uint64_t *out_keys, uint32_t *out_counts) {
     const uint32_t d = ix->opt.dim;
     int rc;
-    if (!ln.init2) {
-        if ((rc = ctx_init(&ln.ctx2, ix))) { ln.ctx2.release_all(); return rc; }
+    auto init_ctx = [&](zh_search_ctx *c, hipStream_t *st, bool *flag) -> int {
+        if (*flag) return ZH_OK;
+        int r = ctx_init(c, ix);
+        if (r) { c->release_all(); return r; }
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        hipError_t e = hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, hi);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ln.ev_d2h[i], hipEventDisableTiming);
+        hipError_t e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+        for (auto &ev : ln.ev_d2h)
+            if (e == hipSuccess && !ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) {
-            ln.ctx2.release_all();
-            if (ln.s2) { hipStreamDestroy(ln.s2); ln.s2 = nullptr; }
-            for (auto &ev : ln.ev_d2h) if (ev) { hipEventDestroy(ev); ev = nullptr; }
+            c->release_all();
+            if (*st) { hipStreamDestroy(*st); *st = nullptr; }
             return fail(ZH_EHIP, "host windows: %s", hipGetErrorString(e));
         }
-        ln.init2 = true;
-    }
+        *flag = true;
+        return ZH_OK;
+    };
+    if ((rc = init_ctx(&ln.ctx2, &ln.s2, &ln.init2))) return rc;
+    if (ahead && init_ctx(&ln.ctx3, &ln.s3, &ln.init3) != ZH_OK) ahead = false;  // (no room for a third context: two, begin + finish back to back)
+    const int NC = ahead ? 3 : 2;                 // contexts the windows rotate through
+    const size_t A = ahead ? 1 : 0;               // windows begun ahead of the one being finished
     const size_t nw = (B + wq - 1) / wq, per = (B + nw - 1) / nw;
     const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;
     if (need > ln.h_stage_cap) {
@@ -2873,12 +2888,12 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, cons
     uint32_t *dCounts = ln.wOutCounts.as<uint32_t>();
     uint64_t *hIds = reinterpret_cast<uint64_t *>(hs + off_ids), *hKeys = reinterpret_cast<uint64_t *>(hs + off_keys);
     uint32_t *hCounts = reinterpret_cast<uint32_t *>(hs + off_counts);
-    zh_search_ctx *ctxs[2] = {&ln.ctx, &ln.ctx2};
-    hipStream_t str[2] = {ln.s, ln.s2};
+    zh_search_ctx *ctxs[3] = {&ln.ctx, &ln.ctx2, &ln.ctx3};
+    hipStream_t str[3] = {ln.s, ln.s2, ln.s3};
     auto win = [&](size_t w, size_t *b0, size_t *nb) { *b0 = w * per; *nb = std::min(per, B - *b0); };
-    auto bail = [&](int code) {  // leave nothing in flight: what was begun is abandoned, what was finished is retired, both streams drained
+    auto bail = [&](int code) {  // leave nothing in flight: what was begun is abandoned, what was finished is retired, every stream drained
         const std::string why = g_err;
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NC; i++) {
             zh_search_ctx_abandon(ctxs[i]);
             if (ctxs[i]->state == 2) ctx_wait(ctxs[i]);
             hipStreamSynchronize(str[i]);
@@ -2888,7 +2903,7 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, cons
         return code;
     };
     auto retire = [&](size_t w) -> int {  // window w: wait (its outputs are complete only then), results -> pinned staging, behind them an event
-        const int i = (int)(w & 1);
+        const int i = (int)(w % NC);
         size_t b0, nb;
         win(w, &b0, &nb);
         int r = ctx_wait(ctxs[i]);
@@ -2905,31 +2920,46 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, cons
     auto hand_out = [&](size_t w) -> int {  // window w's results, once its copies have landed, into the caller's buffers
         size_t b0, nb;
         win(w, &b0, &nb);
-        hipError_t e = hipEventSynchronize(ln.ev_d2h[w & 1]);
+        hipError_t e = hipEventSynchronize(ln.ev_d2h[w % NC]);
         if (e != hipSuccess) return fail(ZH_EHIP, "host windows: %s", hipGetErrorString(e));
         if (k) { memcpy(out_ids + b0 * k, hIds + b0 * k, nb * k * 8); memcpy(out_keys + b0 * k, hKeys + b0 * k, nb * k * 8); }
         memcpy(out_counts + b0, hCounts + b0, nb * 4);
         return ZH_OK;
     };
-    for (size_t w = 0; w < nw; w++) {
-        const int i = (int)(w & 1);
-        size_t b0, nb;
-        win(w, &b0, &nb);
-        if (w >= 2 && (rc = retire(w - 2))) return bail(rc);
-        memcpy(hs + b0 * d * 4, q + b0 * d, nb * d * 4);  // (pageable -> pinned: the copy engine then runs beside the other window's kernels)
-        hipError_t e = hipMemcpyAsync(dQ + b0 * d, hs + b0 * d * 4, nb * d * 4, hipMemcpyHostToDevice, str[i]);
-        if (e != hipSuccess) return bail(fail(ZH_EHIP, "host windows, H2D: %s", hipGetErrorString(e)));
-        const float *dq = dQ + b0 * d;
-        uint64_t *oi = dIds + b0 * k, *ok = dKeys + b0 * k;
-        uint32_t *oc = dCounts + b0;
-        if ((rc = ctx_begin(ctxs[i], &dq, 1, nb, k, metric, mode, str[i]))) return bail(rc);
-        if ((rc = ctx_finish(ctxs[i], &oi, &ok, &oc, ix->sweep_stream))) return bail(rc);
-        if (w >= 3 && (rc = hand_out(w - 3))) return bail(rc);  // (its copies were queued one iteration ago: landed long since)
+    // window w is BEGUN at step w (its context: that of window w - NC, retired first; that window's results are handed out one step later, before
+    // its pinned event is recorded again) and FINISHED at step w + A
+    for (size_t step = 0; step < nw + A; step++) {
+        if (step < nw) {
+            const size_t w = step;
+            const int i = (int)(w % NC);
+            size_t b0, nb;
+            win(w, &b0, &nb);
+            if (w >= (size_t)NC) {
+                if (w >= (size_t)NC + 1 && (rc = hand_out(w - NC - 1))) return bail(rc);  // (its copies were queued one step ago: landed long since)
+                if ((rc = retire(w - NC))) return bail(rc);
+            }
+            memcpy(hs + b0 * d * 4, q + b0 * d, nb * d * 4);  // (pageable -> pinned: the copy engine then runs beside the other windows' kernels)
+            hipError_t e = hipMemcpyAsync(dQ + b0 * d, hs + b0 * d * 4, nb * d * 4, hipMemcpyHostToDevice, str[i]);
+            if (e != hipSuccess) return bail(fail(ZH_EHIP, "host windows, H2D: %s", hipGetErrorString(e)));
+            const float *dq = dQ + b0 * d;
+            if ((rc = ctx_begin(ctxs[i], &dq, 1, nb, k, metric, mode, str[i]))) return bail(rc);
+        }
+        if (step >= A) {
+            const size_t w = step - A;
+            size_t b0, nb;
+            win(w, &b0, &nb);
+            uint64_t *oi = dIds + b0 * k, *ok = dKeys + b0 * k;
+            uint32_t *oc = dCounts + b0;
+            if ((rc = ctx_finish(ctxs[w % NC], &oi, &ok, &oc, ix->sweep_stream))) return bail(rc);
+        }
     }
-    for (size_t w = nw >= 2 ? nw - 2 : 0; w < nw; w++)
+    // what is still in flight: the last NC windows were never retired, the one before them not handed out
+    const size_t first_unretired = nw > (size_t)NC ? nw - NC : 0;
+    if (first_unretired >= 1 && (rc = hand_out(first_unretired - 1))) return bail(rc);
+    for (size_t w = first_unretired; w < nw; w++) {
         if ((rc = retire(w))) return bail(rc);
-    for (size_t w = nw >= 3 ? nw - 3 : 0; w < nw; w++)
         if ((rc = hand_out(w))) return bail(rc);
+    }
     return ZH_OK;
 }
 
@@ -2959,9 +2989,12 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     if ((rc = ln.wQ.ensure(B * d * 4)) || (rc = ln.wOutIds.ensure(std::max<size_t>(B * k, 1) * 8)) ||
         (rc = ln.wOutKeys.ensure(std::max<size_t>(B * k, 1) * 8)) || (rc = ln.wOutCounts.ensure(B * 4)))
         return all_fail(rc);
-    const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B, k) : 0;
-    if (wq) {  // one large batch: windows over two contexts, copies beside the kernels
-        if (search_host_windows(ix, ln, wq, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
+    bool wander = false;
+    const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B, k, &wander) : 0;
+    if (wq) {  // one large batch: windows over two contexts (three, one begun ahead, where the walk wanders), copies beside the kernels
+        const char *la_e = getenv("ZH_HOST_LOOKAHEAD");  // tests / A-B, read per call: 0 never, 1 always
+        const bool ahead = la_e ? la_e[0] == '1' : wander;
+        if (search_host_windows(ix, ln, wq, ahead, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
             std::lock_guard<std::mutex> ls(ix->stats_mu);
             ix->stats.host_window_calls_accum++;
             return;
