@@ -2605,7 +2605,10 @@ int ctx_wait(zh_search_ctx *c) {
         st.timed_batches++;
         st.sweep_rows_accum += tot.rows;
         st.swept_rows_accum += swept;
-        const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim);
+        // (the half-width d = 128 sweep's lean kernels take twice the rows per launch: 256-byte rows -- launch_sweep128h_lean)
+        const char *ke = getenv("ZH_S128H_KERNEL"), *de = getenv("ZH_S128H_DMA");
+        const bool lean128 = apx && c->approx_leaf && !(ke && ke[0] == 'r') && !(de && de[0] == '1');
+        const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim) * (lean128 ? 2 : 1);
         st.sweep_launches_accum += (swept + rpl - 1) / rpl;
         st.scan_batches_accum += c->scan && !pf ? 1 : 0;
         st.approx_batches_accum += apx ? 1 : 0;

@@ -1801,7 +1801,10 @@ template <int FUSE>
 static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                   const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, const ZhApprox &ap,
                                   uint32_t k_top, float Kc, hipStream_t s) {
-    const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
+    // zh_sweep_rows_per_launch sizes a launch as ~12 GB of F32 rows (~2 ms of HBM time: other queues get dispatch slots between launches); this sweep
+    // reads 256-byte rows -- the same row count was a 1.1-ms launch whose tail (24.6k waves over 4096 wave slots: six rounds, the last one partly
+    // empty) cost 6-7 %: twice the rows, the same ~2.2 ms (cfg5 shard, window 4: 359-367 -> 383-384 k QPS; four times: 390-392 k)
+    const uint64_t rows_per_launch = 2 * zh_sweep_rows_per_launch(128);
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         constexpr int CHL = FUSE >= 0 ? ZH_S128F_CH : ZH_S128L_CH;
