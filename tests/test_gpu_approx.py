@@ -380,3 +380,57 @@ def test_windows_through_contexts_and_default_mode(za):
         assert (counts == oc).all() and (ids == oi).all() and (keys == ok).all()
     ctx.close()
     ix.close()
+
+
+def test_fused_sweep_through_pipelined_contexts_windows_and_a_shard_group(za, monkeypatch):
+    """what bench.py's cfg5 loop does, in small: two contexts in flight, each a WINDOW of several batches, the d = 128 sweep FUSED (lists, bounds and
+    counters are per context: nothing of one window may leak into the other), directly and through a one-rank shard group (the exchange's merge behind it)"""
+    import torch
+    monkeypatch.setenv("ZH_S128H_FUSED", "1")
+    n, d, M, T, k, B, W = 16000, 128, 1500, 6, 10, 40, 3
+    X = zo.synth_rows(n, d, kind=1)
+    f = zo.Forest.build(X, M, T)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T), id_base=7)
+    ix.add(X)
+    ix.set_sweep_mode("leaf-half")
+    ix.set_hash_mode("dense")
+    g = za.ShardGroup(ix, za.shard_unique_id(), 1, 0)
+    dev = torch.device("cuda", 0)
+    m, om = za.L2Distance(), zo.L2
+    for make in (lambda: ix.search_context(), lambda: g.search_context()):
+        ctxs = [make(), make()]
+        sharded = isinstance(ctxs[0], za.ShardContext)
+        rounds = 4
+        Qh = [[zo.synth_queries(B, d, n, b0=(r * W + j) * B, kind=1) for j in range(W)] for r in range(rounds)]
+        Qs = [[torch.from_numpy(q).to(dev) for q in row] for row in Qh]
+        outs = [[[torch.zeros((B, k), dtype=torch.int64, device=dev), torch.zeros((B, k), dtype=torch.int64, device=dev),
+                  torch.zeros(B, dtype=torch.int32, device=dev)] for _ in range(W)] for _ in range(rounds)]
+
+        def begin(c, r):
+            args = ([q.data_ptr() for q in Qs[r]], B, k, m)
+            c.begin_window(*args) if sharded else c.begin_window(*args, None)
+
+        def finish(c, r):
+            ptrs = [[o[i].data_ptr() for o in outs[r]] for i in range(3)]
+            c.finish_window(*ptrs) if sharded else c.finish_window(*ptrs, None)
+
+        begin(ctxs[0], 0)
+        finish(ctxs[0], 0)
+        for r in range(1, rounds):        # window r is begun and finished while window r - 1 is still on the GPU
+            begin(ctxs[r & 1], r)
+            finish(ctxs[r & 1], r)
+            ctxs[(r - 1) & 1].wait()
+        ctxs[(rounds - 1) & 1].wait()
+        torch.cuda.synchronize()
+        st = ix.stats()
+        assert st["approx_scan"] == 3 and st["approx_fused"] == 1 and st["approx_fallbacks_accum"] == 0, st
+        for r in range(rounds):
+            for j in range(W):
+                oi, ok, oc = f.search_batch(Qh[r][j], k, om, 0)
+                assert (outs[r][j][2].cpu().numpy().view(np.uint32) == oc).all(), (sharded, r, j)
+                assert (outs[r][j][0].cpu().numpy().view(np.uint64) == oi + np.uint64(7)).all(), (sharded, r, j)
+                assert (outs[r][j][1].cpu().numpy().view(np.uint64) == ok).all(), (sharded, r, j)
+        for c in ctxs:
+            c.close()
+    g.close()
+    ix.close()
