@@ -588,15 +588,17 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         kname = "sweep128_kernel<%d, ...>" % kind  # the half-wave kernel of the 512-byte rows
     leaf_half = half and st.get("approx_scan", 0) == 3  # d = 128, leaf by leaf from the fp16 copy of the rows (sweep128h_kernel)
     fused = leaf_half and st.get("approx_fused", 0) == 1
+    byte_rows = leaf_half and st.get("approx_byte_rows", 0) == 1  # every stored element an integer 0..255 (cfg5's SIFT-style rows): the EXACT 128-byte copy
     if leaf_half:
         # round 6: sweep128h_lean_kernel (+ sweep128h_boundary_kernel for the chunks that cross a leaf group).  FUSED (long leaves, top_k <= 64): the
         # intervals, the bounds and the queries' candidate lists are made inside the sweep -- no 8-byte result per scored row is written (or read
         # back by a select pass), so the algorithmic bytes per scored row are the row (2 d, once per distinct leaf group) and its 4-byte leaf id
         per_row = 4.0 if fused else 12.0
         kinda = 0 if wl["metric"] != "cosine" else 2  # (approx_interval's kind: 0 the L2 family, 2 the reference's literal cosine key)
-        kname = ("sweep128h_lean_kernel<16, %d>" % kinda) if fused else "sweep128h_lean_kernel<4, -1>"
-        bytes_alg = 2.0 * d * rows_per_launch * uniq_frac + per_row * rows_per_launch + 2.0 * d * B / launches_per_batch
-        bytes_nosharing = (2.0 * d + per_row) * rows_per_launch
+        kname = ("sweep128%s_lean_kernel<16, %d>" % ("b" if byte_rows else "h", kinda)) if fused else "sweep128%s_lean_kernel<4, -1>" % ("b" if byte_rows else "h")
+        row_b = 1.0 * d if byte_rows else 2.0 * d  # what the copy holds per stored row = what a launch must move per distinct row (traffic: PMC)
+        bytes_alg = row_b * rows_per_launch * uniq_frac + per_row * rows_per_launch + 2.0 * d * B / launches_per_batch
+        bytes_nosharing = (row_b + per_row) * rows_per_launch
     elif half:  # <D, groups per wave, 0 = L2 family / 1 = cosine distance / 2 = the reference's literal cosine key>
         kname = "scan_approx_kernel<%d, %d, %d>" % (d, 2 if d >= 512 else 4, 0 if wl["metric"] != "cosine" else 2)
         if st.get("approx_scan", 0) == 2:
@@ -631,9 +633,11 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # Leaf-major sweep: SURVEY s8(d)'s bytes ARE what the kernel moves through HBM (PMC traffic 0.99-1.01x): HBM roofline.
         roof = {"bound": "hbm", "achieved": s8d_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s8d_GBps / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": bytes_alg,
-                "sweep_mode": ("leaf by leaf at HALF WIDTH, FUSED: fp16 rows (one table scale) x fp16 queries on v_mfma_f32_16x16x32_f16; the intervals, "
+                "sweep_mode": ("leaf by leaf at HALF WIDTH, FUSED: %s x fp16 queries on v_mfma_f32_16x16x32_f16; the intervals, "
                                "a running top-k bound per visit and wave, and the queries' candidate lists are made inside the sweep -- no per-pair "
-                               "result is written, no select pass reads one back (zh_approx.hip, round 6)") if fused else
+                               "result is written, no select pass reads one back (zh_approx.hip, round 6)"
+                               % ("an EXACT 128-byte copy of the rows (every element an integer 0..255, checked when the copy is made; bytes -> halves in "
+                                  "registers)" if byte_rows else "fp16 rows (one table scale)")) if fused else
                               ("leaf by leaf at half width: raw pairs to the key scratch, select_tau / select_emit behind" if leaf_half else
                                "leaf by leaf, f32 rows, canonical keys"),
                 "achieved_no_sharing_GBps": bytes_nosharing / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0,
@@ -954,6 +958,7 @@ LINE_LIMIT = 6000  # bytes; the driver keeps an 8-KB tail of stdout and parses i
 PREFILTER_DTYPE = {
     "scan_mfma": "f16 (stored rows AND queries, v_mfma_f32_16x16x32_f16, f32 accumulate) -> an interval per pair; every returned key is the f32 canonical one",
     "sweep128h": "f16 (stored rows AND queries, v_mfma_f32_16x16x32_f16, f32 accumulate) -> an interval per pair; every returned key is the f32 canonical one",
+    "sweep128b": "u8 stored rows (an exact copy: every element an integer 0..255) widened to f16 in registers x f16 queries (v_mfma_f32_16x16x32_f16, f32 accumulate) -> an interval per pair; every returned key is the f32 canonical one",
     "scan_approx": "f16 queries x f32 stored rows (v_fma_mix_f32) -> an interval per pair; every returned key is the f32 canonical one",
 }
 

@@ -181,6 +181,8 @@ typedef struct zh_stats_t {
                                      * 0 until a batch has used one, and with modes 1 / 2 / 5 */
     uint64_t approx_fused;           /* 1: approx_scan 3 and the most recent batch's sweep was FUSED -- intervals, bounds and the queries' candidate
                                      * lists inside the sweep kernel (no raw pairs written, no select pass; round 6) */
+    uint64_t approx_byte_rows;       /* 1: approx_scan 3 and the sweep read an EXACT copy of 128 BYTES per stored row: every element of the table is an
+                                     * integer in 0 .. 255 (SIFT descriptors), checked when the copy is made; any other row and the copy is of halves */
 } zh_stats_t;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -36,7 +36,19 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ X, cons
     if (r0 >= n_ids) return;
     const uint32_t my_id = ids[r0 + lane < n_ids ? r0 + lane : n_ids - 1];
     float acc = 0.f;
-    if (ROW16 == 16) {  // four 256-byte rows per wave instruction (the fp16 copy of a d = 128 row): lane's quarter q = lane >> 4
+    if (ROW16 == 8) {  // EIGHT 128-byte rows per wave instruction (a uint8 copy of a d = 128 row): lane's eighth q = lane >> 3
+        const uint32_t ql = lane & 7, q = lane >> 3;
+        for (uint32_t j0 = 0; j0 < 8; j0 += RG) {
+            float4 v[RG];
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const uint32_t id = (uint32_t)__shfl((int)my_id, (int)(8 * (j0 + r) + q));
+                v[r] = ldnt(X + (size_t)id * 8 + ql);
+            }
+#pragma unroll
+            for (int r = 0; r < RG; r++) acc += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+        }
+    } else if (ROW16 == 16) {  // four 256-byte rows per wave instruction (the fp16 copy of a d = 128 row): lane's quarter q = lane >> 4
         const uint32_t ql = lane & 15, q = lane >> 4;
         for (uint32_t j0 = 0; j0 < 16; j0 += RG) {
             float4 v[RG];
@@ -97,7 +109,7 @@ static void run(const float4 *dX, size_t table_rows, double table_gb, const char
     float ms;
     hipEventElapsedTime(&ms, a, b);
     ms /= reps;
-    const int in_flight = ROW16 == 16 ? 4 * RG : (ROW16 == 32 ? 2 * RG : RG);
+    const int in_flight = ROW16 == 8 ? 8 * RG : (ROW16 == 16 ? 4 * RG : (ROW16 == 32 ? 2 * RG : RG));
     printf("%d,%.4f,%s,%d,4,%llu,%.3f,%.3f\n", ROW16 * 16, table_gb, order, in_flight, (unsigned long long)n, ms, (double)n * ROW16 * 16 / (ms * 1e-3) / 1e12);
     fflush(stdout);
     hipEventDestroy(a); hipEventDestroy(b);
@@ -117,8 +129,10 @@ int main(int argc, char **argv) {
     printf("row_bytes,table_GB,order,rows_in_flight_per_wave,waves_per_block,rows,ms,TB_per_s\n");
     std::mt19937_64 rng(7);
     const bool only256 = argc > 3 && argv[3][0] == 'h';  // ./gather512 32 n h: 256-byte rows only (a 125M x 128 fp16 table is 32 GB)
-    for (int row16 : {16, 32, 64, 192}) {
-        if (only256 != (row16 == 16)) continue;
+    const bool only128 = argc > 3 && argv[3][0] == 'b';  // ./gather512 16 n b: 128-byte rows only (a 125M x 128 uint8 table is 16 GB)
+    for (int row16 : {8, 16, 32, 64, 192}) {
+        if (only128 != (row16 == 8)) continue;
+        if (!only128 && only256 != (row16 == 16)) continue;
         const size_t rows = bytes / ((size_t)row16 * 16);
         const uint64_t n = row16 == 192 ? n_ids / 6 : (row16 == 64 ? n_ids / 2 : n_ids);
         std::vector<uint32_t> rnd(n), srt, run64(n), seq(n);
@@ -132,7 +146,12 @@ int main(int argc, char **argv) {
         for (uint64_t i = 0; i < n; i++) seq[i] = (uint32_t)(i % rows);
         const std::pair<const char *, const std::vector<uint32_t> *> orders[] = {{"random", &rnd}, {"sorted", &srt}, {"run64", &run64}, {"seq", &seq}};
         for (auto &o : orders) {
-            if (row16 == 16) {
+            if (row16 == 8) {
+                run<8, 1>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
+                run<8, 2>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
+                run<8, 4>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
+                run<8, 8>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
+            } else if (row16 == 16) {
                 run<16, 2>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
                 run<16, 4>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);
                 run<16, 8>(dX, rows, table_gb, o.first, *o.second, dIds, dOut);

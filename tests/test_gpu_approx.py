@@ -17,9 +17,12 @@ from oracle import zebra_oracle as zo  # noqa: E402  (the checker)
 def set_s128h_variant(monkeypatch, variant):
     """fused: sweep128h_lean_kernel<CH, KINDA> + sweep128h_boundary_kernel<KINDA> with intervals, bounds and the queries' lists inside the sweep
     (round 6; chosen by the library for long leaves, forced here: ZH_S128H_FUSED=1; top_k <= 64); lean: the same kernels writing raw pairs for
-    select_tau_kernel (ZH_S128H_FUSED=0); r5: sweep128h_kernel (ZH_S128H_KERNEL=r5); dma: sweep128h_dma_kernel (ZH_S128H_DMA=1)"""
-    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"}}[variant]
-    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA"):
+    select_tau_kernel (ZH_S128H_FUSED=0); r5: sweep128h_kernel (ZH_S128H_KERNEL=r5); dma: sweep128h_dma_kernel (ZH_S128H_DMA=1).
+    fused / lean read the 128-byte copy of a table of integers 0 .. 255 (sweep128b_lean_kernel, sweep128h_boundary_kernel<.., true>) when every
+    stored row qualifies; fused_halves / lean_halves keep them on the copy of halves whatever the rows are (ZH_S128H_BYTES=0)"""
+    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"},
+           "fused_halves": {"ZH_S128H_FUSED": "1", "ZH_S128H_BYTES": "0"}, "lean_halves": {"ZH_S128H_FUSED": "0", "ZH_S128H_BYTES": "0"}}[variant]
+    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA", "ZH_S128H_BYTES"):
         if var in env:
             monkeypatch.setenv(var, env[var])
         else:
@@ -226,7 +229,7 @@ LEAF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["fused", "lean", "r5", "dma"])
+@pytest.mark.parametrize("variant", ["fused", "lean", "r5", "dma", "fused_halves", "lean_halves"])
 @pytest.mark.parametrize("n,M,T,k,B,kind", LEAF_CASES)
 def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, B, kind, variant):
     """d = 128, leaf by leaf at half width on the matrix cores (sweep128h_kernel, zh_set_sweep_mode 6): an fp16 copy of the rows under one
@@ -245,7 +248,80 @@ def test_leaf_major_half_width_sweep_equals_oracle(za, monkeypatch, n, M, T, k, 
         st = check(ix, f, Q, k, m, om, omode)
         assert st["approx_scan"] == 3 and st["table_scan"] == 0, (om, omode, st)
         assert st["approx_fallbacks_accum"] == 0, st
-        assert st["approx_fused"] == (1 if variant == "fused" and k <= 64 else 0), st
+        assert st["approx_fused"] == (1 if variant.startswith("fused") and k <= 64 else 0), st
+        assert st["approx_byte_rows"] == (1 if kind == 1 and variant in ("fused", "lean") else 0), st
+    ix.close()
+
+
+@pytest.mark.parametrize("variant", ["fused", "lean"])
+def test_byte_rows_copy_follows_the_stored_rows(za, monkeypatch, variant):
+    """a table of integers 0 .. 255 is swept from an exact copy of 128 bytes per row (row_byte128_kernel): appended rows of bytes join it; ONE
+    appended element that is anything else (a fraction, a negative, 256, NaN) and the copy is re-made in halves; ZH_S128H_BYTES=0 and the round-5
+    kernels get the copy of halves from the same rows and a later batch the bytes again; replaced rows (clear + refill) are checked afresh"""
+    set_s128h_variant(monkeypatch, variant)
+    n, d, M, T, k, B = 9000, 128, 1200, 5, 10, 48
+    X = zo.synth_rows(2 * n, d, kind=1)
+    X[5] = 0.0; X[6] = 255.0; X[7, ::2] = 0.0; X[8] = X[9]
+    assert X.min() >= 0 and X.max() <= 255 and np.all(X == np.round(X))
+    Q = zo.synth_queries(B, d, n, kind=1)
+    Q[0] = X[6]; Q[1] = 0.0; Q[2] = X[8]; Q[3] = Q[3] + np.float32(0.37)
+    ix = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+    ix.append(X[:n])
+    f = zo.Forest.build(X[:n], M, T)
+    ix.set_forest(f.arrays())
+    ix.set_sweep_mode("leaf-half")
+    fused = 1 if variant == "fused" else 0
+    for mm, omm, omo in all_metrics(za):
+        st = check(ix, f, Q, k, mm, omm, omo, "bytes")
+        assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 1 and st["approx_fused"] == fused, st
+        assert omm == zo.COSINE or st["approx_fallbacks_accum"] == 0, st  # (the zero query's cosine intervals are all "nothing certain": its list may run over)
+    bytes_copy = st["row_copy_bytes"]
+    assert bytes_copy < n * 256, st
+    m, om = za.L2Distance(), zo.L2
+    monkeypatch.setenv("ZH_S128H_BYTES", "0")
+    st = check(ix, f, Q, k, m, om, 0, "halves on request")
+    assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 0 and st["row_copy_bytes"] >= n * 256, st
+    monkeypatch.delenv("ZH_S128H_BYTES")
+    monkeypatch.setenv("ZH_S128H_KERNEL", "r5")
+    monkeypatch.delenv("ZH_S128H_FUSED")
+    st = check(ix, f, Q, k, m, om, 0, "the round-5 kernel reads halves")
+    assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 0, st
+    set_s128h_variant(monkeypatch, variant)
+    st = check(ix, f, Q, k, m, om, 0, "bytes again")
+    assert st["approx_byte_rows"] == 1, st
+    ix.append(X[n:n + n // 2])          # more rows of bytes: added to the copy
+    f2 = zo.Forest.build(X[:n + n // 2], M, T)
+    ix.set_forest(f2.arrays())
+    st = check(ix, f2, Q, k, m, om, 0, "appended bytes")
+    assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 1, st
+    for bad in (np.float32(0.5), np.float32(-1.0), np.float32(256.0), np.float32(np.nan)):
+        Y = X[n + n // 2:].copy()
+        Y[17, 101] = bad
+        iy = za.LSHIndex(d, za.LSHIndexOptions(M, T))
+        iy.append(X[:n + n // 2])
+        iy.set_forest(f2.arrays())
+        iy.set_sweep_mode("leaf-half")
+        st = check(iy, f2, Q, k, m, om, 0, "bytes before the append")
+        assert st["approx_byte_rows"] == 1, st
+        iy.append(Y)
+        Z = np.concatenate([X[:n + n // 2], Y])
+        f3 = zo.Forest.build(Z, M, T)
+        iy.set_forest(f3.arrays())
+        st = check(iy, f3, Q, k, m, om, 0, "an appended element %r" % bad)
+        assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 0, (bad, st)
+        iy.close()
+    ix.clear()                          # replaced rows are checked afresh
+    W = X[:n] * np.float32(0.5)
+    ix.append(W)
+    fw = zo.Forest.build(W, M, T)
+    ix.set_forest(fw.arrays())
+    st = check(ix, fw, Q * np.float32(0.5), k, m, om, 0, "replaced by rows of halves")
+    assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 0, st
+    ix.clear()
+    ix.append(X[:n])
+    ix.set_forest(f.arrays())
+    st = check(ix, f, Q, k, m, om, 0, "replaced by rows of bytes")
+    assert st["approx_scan"] == 3 and st["approx_byte_rows"] == 1, st
     ix.close()
 
 

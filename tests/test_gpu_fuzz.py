@@ -240,6 +240,8 @@ def test_fuzz_fused_leaf_sweep(seed, monkeypatch):
     ties, duplicates, all four simsimd-path keys, windows of several queries per leaf.  ZH_FUZZ_FUSED_SEEDS=first:count soaks."""
     import zebra_amd as za
     monkeypatch.setenv("ZH_S128H_FUSED", "1")
+    if seed % 3 == 2:  # (kind 1 -- and the rounded tables below when they are non-negative -- are rows of BYTES: sweep128b_lean_kernel unless told otherwise)
+        monkeypatch.setenv("ZH_S128H_BYTES", "0")
     rng = np.random.default_rng(99000 + seed)
     d = 128
     n = int(rng.integers(500, 30000))

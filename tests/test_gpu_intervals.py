@@ -23,8 +23,9 @@ def set_s128h_variant(monkeypatch, variant):
     """fused: sweep128h_lean_kernel<CH, KINDA> + sweep128h_boundary_kernel<KINDA> with intervals, bounds and the queries' lists inside the sweep
     (round 6; chosen by the library for long leaves, forced here: ZH_S128H_FUSED=1; top_k <= 64); lean: the same kernels writing raw pairs for
     select_tau_kernel (ZH_S128H_FUSED=0); r5: sweep128h_kernel (ZH_S128H_KERNEL=r5); dma: sweep128h_dma_kernel (ZH_S128H_DMA=1)"""
-    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"}}[variant]
-    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA"):
+    env = {"fused": {"ZH_S128H_FUSED": "1"}, "lean": {"ZH_S128H_FUSED": "0"}, "r5": {"ZH_S128H_KERNEL": "r5"}, "dma": {"ZH_S128H_DMA": "1"},
+           "lean_halves": {"ZH_S128H_FUSED": "0", "ZH_S128H_BYTES": "0"}}[variant]  # (lean reads the copy of BYTES when every row is one of integers 0 .. 255)
+    for var in ("ZH_S128H_FUSED", "ZH_S128H_KERNEL", "ZH_S128H_DMA", "ZH_S128H_BYTES"):
         if var in env:
             monkeypatch.setenv(var, env[var])
         else:
@@ -263,7 +264,7 @@ def test_valu_scan_intervals_contain_the_key(za, torch, d):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", ["lean", "r5", "dma"])  # (the fused sweep writes no raw pairs: zh_debug_keep_raw keeps it off)
+@pytest.mark.parametrize("variant", ["lean", "lean_halves", "r5", "dma"])  # (the fused sweep writes no raw pairs: zh_debug_keep_raw keeps it off)
 @pytest.mark.parametrize("kind", [0, 1])
 def test_leaf_major_half_width_intervals_contain_the_key(za, torch, monkeypatch, kind, variant):
     """sweep128h_kernel (d = 128, zh_set_sweep_mode 6): a row-major fp16 copy under ONE table scale (rows it does not serve: NaNs -> the exact path);
@@ -289,6 +290,7 @@ def test_leaf_major_half_width_intervals_contain_the_key(za, torch, monkeypatch,
         run_batch(torch, ix, Q, k, m)
         info, pairs, qmeta = ix.debug_scan_pairs()
         assert info["approx_scan"] == 3, info
+        assert ix.stats()["approx_byte_rows"] == (1 if kind == 1 and variant == "lean" else 0)  # (kind 1: SIFT-style rows -> sweep128b_lean_kernel)
         r = check_containment(X, Q, info, pairs, qmeta, f"sweep128h_kernel kind {kind} {name}")
         w, a = check_rounding_model(X, Q, info, pairs, qmeta, d, f"sweep128h_kernel kind {kind} {name}", table_ex=int(table_ex))
         print(f"sweep128h_kernel kind {kind} {name}: {r['pairs']} pairs, {r['unsure']} uncertain, median half-width {r['median_rel_halfwidth']:.2e}; "

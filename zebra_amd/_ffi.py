@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("approx_list_entries", C.c_uint64), ("approx_columns", C.c_uint64), ("approx_column_pairs", C.c_uint64), ("approx_batches_accum", C.c_uint64), ("approx_fallbacks_accum", C.c_uint64),
                 ("approx_last_overflow", C.c_uint64), ("combined_batches_accum", C.c_uint64), ("combined_calls_accum", C.c_uint64),
                 ("host_window_calls_accum", C.c_uint64), ("scan_order_keys", C.c_uint64), ("scan_order_share_permille", C.c_uint64),
-                ("row_copy_bytes", C.c_uint64), ("approx_fused", C.c_uint64)]
+                ("row_copy_bytes", C.c_uint64), ("approx_fused", C.c_uint64), ("approx_byte_rows", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

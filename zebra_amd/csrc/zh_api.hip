@@ -331,6 +331,7 @@ struct zh_search_ctx {
     // decide.  Its control words come back pinned for the statistics only: an overflow is redone on the device, in stream order.
     bool approx_f32rows = false;  // (approx_mfma without an fp16 copy of the table: scan_mfma_kernel<D, true>)
     bool approx_fused = false;  // (approx_leaf, round 6: intervals, bounds and lists inside the sweep kernel)
+    bool approx_bytes = false;  // (approx_leaf, round 6: the sweep reads the copy of BYTES -- a table of integers 0 .. 255)
     bool approx = false, approx_mfma = false, approx_leaf = false;  // (approx_leaf: the d = 128 leaf-major sweep at half width, sweep128h_kernel)
     uint32_t *h_ap = nullptr;
     bool score_hash = false;  // its signs came from row scores (zh_score.hip) instead of one dot product per plane
@@ -419,6 +420,9 @@ struct zh_index {
     int h128_ex = 0;
     float h128_rho = 0.f;
     std::atomic<bool> h128_failed{false};
+    // ... or, for a table of integers 0 .. 255 (SIFT descriptors), an EXACT copy of 128 bytes per row in the same buffer (row_byte128_kernel):
+    // h128_bytes = the current copy is that one; h128_not_bytes = some stored row is known not to qualify (until the rows are replaced)
+    bool h128_bytes = false, h128_not_bytes = false;
     std::atomic<uint64_t> scale_rows{0}, scale_gen{0};
     float row_rho = 0.f;
     // Round 5 (VERDICT r4 #4b): the matrix-core scan's OWN view of the rows -- the fp16 tiles, their {|x|^2, 1 / scale} and the row -> leaf entries --
@@ -694,6 +698,7 @@ extern "C" int zh_index_clear(zh_index *ix) {
     ix->scale_rows = 0; ix->scale_gen = 0; ix->row_rho = 0.f; ix->row_half.release(); ix->row_meta.release(); ix->row_half_failed = false;
     ix->perm_rows = 0; ix->perm_gen++; ix->scan_perm.release(); ix->row_leaf_p.release(); ix->row_order_off = false;  // (a new table gets a new chance at the scan's row order)
     ix->h128_rows = 0; ix->h128_gen = 0; ix->h128_rho = 0.f; ix->row_half128.release(); ix->h128_failed = false;
+    ix->h128_bytes = false; ix->h128_not_bytes = false;
     ix->h_live.clear(); ix->h_live.shrink_to_fit();
     ix->h_live_rows = ix->h_live_dead = ix->h_live_gen = ~0ull;
     return ZH_OK;
@@ -1849,25 +1854,44 @@ static int ensure_row_half(zh_index *ix, bool *ok) {
 }
 
 // The row-major fp16 copy of a d = 128 table under one scale (under blk_mu).  Appended rows that fit the scale are added; a larger element
-// than the scale allows re-makes the copy.
-static int ensure_row_half128(zh_index *ix, bool *ok) {
+// than the scale allows re-makes the copy.  want_bytes: the caller's kernels can read the 128-byte copy of a table of integers 0 .. 255 -- made
+// instead whenever every stored row qualifies (an appended row that does not re-makes the copy in halves); the two kinds share the buffer, and a
+// caller that wants the other kind than the one present (tests switching kernels) gets the copy re-made.
+static int ensure_row_half128(zh_index *ix, bool *ok, bool want_bytes) {
     *ok = false;
+    const bool bytes = want_bytes && !ix->h128_not_bytes;
     const bool current = ix->h128_gen == ix->rows_gen && ix->h128_rows == ix->n_rows;
-    if (current) { *ok = !ix->h128_failed; return ZH_OK; }
+    if (current && (ix->h128_failed || ix->h128_bytes == bytes)) { *ok = !ix->h128_failed; return ZH_OK; }
     ix->h128_failed = false;
     size_t mem_free = 0, mem_total = 0;
-    const uint64_t want = std::max<uint64_t>(ix->n_rows, 1) * 256;
+    const uint64_t want = std::max<uint64_t>(ix->n_rows, 1) * (bytes ? 128 : 256);
     const bool room = want <= ix->row_half128.cap || (zh_mem_info(&mem_free, &mem_total) == hipSuccess && mem_free >= want + want / 2 + mem_total / 16);
-    if (!room || ix->row_half128.ensure(want, true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(8) != ZH_OK) {
+    if (!room || ix->row_half128.ensure(want, true, ix->stream) != ZH_OK || ix->row_rho_dev.ensure(12) != ZH_OK) {
         ix->row_half128.release();
-        ix->h128_failed = true;
+        ix->h128_failed = true; ix->h128_bytes = false;
         ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
         return ZH_OK;
     }
-    uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows) ? ix->h128_rows.load() : 0;
+    uint64_t from = (ix->h128_gen == ix->rows_gen && ix->h128_rows <= ix->n_rows && ix->h128_bytes == bytes) ? ix->h128_rows.load() : 0;
     {
         const int rcq = quiesce_before_rewrite();
         if (rcq) return rcq;
+    }
+    if (bytes) {
+        uint32_t *dflag = ix->row_rho_dev.as<uint32_t>() + 2, flag = 0;
+        HIPCHK(hipMemsetAsync(dflag, 0, 4, ix->stream));
+        HIPCHK(zh_launch_row_byte128(ix->X.as<float>(), from, ix->n_rows - from, ix->row_half128.p, dflag, ix->stream));
+        HIPCHK(hipMemcpyAsync(&flag, dflag, 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        if (!flag) {
+            ix->h128_bytes = true; ix->h128_rho = 0.f; ix->h128_ex = 14;
+            ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
+            *ok = true;
+            return ZH_OK;
+        }
+        ix->h128_not_bytes = true;  // some row is not a row of bytes: the copy of halves, from the first row, now and from now on
+        ix->h128_bytes = false; ix->h128_gen = 0;
+        return ensure_row_half128(ix, ok, false);
     }
     uint32_t *dmax = ix->row_rho_dev.as<uint32_t>() + 1;
     for (int pass = 0; pass < 2; pass++) {
@@ -1891,7 +1915,8 @@ static int ensure_row_half128(zh_index *ix, bool *ok) {
     float rho = 0.f;
     HIPCHK(hipMemcpyAsync(&rho, ix->row_rho_dev.p, 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->h128_rho = rho;
+    ix->h128_rho = from == 0 ? rho : std::max(rho, ix->h128_rho);
+    ix->h128_bytes = false;
     ix->h128_rows = ix->n_rows; ix->h128_gen = ix->rows_gen;
     *ok = true;
     return ZH_OK;
@@ -2144,7 +2169,7 @@ static int ctx_begin(zh_search_ctx *c, const float *const *dQs, size_t nwin, siz
     c->dQ = dQ; c->B = B; c->k = k; c->metric = metric; c->mode = mode; c->s = s;
     c->nwin = nwin; c->bwin = bwin;
     c->trivial = (B == 0 || k == 0 || ix->n_rows == 0 || T == 0);  // core.rs:295-297: empty index -> no neighbours
-    c->approx = false; c->approx_leaf = false; c->approx_mfma = false; c->approx_fused = false;
+    c->approx = false; c->approx_leaf = false; c->approx_mfma = false; c->approx_fused = false; c->approx_bytes = false;
     c->state = 1;
     if (c->trivial) return ZH_OK;
     const uint64_t pairs = (uint64_t)B * T;
@@ -2387,12 +2412,17 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (!no_wave_table && !c->scan)
         HIPCHK(zh_launch_wave_groups(c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(), tot.groups, c->wWaveGroup.as<uint32_t>(), s));
     c->approx = c->scan && use_approx(ix, tot, B, k, c->metric);
-    c->approx_leaf = false;
+    c->approx_leaf = false; c->approx_bytes = false;
     if (!c->scan && !no_wave_table && use_approx_leaf(ix, tot, B, k, c->metric)) {
         bool ok = false;
+        // rows of bytes (integers 0 .. 255: SIFT descriptors) are copied as bytes -- half the sweep's bytes, no rounding -- for the lean kernels;
+        // ZH_S128H_BYTES=0 (read per batch: tests) keeps the copy of halves
+        const char *be = getenv("ZH_S128H_BYTES"), *ke = getenv("ZH_S128H_KERNEL"), *de = getenv("ZH_S128H_DMA");
+        const bool want_bytes = !(be && be[0] == '0') && !(ke && ke[0] == 'r') && !(de && de[0] == '1');
         std::lock_guard<std::mutex> lk(ix->blk_mu);
-        if ((rc = ensure_row_half128(ix, &ok))) return rc;
+        if ((rc = ensure_row_half128(ix, &ok, want_bytes))) return rc;
         c->approx = c->approx_leaf = ok;
+        c->approx_bytes = ok && ix->h128_bytes;
     }
     ZhApprox ap{};
     // the scan on the matrix cores, from an fp16 copy of the stored rows (+50 % of the row table, made on first use); no room for it, or mode 5:
@@ -2438,7 +2468,10 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
         ap.n_queries = (uint32_t)B; ap.iv_cap = tot.rows;
         ap.mfma = mfma ? 1u : 0u; ap.row_half = mfma ? ix->row_half.p : nullptr; ap.row_meta = mfma ? ix->row_meta.as<float2>() : nullptr;  // (row_half null with mfma: the scan converts the f32 rows itself)
         ap.row_rho = mfma ? ix->row_rho : 0.f;
-        if (c->approx_leaf) { ap.mfma = 2u; ap.row_rho = ap.rho_norm = ix->h128_rho; }
+        if (c->approx_leaf) { ap.mfma = 2u; ap.row_rho = ap.rho_norm = c->approx_bytes ? 0.f : ix->h128_rho; }
+        // (a row of bytes: |x|^2 <= 128 * 255^2 exactly, approx_interval's nx = sqrtf of it * (1 + 1e-5) < 2885.1; ZH_S128H_PRETEST=0, read per batch: tests)
+        const char *pte = getenv("ZH_S128H_PRETEST");
+        ap.nx_max = c->approx_leaf && c->approx_bytes && !(pte && pte[0] == '0') ? 2885.1f : 0.f;
         HIPCHK(hipMemsetAsync(c->wApCount.p, 0, B * 4, s));
         HIPCHK(hipMemsetAsync(ap.qtau, 0xFF, B * 4, s));
         HIPCHK(hipMemsetAsync(c->wApCtl.p, 0, ZH_APX_CTL_WORDS * 4, s));
@@ -2464,7 +2497,7 @@ static int ctx_finish(zh_search_ctx *c, uint64_t *const *outIds, uint64_t *const
     if (c->approx_leaf)
         HIPCHK(zh_launch_sweep128h(ix->row_half128.p, c->wQh.p, ldexpf(1.f, ix->h128_ex - 14), c->wGroups.as<ZhGroup>(), c->wGroupRowOff.as<uint64_t>(),
                                    tot.groups, c->wWaveGroup.as<uint32_t>(), f.leaf_ids, tot.group_rows, c->wKeys.as<uint64_t>(), hs,
-                                   c->approx_fused ? &ap : nullptr, kinda, (uint32_t)k, zh_approx_bound(c->metric, d, 2)));
+                                   c->approx_fused ? &ap : nullptr, kinda, (uint32_t)k, zh_approx_bound(c->metric, d, 2), c->approx_bytes));
     else if (c->approx)
         HIPCHK(zh_launch_scan_approx(ix->X.as<float>(), d, ix->n_rows, ap, mfma ? scan_row_leaf : ix->row_leaf.as<uint2>(), T, c->wVisitBits.as<uint32_t>(),
                                      c->wNodeVisit.as<uint4>(), c->wGroups.as<ZhGroup>(), f.group, c->metric, c->mode, hs));
@@ -2579,6 +2612,7 @@ int ctx_wait(zh_search_ctx *c) {
     const bool apx = c->approx && !pf;
     st.approx_scan = apx ? (c->approx_leaf ? 3 : (c->approx_mfma ? 2 : 1)) : 0;
     st.approx_fused = apx && c->approx_leaf && c->approx_fused ? 1 : 0;
+    st.approx_byte_rows = apx && c->approx_leaf && c->approx_bytes ? 1 : 0;
     st.approx_exact_visits = apx ? c->h_ap[0] : 0;
     st.approx_survivors = apx ? c->h_ap[3] : 0;
     st.approx_list_entries = apx ? c->h_ap[4] : 0;
@@ -2605,10 +2639,10 @@ int ctx_wait(zh_search_ctx *c) {
         st.timed_batches++;
         st.sweep_rows_accum += tot.rows;
         st.swept_rows_accum += swept;
-        // (the half-width d = 128 sweep's lean kernels take twice the rows per launch: 256-byte rows -- launch_sweep128h_lean)
+        // (the half-width d = 128 sweep's lean kernels take two or four times the rows per launch: 256- or 128-byte rows -- launch_sweep128h_lean)
         const char *ke = getenv("ZH_S128H_KERNEL"), *de = getenv("ZH_S128H_DMA");
         const bool lean128 = apx && c->approx_leaf && !(ke && ke[0] == 'r') && !(de && de[0] == '1');
-        const uint64_t rpl = zh_sweep_rows_per_launch(ix->opt.dim) * (lean128 ? 2 : 1);
+        const uint64_t rpl = apx && c->approx_leaf ? zh_sweep128h_rows_per_launch(lean128, c->approx_bytes) : zh_sweep_rows_per_launch(ix->opt.dim);
         st.sweep_launches_accum += (swept + rpl - 1) / rpl;
         st.scan_batches_accum += c->scan && !pf ? 1 : 0;
         st.approx_batches_accum += apx ? 1 : 0;

@@ -155,6 +155,18 @@ __device__ __forceinline__ float group_sum(float s) {
     return s;
 }
 
+// The L2 family's interval is V -+ E: V from the pair's sums, E from the norms.  Both as functions of their own, because the fused sweep's pre-test
+// (fused_pretest) evaluates V the same way and E at an upper bound of nx: every operation of l2_E is non-decreasing in nx >= 0 (all factors are
+// non-negative) and so is its rounded result -- E(nx_max) >= E(nx) in f32, whatever the roundings.
+__device__ __forceinline__ float l2_V(float s, float a2, const float4 qm) {
+    const float sh = s * qm.x, sum = a2 + qm.y;
+    return sum - 2.0f * sh;
+}
+__device__ __forceinline__ float l2_E(float nx, const float4 qm, float Kc, float rho, float rho_n) {
+    const float nn = nx + qm.z;
+    // |s / sigma - x.q| <= |x| dq + |x - x'| (|q| + dq), |x - x'| <= rho |x| (rho = 0: the scan multiplied the f32 row)
+    return Kc * nn * nn + 2.02f * nx * (qm.w + rho * (qm.z + qm.w)) + 2.2f * rho_n * nx * nx;
+}
 // the interval of one (row, query) pair from its sums: sortable lo | sortable hi << 32; (0, all ones) = nothing certain
 template <int KINDA>
 __device__ __forceinline__ uint64_t approx_interval(float s, float a2, const float4 qm, float Kc, float rho, float rho_n) {
@@ -163,9 +175,8 @@ __device__ __forceinline__ uint64_t approx_interval(float s, float a2, const flo
     if (KINDA == 0) {
         // rho_n != 0: a2 is the ROUNDED row's |x'|^2 (sweep128h_kernel): |x| <= |x'| (1 + 2 rho_n), ||x'|^2 - |x|^2| <= 2.2 rho_n |x'|^2
         const float nx = sqrtf(a2) * (1.0f + 1e-5f) * (1.0f + 2.0f * rho_n), nn = nx + qm.z, sum = a2 + qm.y;
-        const float V = sum - 2.0f * sh;
-        // |s / sigma - x.q| <= |x| dq + |x - x'| (|q| + dq), |x - x'| <= rho |x| (rho = 0: the scan multiplied the f32 row)
-        const float E = Kc * nn * nn + 2.02f * nx * (qm.w + rho * (qm.z + qm.w)) + 2.2f * rho_n * nx * nx;
+        const float V = l2_V(s, a2, qm);
+        const float E = l2_E(nx, qm, Kc, rho, rho_n);
         if ((V - V == 0.f) && (E - E == 0.f) && nn > 1e-12f && sum < 1e37f) { lo_s = f32_sortable(V - E); hi_s = f32_sortable(V + E); }
     } else {
         const float nx = sqrtf(a2), nq = sqrtf(qm.y);
@@ -1040,6 +1051,46 @@ hipError_t zh_launch_row_half128(const float *dX, uint64_t row0, uint64_t n_rows
     return hipGetLastError();
 }
 
+// ---- BYTE rows (round 6).  A table whose every element is an integer in 0 .. 255 -- SIFT descriptors, BASELINE's "SIFT-style" cfg5 -- has an EXACT
+// copy of 128 bytes per row: half the bytes of the fp16 copy for a sweep that is bound by the bytes it gathers, and no rounding of the row at all
+// (rho = 0 in approx_interval; |x|^2 <= 128 * 255^2 < 2^24 is exact in the Gram diagonal's f32).  A thread per four elements; any element that is
+// not such an integer (a fraction, a negative, > 255, NaN) raises *notBytes and the caller falls back to the fp16 copy.
+__global__ __launch_bounds__(256) void row_byte128_kernel(const float4 *__restrict__ X4, uint64_t n4, uint32_t *__restrict__ Xb,
+                                                          uint32_t *__restrict__ notBytes) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+        const float4 v = X4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t b = (uint32_t)fminf(fmaxf(e[j], 0.f), 255.f);  // (NaN -> 0, then caught by the comparison)
+            bad |= !((float)b == e[j]);
+            w |= b << (8 * j);
+        }
+        Xb[i] = w;
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(notBytes, 1u);
+}
+hipError_t zh_launch_row_byte128(const float *dX, uint64_t row0, uint64_t n_rows, void *dXb, uint32_t *dNotBytes, hipStream_t s) {
+    if (!n_rows) return hipSuccess;
+    const uint64_t n4 = n_rows * 32;
+    hipLaunchKernelGGL(row_byte128_kernel, dim3((uint32_t)std::min<uint64_t>((n4 + 255) / 256, 256 * 32)), dim3(256), 0, s,
+                       reinterpret_cast<const float4 *>(dX + (size_t)row0 * 128), n4, reinterpret_cast<uint32_t *>(dXb) + (size_t)row0 * 32, dNotBytes);
+    return hipGetLastError();
+}
+// eight stored bytes (two words) -> the eight halves of an MFMA fragment, exactly: 0x6400 | b is the half 1024 + b (one ulp is 1 from 1024 to
+// 2048), and (1024 + b) - 1024 is exact: a v_perm_b32 and a v_pk_add_f16 per two elements
+__device__ __forceinline__ f16x8 bytes8_to_f16(uint32_t w0, uint32_t w1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 off = {(_Float16)-1024.f, (_Float16)-1024.f};
+    const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04010400u)) + off;
+    const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04030402u)) + off;
+    const h2 c = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04010400u)) + off;
+    const h2 d = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04030402u)) + off;
+    return f16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot8_self(const f16x8 v, float c) {
     c = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), c, false);
@@ -1421,7 +1472,9 @@ __device__ __forceinline__ void topk_merge(uint32_t &topv, uint32_t v, uint32_t 
 
 template <int KINDA>
 __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint32_t lane, uint32_t bq, uint32_t take, uint32_t glen, uint32_t k_top,
-                                           float Kc, const ZhApprox &ap, uint64_t *__restrict__ iv_slot, uint32_t &topv, uint32_t *scratch) {
+                                           float Kc, const ZhApprox &ap, uint64_t *__restrict__ iv_slot, uint32_t &topv, uint32_t *scratch, uint32_t tau) {
+    // tau: the query's bound as the caller read it BEFORE the chunk's tiles (fused_tau) -- any value qtau ever held is a certified bound, and a read
+    // here would sit behind the row loads in flight (vmcnt counts in order): every slot a memory round trip with nothing else to do
     if (take == 0) return;  // (wave-uniform)
     const float4 qm = ap.qmeta[bq];
     const uint64_t w = approx_interval<KINDA>(s, a2, qm, Kc, ap.row_rho, ap.rho_norm);
@@ -1430,7 +1483,6 @@ __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint3
         __builtin_nontemporal_store(w, iv_slot);
         return;
     }
-    uint32_t tau = __hip_atomic_load(&ap.qtau[bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau);
     if (take < glen) {  // top_k rows of a longer leaf
         const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)topv, (int)(take - 1));
@@ -1455,6 +1507,44 @@ __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint3
     }
 }
 
+// the bounds of a group's queries, requested before the chunk's tiles are waited for (slots past gsize: none)
+__device__ __forceinline__ void fused_tau(const ZhGroup *gr, uint32_t gsize, const ZhApprox &ap, uint32_t (&tau)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        tau[j] = (uint32_t)j < gsize ? __hip_atomic_load(&ap.qtau[gr->b[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+}
+// The fused sweep's PRE-TEST (L2 family, a table whose rows' norm estimates are bounded: ap.nx_max > 0 -- the byte copy).  Once a query has a bound,
+// nearly every (row, query) pair of a chunk is far above it, and telling so does not take the pair's interval: with Emax = l2_E(nx_max) >= E,
+//     V - Emax > tau   =>   lo = V - E >= V - Emax > tau:   the row joins no list, and its hi > tau could only enter the wave's running top-k as a
+// value that never brings the k-th below tau -- i.e. never changes what the sweep certifies.  A chunk whose 64 rows all pass for a slot skips
+// fused_slot for it (five VALU operations per pair instead of ~45); anything else -- a row near or under the bound, no bound yet, a query or sum
+// that approx_interval would call uncertain -- takes fused_slot as before, for the whole chunk.  pre[j] = {1 / sigma, |q|^2, Emax} of slot j, Emax < 0: no pre-test.
+__device__ __forceinline__ void fused_pretest_setup(const ZhGroup *gr, uint32_t gsize, const ZhApprox &ap, float Kc, float (&pre)[4][3]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        pre[j][0] = 0.f; pre[j][1] = 0.f; pre[j][2] = -1.f;
+        if ((uint32_t)j < gsize && ap.nx_max > 0.f) {
+            const float4 qm = ap.qmeta[gr->b[j]];
+            const float E = l2_E(ap.nx_max, qm, Kc, ap.row_rho, ap.rho_norm);
+            // what approx_interval asks of a pair before it is certain of anything: nn > 1e-12 (here from the query alone), sum < 1e37 (the rows' share is < 1e36)
+            const bool ok = qm.z > 1e-12f && qm.y < 1e36f && E < 3.0e38f && ap.nx_max < 1e18f;
+            // (wave-uniform, and said so: twelve scalar registers, not twelve vector ones)
+            pre[j][0] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(qm.x)));
+            pre[j][1] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(qm.y)));
+            pre[j][2] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(ok ? E : -1.f)));
+        }
+    }
+}
+__device__ __forceinline__ float f32_unsortable(uint32_t s) {  // (0xFFFFFFFF, "no bound yet", is a NaN: every comparison below fails)
+    return __uint_as_float(s ^ ((s >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// true: no row of the chunk can matter to the slot's query (wave-uniform)
+__device__ __forceinline__ bool fused_pretest(float s, float a2, const float (&pre)[3], uint32_t tau) {
+    if (!(pre[2] >= 0.f)) return false;
+    const float V = l2_V(s, a2, make_float4(pre[0], pre[1], 0.f, 0.f));
+    const bool drop = (V - pre[2] > f32_unsortable(tau)) && V < 3.0e38f;
+    return __ballot(!drop) == 0;
+}
 template <int N>
 __device__ __forceinline__ uint32_t row_newbcast(uint32_t v) {  // every lane: the value of lane N of its own 16-lane row (DPP, no LDS)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);  // (bound_ctrl: no `old` operand to initialise)
@@ -1517,6 +1607,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
     // fused form: per slot, the top_k smallest hi of the visit's rows this wave has seen (lane i the i-th; reset when the group changes), and where
     // flat row `lane` of a chunk finds its id (lane (h, c16) holds row 4 c16 + h)
     uint32_t topv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    float pre[4][3] = {{0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}};  // (fused_pretest_setup, per group)
     const uint32_t nat_src = (((lane & 3u) << 4) | (lane >> 2)) << 2;
     bool carried = false;          // the previous chunk left THIS chunk's first tile travelling in R and its ids in `ids`
     uint32_t ids = 0;              // lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
@@ -1541,6 +1632,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
         if (g != a_g) {  // (wave-uniform) A's row m = query slot m & 3 of group g, zero past gsize
             a_g = g;
             topv[0] = topv[1] = topv[2] = topv[3] = 0xFFFFFFFFu;
+            if constexpr (FUSE == 0) fused_pretest_setup(gr, gsize, ap, Kc, pre);
             const bool on = (c16 & 3u) < gsize;
             const uint32_t b = on ? gr->b[c16 & 3u] : 0u;
 #pragma unroll
@@ -1560,6 +1652,8 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
         // h keep tile h's, so that after the chunk's four tiles lane l holds flat row l of the chunk -- ONE 512-byte run per slot and chunk
         // instead of a 128-byte run per slot and tile (small scattered writes among the row reads cost HBM more than their bytes:
         // profiles/r06_sweep128h_experiments.txt)
+        uint32_t tau_pre[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if constexpr (FUSE >= 0) fused_tau(gr, gsize, ap, tau_pre);
         float res[4] = {0.f, 0.f, 0.f, 0.f}, res_a2 = 0.f;
         auto tile = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -1621,9 +1715,190 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
             const uint32_t take4 = gr->take4;
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((uint32_t)j < gsize)
-                    fused_slot<FUSE>(res[j] * inv, a2s, idn, lane, gr->b[j], (take4 >> (8 * j)) & 255u, glen, k_top, Kc, ap,
-                                     iv + gr->key_off[j] + within0 + lane, topv[j], reinterpret_cast<uint32_t *>(tl));  // (the tile buffer is idle here: the next tile waits in R)
+                if ((uint32_t)j < gsize) {
+                    const uint32_t take = (take4 >> (8 * j)) & 255u;
+                    if constexpr (FUSE == 0) {
+                        if (!(take < glen && take < k_top)) {  // (the exact path's visits keep every interval)
+                            const uint32_t t_w = take < glen ? (uint32_t)__builtin_amdgcn_readlane((int)topv[j], (int)(take - 1)) : 0xFFFFFFFFu;
+                            const uint32_t t_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_pre[j]);
+                            if (fused_pretest(res[j] * inv, a2s, pre[j], t_w < t_q ? t_w : t_q)) continue;
+                        }
+                    }
+                    fused_slot<FUSE>(res[j] * inv, a2s, idn, lane, gr->b[j], take, glen, k_top, Kc, ap,
+                                     iv + gr->key_off[j] + within0 + lane, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j]);  // (the tile buffer is idle here: the next tile waits in R)
+                }
+        }
+        carried = next_fast;
+        if (next_fast) { ids = nxt_ids; within0 += 64; }
+    }
+}
+
+// ---- the lean kernel over BYTE rows (row_byte128_kernel's copy): the same chunk, the same epilogues, half the bytes.  A stored row is eight 16-byte
+// pieces, so ONE wave instruction loads eight rows and the unit staged through LDS is a DOUBLE tile -- 32 rows, the same four instructions and 4 KB
+// in flight per wave as a 16-row tile of halves -- scored by two sets of MFMAs:
+//   * instruction i of double tile T: the 16-lane row h loads the rows whose ids its lanes 8 T + 2 i and 8 T + 2 i + 1 hold (flat rows
+//     32 T + 8 i + 4 sub + h: two row_newbcasts and a select), lanes 0-7 the pieces of one, lanes 8-15 of the other; they land in the LDS image as
+//     image rows J = 8 i + 2 h + sub (neighbours: the sixteen lanes fill 256 consecutive bytes), piece p of image row J at J * 8 + (p ^ ((J >> 1) & 7));
+//   * set m scores image rows 16 m .. 16 m + 15: lane (c16, h) reads pieces 2 h and 2 h + 1 of image row 16 m + c16 -- elements 32 h .. 32 h + 31 --
+//     converts them (bytes8_to_f16: exact) and step st multiplies elements 32 h + 8 st ..: the K index of the matrix instruction is only a
+//     summation order, so A holds the queries' pieces 4 h + st where the kernel of halves holds 4 st + h;
+//   * the lanes of 16-lane row h keep set h's results (h = 2 T + m), i.e. lane l ends up with flat row pi(l) = 16 h + 8 (c16 >> 3) + 4 (c16 & 1)
+//     + ((c16 >> 1) & 3) of the chunk: a fixed permutation inside each 16 -- ids, key positions and raw runs are addressed through it.
+// inv = 1: the rows are their own values (no table scale); |x|^2 is exact.
+template <int T>
+__device__ __forceinline__ void issue_byte_tile(const u32x4v *__restrict__ Xb, uint32_t ids, uint32_t p8, bool sub, u32x4v (&R)[4]) {
+    // (every broadcast with ALL lanes active -- a DPP read of a lane that is switched off returns zero -- and only then the choice)
+    const uint32_t e0 = row_newbcast<8 * T + 0>(ids), o0 = row_newbcast<8 * T + 1>(ids), e1 = row_newbcast<8 * T + 2>(ids), o1 = row_newbcast<8 * T + 3>(ids);
+    const uint32_t e2 = row_newbcast<8 * T + 4>(ids), o2 = row_newbcast<8 * T + 5>(ids), e3 = row_newbcast<8 * T + 6>(ids), o3 = row_newbcast<8 * T + 7>(ids);
+    const uint32_t i0 = sub ? o0 : e0, i1 = sub ? o1 : e1, i2 = sub ? o2 : e2, i3 = sub ? o3 : e3;
+    R[0] = __builtin_nontemporal_load(Xb + (size_t)i0 * 8 + p8);
+    R[1] = __builtin_nontemporal_load(Xb + (size_t)i1 * 8 + p8);
+    R[2] = __builtin_nontemporal_load(Xb + (size_t)i2 * 8 + p8);
+    R[3] = __builtin_nontemporal_load(Xb + (size_t)i3 * 8 + p8);
+}
+#ifndef ZH_S128B_WAVES
+#define ZH_S128B_WAVES 4   // waves per SIMD the byte kernel's register allocation is held to (A/B)
+#endif
+#ifndef ZH_S128B_EXP
+#define ZH_S128B_EXP 0     // timing experiments on the byte kernel (profiles/r06_sweep128b_experiments.txt), results INVALID: 1 no conversion, 2 no epilogue, 3 no Gram; valid: 4 no pre-test
+#endif
+template <int CH, int FUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZH_S128B_WAVES, ZH_S128B_WAVES)))
+void sweep128b_lean_kernel(const u32x4v *__restrict__ Xb, const u32x4v *__restrict__ Qh,
+                           const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
+                           uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
+                           const uint32_t *__restrict__ leaf_ids, uint64_t row_begin, uint64_t R_grouped,
+                           uint64_t *__restrict__ iv, ZhApprox ap, uint32_t k_top, float Kc) {
+    __shared__ u32x4v rows_lds[4][32 * 8];  // per wave: ONE double tile = 32 image rows x 8 pieces of 16 bytes
+    const uint32_t lane = threadIdx.x & 63, c16 = lane & 15, h = lane >> 4, p8 = c16 & 7u;
+    const bool sub = (c16 & 8u) != 0;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t r_first = row_begin + wave * (64 * CH);
+    if (r_first >= R_grouped) return;
+    u32x4v *tl = rows_lds[wid];
+    f16x8 Aq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) Aq[st] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t a_g = 0xFFFFFFFFu;
+    const uint32_t diag_src = (((c16 >> 2) << 4) | c16) << 2;
+    const bool c_odd = (c16 & 1u) != 0, c_up = (c16 & 2u) != 0;
+    const uint32_t pi = 16u * h + 8u * (c16 >> 3) + 4u * (c16 & 1u) + ((c16 >> 1) & 3u);  // the flat row of the chunk this lane ends up with
+    const uint32_t nat_src = (((pi & 3u) << 4) | (pi >> 2)) << 2;                          // ... and the lane that holds its id
+    // where this lane's loads land in the image, and where its fragments come from (16-byte units; + 128 * m for set m)
+    uint32_t wr_at[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t J = 8u * i + 2u * h + (sub ? 1u : 0u);
+        wr_at[i] = J * 8 + (p8 ^ ((J >> 1) & 7u));
+    }
+    const uint32_t rd_sw = (c16 >> 1) & 7u, rd0 = c16 * 8 + ((2u * h) ^ rd_sw), rd1 = c16 * 8 + ((2u * h + 1u) ^ rd_sw);
+    u32x4v R[4];
+    uint32_t topv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    float pre[4][3] = {{0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}};  // (fused_pretest_setup, per group)
+    bool carried = false;
+    uint32_t ids = 0;              // lane (h, c16) holds the id of flat row 4 c16 + h of the chunk
+    uint32_t g = 0, within0 = 0;
+    for (int c = 0; c < CH; c++) {
+        const uint64_t r0 = r_first + 64ull * c;
+        if (r0 >= R_grouped) break;
+        if (!carried) {
+            uint32_t g_v, w_v;
+            const bool fast = lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
+            if (!fast) continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_v);
+            within0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_v);
+        }
+        const ZhGroup *gr = groups + g;
+        const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
+        if (!carried) {
+            const uint32_t w = within0 + 4u * c16 + h;
+            ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+            issue_byte_tile<0>(Xb, ids, p8, sub, R);
+        }
+        if (g != a_g) {  // (wave-uniform) A's row m = query slot m & 3 of group g, zero past gsize; step st = the query's piece 4 h + st
+            a_g = g;
+            topv[0] = topv[1] = topv[2] = topv[3] = 0xFFFFFFFFu;
+            if constexpr (FUSE == 0) fused_pretest_setup(gr, gsize, ap, Kc, pre);
+            const bool on = (c16 & 3u) < gsize;
+            const uint32_t b = on ? gr->b[c16 & 3u] : 0u;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const u32x4v v = Qh[(size_t)b * 16 + 4 * h + st];
+                Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
+        uint32_t nxt_ids = 0;
+        if (next_fast) {
+            const uint32_t w = within0 + 64u + 4u * c16 + h;
+            nxt_ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
+        }
+        uint32_t tau_pre[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if constexpr (FUSE >= 0) fused_tau(gr, gsize, ap, tau_pre);
+        float res[4] = {0.f, 0.f, 0.f, 0.f}, res_a2 = 0.f;
+        auto dtile = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; i++) tl[wr_at[i]] = R[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (T == 0) issue_byte_tile<1>(Xb, ids, p8, sub, R);
+            else if (next_fast) issue_byte_tile<0>(Xb, nxt_ids, p8, sub, R);
+            const u32x4v v00 = tl[rd0], v01 = tl[rd1], v10 = tl[128 + rd0], v11 = tl[128 + rd1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const u32x4v v0 = m ? v10 : v00, v1 = m ? v11 : v01;
+#if ZH_S128B_EXP == 1
+                const f16x8 Bf[4] = {__builtin_bit_cast(f16x8, v0), __builtin_bit_cast(f16x8, v1), __builtin_bit_cast(f16x8, v0), __builtin_bit_cast(f16x8, v1)};
+#else
+                const f16x8 Bf[4] = {bytes8_to_f16(v0[0], v0[1]), bytes8_to_f16(v0[2], v0[3]), bytes8_to_f16(v1[0], v1[1]), bytes8_to_f16(v1[2], v1[3])};
+#endif
+                f32x4v dsum = {0.f, 0.f, 0.f, 0.f}, gram = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[st], Bf[st], dsum, 0, 0, 0);
+#if ZH_S128B_EXP != 3
+                    gram = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[st], Bf[st], gram, 0, 0, 0);
+#else
+                    gram = dsum;
+#endif
+                }
+                const float dg_lo = c_odd ? gram[1] : gram[0], dg_hi = c_odd ? gram[3] : gram[2], dg = c_up ? dg_hi : dg_lo;
+                const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)diag_src, __float_as_int(dg)));
+                const bool keep = h == (uint32_t)(2 * T + m);
+#pragma unroll
+                for (int j = 0; j < 4; j++) res[j] = keep ? dsum[j] : res[j];
+                res_a2 = keep ? a2 : res_a2;
+            }
+        };
+        dtile(std::integral_constant<int, 0>{});
+        dtile(std::integral_constant<int, 1>{});
+        if constexpr (FUSE < 0) {
+            const uint32_t a2b = __float_as_uint(res_a2);
+            uint64_t *const dst = iv + within0 + pi;  // slot j's results of the chunk: its key slice, positions within0 .. within0 + 63 (a permutation of them)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)j < gsize) __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(res[j]), dst + gr->key_off[j]);
+        } else {
+            const uint32_t idn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)nat_src, (int)ids);
+            const uint32_t take4 = gr->take4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)j < gsize && (ZH_S128B_EXP != 2 || res[j] == 123456.789f)) {
+                    const uint32_t take = (take4 >> (8 * j)) & 255u;
+                    if constexpr (FUSE == 0 && ZH_S128B_EXP != 4) {
+                        if (!(take < glen && take < k_top)) {  // (the exact path's visits keep every interval)
+                            const uint32_t t_w = take < glen ? (uint32_t)__builtin_amdgcn_readlane((int)topv[j], (int)(take - 1)) : 0xFFFFFFFFu;
+                            const uint32_t t_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_pre[j]);
+                            if (fused_pretest(res[j], res_a2, pre[j], t_w < t_q ? t_w : t_q)) continue;
+                        }
+                    }
+                    fused_slot<FUSE>(res[j], res_a2, idn, lane, gr->b[j], take, glen, k_top, Kc, ap,
+                                     iv + gr->key_off[j] + within0 + pi, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j]);  // (the image is idle here: the next double tile waits in R)
+                }
         }
         carried = next_fast;
         if (next_fast) { ids = nxt_ids; within0 += 64; }
@@ -1632,8 +1907,9 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
 
 // The chunks lean_chunk() turns down -- a group boundary inside the 64 rows, or the launch's short last chunk: ~1 in 70 with leaves of thousands of
 // rows -- in the general per-lane form of sweep128h_kernel, one chunk at a time.  A wave looks at 64 chunks (a lane each: two loads) and
-// works through the ones that are its business; |x^|^2 from the Gram diagonal here too.
-template <int FUSE>
+// works through the ones that are its business; |x^|^2 from the Gram diagonal here too.  BYTES: Xh is row_byte128_kernel's copy (a 16-row tile
+// is two load instructions: image row J = 8 i + 2 h + sub = the tile's row J, the image and the K order as in sweep128b_lean_kernel; inv = 1).
+template <int FUSE, bool BYTES>
 __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restrict__ Qh, float inv,
                                                                   const ZhGroup *__restrict__ groups, const uint64_t *__restrict__ groupRowOff,
                                                                   uint64_t n_groups, const uint32_t *__restrict__ waveGroup,
@@ -1676,21 +1952,38 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
         uint32_t c_rg = 0xFFFFFFFFu, c_hi = 0, c_lo[4] = {0, 0, 0, 0};
         uint32_t c_b[4] = {0, 0, 0, 0}, c_take4 = 0, c_len = 0;  // fused form: the rest of the lane's group record
         auto issue_tile = [&](uint32_t t) {
+            if constexpr (BYTES) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t fr = 16u * t + 4u * i + h;
-                const uint32_t id = (uint32_t)__shfl((int)my_id, (int)(fr < cnt ? fr : cnt - 1));
-                R[i] = __builtin_nontemporal_load(Xh + (size_t)id * 16 + c16);
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t fr = 16u * t + 8u * i + 2u * h + (c16 >> 3);
+                    const uint32_t id = (uint32_t)__shfl((int)my_id, (int)(fr < cnt ? fr : cnt - 1));
+                    R[i] = __builtin_nontemporal_load(Xh + (size_t)id * 8 + (c16 & 7u));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t fr = 16u * t + 4u * i + h;
+                    const uint32_t id = (uint32_t)__shfl((int)my_id, (int)(fr < cnt ? fr : cnt - 1));
+                    R[i] = __builtin_nontemporal_load(Xh + (size_t)id * 16 + c16);
+                }
             }
         };
         issue_tile(0);
         const uint32_t ntile = (cnt + 15) / 16;
 #pragma unroll 1
         for (uint32_t t = 0; t < ntile; t++) {
+            if constexpr (BYTES) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t rr = 4u * i + h;
-                tl[rr * 16 + (c16 ^ rr)] = R[i];
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t J = 8u * i + 2u * h + (c16 >> 3);
+                    tl[J * 8 + ((c16 & 7u) ^ ((J >> 1) & 7u))] = R[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t rr = 4u * i + h;
+                    tl[rr * 16 + (c16 ^ rr)] = R[i];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1712,8 +2005,15 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
             }
             if (t + 1 < ntile) issue_tile(t + 1);
             f16x8 Bf[4];
+            if constexpr (BYTES) {
+                const uint32_t sw = (c16 >> 1) & 7u;
+                const u32x4v v0 = tl[c16 * 8 + ((2u * h) ^ sw)], v1 = tl[c16 * 8 + ((2u * h + 1u) ^ sw)];
+                Bf[0] = bytes8_to_f16(v0[0], v0[1]); Bf[1] = bytes8_to_f16(v0[2], v0[3]);
+                Bf[2] = bytes8_to_f16(v1[0], v1[1]); Bf[3] = bytes8_to_f16(v1[2], v1[3]);
+            } else {
 #pragma unroll
-            for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+                for (int st = 0; st < 4; st++) Bf[st] = __builtin_bit_cast(f16x8, tl[c16 * 16 + ((4u * st + h) ^ c16)]);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t last = 16 * t + 15 < cnt ? 16 * t + 15 : cnt - 1;
@@ -1732,7 +2032,7 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
                     const uint32_t b = on ? groups[grp].b[c16 & 3u] : 0u;
 #pragma unroll
                     for (int st = 0; st < 4; st++) {
-                        const u32x4v v = Qh[(size_t)b * 16 + 4 * st + h];
+                        const u32x4v v = Qh[(size_t)b * 16 + (BYTES ? 4 * h + st : 4 * st + h)];
                         Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     }
                 }
@@ -1797,26 +2097,36 @@ hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, u
 #ifndef ZH_S128F_CH
 #define ZH_S128F_CH 16  // ... of its fused form: a wave's bound comes from the rows IT has seen (64 chunks = the top_k / 1024 quantile at best)
 #endif
-template <int FUSE>
+#ifndef ZH_S128B_LAUNCH_X
+#define ZH_S128B_LAUNCH_X 4   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128) (A/B): the same ~2 ms as the others'
+#endif
+uint64_t zh_sweep128h_rows_per_launch(bool lean, bool byte_rows) {
+    return (lean ? (byte_rows ? ZH_S128B_LAUNCH_X : 2) : 1) * zh_sweep_rows_per_launch(128);
+}
+template <int FUSE, bool BYTES>
 static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                   const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, const ZhApprox &ap,
                                   uint32_t k_top, float Kc, hipStream_t s) {
     // zh_sweep_rows_per_launch sizes a launch as ~12 GB of F32 rows (~2 ms of HBM time: other queues get dispatch slots between launches); this sweep
     // reads 256-byte rows -- the same row count was a 1.1-ms launch whose tail (24.6k waves over 4096 wave slots: six rounds, the last one partly
     // empty) cost 6-7 %: twice the rows, the same ~2.2 ms (cfg5 shard, window 4: 359-367 -> 383-384 k QPS; four times: 390-392 k)
-    const uint64_t rows_per_launch = 2 * zh_sweep_rows_per_launch(128);
+    const uint64_t rows_per_launch = zh_sweep128h_rows_per_launch(true, BYTES);
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         constexpr int CHL = FUSE >= 0 ? ZH_S128F_CH : ZH_S128L_CH;
         const uint64_t wl = (r_end - r + 64 * CHL - 1) / (64 * CHL);
-        hipLaunchKernelGGL((sweep128h_lean_kernel<CHL, FUSE>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh,
-                           (const u32x4v *)dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv, ap, k_top, Kc);
+        if constexpr (BYTES)
+            hipLaunchKernelGGL((sweep128b_lean_kernel<CHL, FUSE>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh,
+                               (const u32x4v *)dQh, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv, ap, k_top, Kc);
+        else
+            hipLaunchKernelGGL((sweep128h_lean_kernel<CHL, FUSE>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh,
+                               (const u32x4v *)dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv, ap, k_top, Kc);
     }
 #if ZH_S128L_EXP != 5    // (5: timing experiment without the boundary kernel, results invalid)
     // the chunks that cross a group boundary, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
     // looks at 64 chunks.  Chunk boundaries are absolute (every launch above starts on a multiple of 256 rows), so both kernels see the same chunks
     const uint64_t bw = ((R_grouped + 63) / 64 + 63) / 64, bb = (bw + 3) / 4;
-    hipLaunchKernelGGL((sweep128h_boundary_kernel<FUSE>), dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
+    hipLaunchKernelGGL((sweep128h_boundary_kernel<FUSE, BYTES>), dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
                        dGroupRowOff, n_groups, dWaveGroup, dLeafIds, (uint64_t)0, R_grouped, dIv, ap, k_top, Kc);
 #endif
 }
@@ -1824,7 +2134,7 @@ static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, c
 // inside the sweep; exact_register_kernel instead of the select pass): `fuse_kinda` = approx_interval's kind, k_top <= 64
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s,
-                               const ZhApprox *fuse, int fuse_kinda, uint32_t k_top, float Kc) {
+                               const ZhApprox *fuse, int fuse_kinda, uint32_t k_top, float Kc, bool byte_rows) {
     if (R_grouped == 0 || n_groups == 0) return hipSuccess;
     constexpr int CH = 4;
     const uint64_t rows_per_launch = zh_sweep_rows_per_launch(128);
@@ -1836,15 +2146,24 @@ hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, cons
     const bool dma = dma_e && dma_e[0] == '1', r5 = kern_e && kern_e[0] == 'r';
     if (fuse) {
         if (!dWaveGroup || k_top == 0 || k_top > 64) return hipErrorInvalidValue;
-        if (fuse_kinda == 0) launch_sweep128h_lean<0>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
-        else if (fuse_kinda == 1) launch_sweep128h_lean<1>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
-        else launch_sweep128h_lean<2>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);
+#define ZH_LEAN(F)                                                                                                                                  \
+    do {                                                                                                                                            \
+        if (byte_rows) launch_sweep128h_lean<F, true>(dXh, dQh, 1.f, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s); \
+        else launch_sweep128h_lean<F, false>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, *fuse, k_top, Kc, s);           \
+    } while (0)
+        if (fuse_kinda == 0) ZH_LEAN(0);
+        else if (fuse_kinda == 1) ZH_LEAN(1);
+        else ZH_LEAN(2);
+#undef ZH_LEAN
         return hipGetLastError();
     }
     if (!dma && !r5) {
-        launch_sweep128h_lean<-1>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, ZhApprox{}, 0u, 0.f, s);
+        const ZhApprox none{};
+        if (byte_rows) launch_sweep128h_lean<-1, true>(dXh, dQh, 1.f, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, none, 0u, 0.f, s);
+        else launch_sweep128h_lean<-1, false>(dXh, dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, R_grouped, dIv, none, 0u, 0.f, s);
         return hipGetLastError();
     }
+    if (byte_rows) return hipErrorInvalidValue;  // (the round-5 kernels read the copy of halves)
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
         const uint64_t w = (r_end - r + 64 * CH - 1) / (64 * CH), blocks = (w + 3) / 4;

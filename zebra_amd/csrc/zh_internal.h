@@ -248,6 +248,7 @@ struct ZhApprox {
     uint32_t mfma;           // zh_approx_bound's kind: 0 VALU scans, 1 scan_mfma_kernel, 2 sweep128h_kernel
     uint32_t n_queries;      // queries of the internal batch, entries of iv (diagnostic builds check every index against them: -DZH_SCAN_GUARD)
     uint64_t iv_cap;
+    float nx_max;            // > 0: no stored row's norm estimate (approx_interval's nx) exceeds it -- the byte copy: sqrt(128) * 255 (fused sweep's pre-test)
 };
 uint32_t zh_approx_groups(uint32_t d);
 bool zh_approx_pays(uint32_t d);
@@ -270,7 +271,11 @@ hipError_t zh_launch_absmax(const float *dX, uint64_t n, uint32_t *dOut, hipStre
 hipError_t zh_launch_row_half128(const float *dX, uint64_t row0, uint64_t n_rows, float sigma, void *dXh, uint32_t *dRhoMax, hipStream_t s);
 hipError_t zh_launch_sweep128h(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
                                const uint32_t *dWaveGroup, const uint32_t *dLeafIds, uint64_t R_grouped, uint64_t *dIv, hipStream_t s,
-                               const ZhApprox *fuse = nullptr, int fuse_kinda = 0, uint32_t k_top = 0, float Kc = 0.f);
+                               const ZhApprox *fuse = nullptr, int fuse_kinda = 0, uint32_t k_top = 0, float Kc = 0.f, bool byte_rows = false);
+// ... and of a table whose every element is an integer in 0 .. 255 (SIFT descriptors): an EXACT copy of 128 bytes per row (*dNotBytes |= 1 when an
+// element of rows row0 .. is anything else: the copy is then void); byte_rows above = dXh is that copy (the lean kernels only)
+uint64_t zh_sweep128h_rows_per_launch(bool lean, bool byte_rows);  // stored rows one launch of the sweep takes (the host's launch accounting)
+hipError_t zh_launch_row_byte128(const float *dX, uint64_t row0, uint64_t n_rows, void *dXb, uint32_t *dNotBytes, hipStream_t s);
 // (fused sweep) the exact path's visits, as select_tau_kernel lists them
 hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, uint32_t k, ZhApprox ap, hipStream_t s);
 hipError_t zh_launch_scan_approx(const float *dX, uint32_t d, uint64_t n_rows, ZhApprox ap, const uint2 *dRowLeaf, uint32_t T,
