@@ -2098,7 +2098,10 @@ hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, u
 #define ZH_S128F_CH 16  // ... of its fused form: a wave's bound comes from the rows IT has seen (64 chunks = the top_k / 1024 quantile at best)
 #endif
 #ifndef ZH_S128B_LAUNCH_X
-#define ZH_S128B_LAUNCH_X 4   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128) (A/B): the same ~2 ms as the others'
+#define ZH_S128B_LAUNCH_X 4   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128): the same ~2 ms as the others' (A/B, cfg5 shard:
+#endif                        // 2: -2 %, 8: -1 % .. +3 % with 4.6-ms launches; profiles/r06_sweep128b_experiments.txt)
+#ifndef ZH_S128B_CH
+#define ZH_S128B_CH 32        // 64-row chunks per wave of the fused byte kernel (8: -11 %, 16: -3.5 %, 48 / 64: level)
 #endif
 uint64_t zh_sweep128h_rows_per_launch(bool lean, bool byte_rows) {
     return (lean ? (byte_rows ? ZH_S128B_LAUNCH_X : 2) : 1) * zh_sweep_rows_per_launch(128);
@@ -2113,7 +2116,7 @@ static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, c
     const uint64_t rows_per_launch = zh_sweep128h_rows_per_launch(true, BYTES);
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
-        constexpr int CHL = FUSE >= 0 ? ZH_S128F_CH : ZH_S128L_CH;
+        constexpr int CHL = FUSE >= 0 ? (BYTES ? ZH_S128B_CH : ZH_S128F_CH) : ZH_S128L_CH;
         const uint64_t wl = (r_end - r + 64 * CHL - 1) / (64 * CHL);
         if constexpr (BYTES)
             hipLaunchKernelGGL((sweep128b_lean_kernel<CHL, FUSE>), dim3((uint32_t)((wl + 3) / 4)), dim3(256), 0, s, (const u32x4v *)dXh,
