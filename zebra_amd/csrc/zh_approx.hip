@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__rest
 //     v_mfma_f32_16x16x32_f16 coincide) on a matrix pipe that has nothing else to do, three selects and one ds_bpermute;
 //   * the four K-steps chain through one accumulator.
 // A chunk that crosses a group boundary (or the batch's last, short one) is sweep128h_boundary_kernel's: the general per-lane form of the kernel above,
-// one chunk at a time, one launch per batch (lean_chunk() is the predicate both kernels split the chunks by).  Same raw pairs up to the summation
+// one chunk at a time, one launch per batch (chunk_segments() is the predicate both kernels split the chunks by).  Same raw pairs up to the summation
 // order inside the matrix pipe (covered by zh_approx_bound's MFMA term, tests/test_gpu_intervals.py) -- the results behind them are bit-identical
 // by construction as before.
 // ---- the fused sweep (round 6).  The stores of the raw pairs -- under 4 % of the sweep's bytes -- cost the lean kernel a fifth of its time (0.99 ms per
@@ -1472,15 +1472,17 @@ __device__ __forceinline__ void topk_merge(uint32_t &topv, uint32_t v, uint32_t 
 
 template <int KINDA>
 __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint32_t lane, uint32_t bq, uint32_t take, uint32_t glen, uint32_t k_top,
-                                           float Kc, const ZhApprox &ap, uint64_t *__restrict__ iv_slot, uint32_t &topv, uint32_t *scratch, uint32_t tau) {
+                                           float Kc, const ZhApprox &ap, uint64_t *__restrict__ iv_slot, uint32_t &topv, uint32_t *scratch, uint32_t tau,
+                                           bool valid) {
+    // valid: the lane holds a row of the segment (a short segment's other lanes hold copies of its last row: no interval stored, none offered, none listed)
     // tau: the query's bound as the caller read it BEFORE the chunk's tiles (fused_tau) -- any value qtau ever held is a certified bound, and a read
     // here would sit behind the row loads in flight (vmcnt counts in order): every slot a memory round trip with nothing else to do
     if (take == 0) return;  // (wave-uniform)
     const float4 qm = ap.qmeta[bq];
     const uint64_t w = approx_interval<KINDA>(s, a2, qm, Kc, ap.row_rho, ap.rho_norm);
-    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    const uint32_t lo = (uint32_t)w, hi = valid ? (uint32_t)(w >> 32) : 0xFFFFFFFFu;
     if (take < glen && take < k_top) {  // the exact path's visit
-        __builtin_nontemporal_store(w, iv_slot);
+        if (valid) __builtin_nontemporal_store(w, iv_slot);
         return;
     }
     tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau);
@@ -1491,7 +1493,7 @@ __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint3
         if (mine < before && mine < tau && lane == 0) atomicMin(&ap.qtau[bq], mine);
         if (mine < tau) tau = mine;
     }
-    const uint64_t m = __ballot(lo <= tau);
+    const uint64_t m = __ballot(valid && lo <= tau);
     if (!m) return;
     const uint32_t M = (uint32_t)__builtin_popcountll(m);
     uint32_t base = 0;
@@ -1501,7 +1503,7 @@ __device__ __forceinline__ void fused_slot(float s, float a2, uint32_t id, uint3
         if (lane == 0) atomicOr(&ap.ctl[1], 1u);
         return;
     }
-    if (lo <= tau) {
+    if (valid && lo <= tau) {
         const size_t o = (size_t)bq * ap.capq + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         ap.list_lo[o] = lo; ap.list_hi[o] = hi; ap.list_id[o] = id;
     }
@@ -1539,10 +1541,10 @@ __device__ __forceinline__ float f32_unsortable(uint32_t s) {  // (0xFFFFFFFF, "
     return __uint_as_float(s ^ ((s >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 // true: no row of the chunk can matter to the slot's query (wave-uniform)
-__device__ __forceinline__ bool fused_pretest(float s, float a2, const float (&pre)[3], uint32_t tau) {
+__device__ __forceinline__ bool fused_pretest(float s, float a2, const float (&pre)[3], uint32_t tau, bool valid) {
     if (!(pre[2] >= 0.f)) return false;
     const float V = l2_V(s, a2, make_float4(pre[0], pre[1], 0.f, 0.f));
-    const bool drop = (V - pre[2] > f32_unsortable(tau)) && V < 3.0e38f;
+    const bool drop = !valid || ((V - pre[2] > f32_unsortable(tau)) && V < 3.0e38f);
     return __ballot(!drop) == 0;
 }
 template <int N>
@@ -1564,16 +1566,25 @@ __device__ __forceinline__ void issue_lean_tile(const u32x4v *__restrict__ Xh, u
     R[3] = __builtin_nontemporal_load(Xh + (size_t)row_newbcast<4 * T + 3>(ids) * 16 + c16);
 #endif
 }
-// Is the full chunk of flat rows r0 .. r0 + 63 inside ONE group?  (r0 a multiple of 64.)  THE predicate that splits a launch's chunks between
-// sweep128h_lean_kernel (true) and sweep128h_boundary_kernel (false): every chunk is scored by exactly one of them.
-__device__ __forceinline__ bool lean_chunk(uint64_t r0, uint32_t cnt, const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
-                                           const uint32_t *__restrict__ waveGroup, uint32_t &g, uint32_t &within0) {
-    if (!waveGroup || cnt != 64) return false;
+// The chunk of flat rows r0 .. r0 + cnt - 1 (r0 a multiple of 64, cnt <= 64: the batch's last chunk is short) as at most TWO SEGMENTS, each inside one
+// group: cntA rows of group g from its row within0 and -- where a group ends inside the chunk -- cntB rows from the first row of group g + 1.
+// THE predicate that splits a launch's chunks between the lean kernels (true: with leaves of thousands of rows every chunk; a segment is scored
+// like a chunk whose lanes past its count are switched off) and sweep128h_boundary_kernel (false: three or more groups in 64 rows): every chunk
+// is scored by exactly one of them.  (Until the last session of round 6 a chunk with a group boundary in it was the boundary kernel's: ~1 chunk in 70
+// at cfg5, scored one chunk per wave at a time -- a serial 1.2-1.3 ms behind every window's sweep launches, 5 % of the stage.)
+__device__ __forceinline__ bool chunk_segments(uint64_t r0, uint32_t cnt, const uint64_t *__restrict__ groupRowOff, uint64_t n_groups,
+                                               const uint32_t *__restrict__ waveGroup, uint32_t &g, uint32_t &within0, uint32_t &cntA, uint32_t &cntB) {
+    if (!waveGroup || cnt == 0) return false;
     g = waveGroup[r0 >> 6];
-    const uint64_t off = groupRowOff[g];
+    const uint64_t off = groupRowOff[g], end = r0 + cnt;
     const uint64_t nxt = (uint64_t)g + 1 < n_groups ? groupRowOff[g + 1] : ~0ull;
     within0 = (uint32_t)(r0 - off);
-    return nxt >= r0 + 64;
+    cntA = cnt; cntB = 0;
+    if (nxt >= end) return true;
+    const uint64_t nxt2 = (uint64_t)g + 2 < n_groups ? groupRowOff[g + 2] : ~0ull;
+    if (nxt2 < end) return false;
+    cntA = (uint32_t)(nxt - r0); cntB = (uint32_t)(end - nxt);
+    return true;
 }
 #ifndef ZH_S128L_EXP
 #define ZH_S128L_EXP 0     // timing experiments on the lean kernel (profiles/r06_sweep128h_experiments.txt); 0 = the shipped form
@@ -1615,17 +1626,23 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
     for (int c = 0; c < CH; c++) {
         const uint64_t r0 = r_first + 64ull * c;
         if (r0 >= R_grouped) break;
+        uint32_t cntA = 64, cntB = 0;  // (a carried chunk is a full one inside its group)
         if (!carried) {
-            uint32_t g_v, w_v;
-            const bool fast = lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
-            if (!fast) continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
+            uint32_t g_v, w_v, a_v, b_v;
+            if (!chunk_segments(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v, a_v, b_v))
+                continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
             g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_v);
             within0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_v);
+            cntA = (uint32_t)__builtin_amdgcn_readfirstlane((int)a_v);
+            cntB = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_v);
         }
+      for (uint32_t seg = 0; seg < (cntB ? 2u : 1u); seg++) {  // the chunk's segments: one, or two where a group ends inside it
+        const uint32_t cnt = seg ? cntB : cntA;
+        if (seg) { g += 1; within0 = 0; }
         const ZhGroup *gr = groups + g;
         const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
         if (!carried) {
-            const uint32_t w = within0 + 4u * c16 + h;
+            const uint32_t fr = 4u * c16 + h, w = within0 + (fr < cnt ? fr : cnt - 1);  // (a short segment: the lanes past it hold its last row again)
             ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
             issue_lean_tile<0>(Xh, ids, c16, R);
         }
@@ -1642,7 +1659,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
             }
         }
         // the next chunk: entirely inside the same group?  Then its ids are requested now and its first tile behind this chunk's last one
-        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
+        const bool next_fast = cnt == 64 && cntB == 0 && c + 1 < CH && (uint64_t)within0 + 128 <= glen;
         uint32_t nxt_ids = 0;
         if (next_fast) {
             const uint32_t w = within0 + 64u + 4u * c16 + h;
@@ -1693,7 +1710,7 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
             uint64_t *const dst = iv + within0 + lane;  // slot j's results of the chunk: its key slice, positions within0 .. within0 + 63
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((uint32_t)j < gsize) {
+                if ((uint32_t)j < gsize && lane < cnt) {
                     const uint64_t v = ((uint64_t)a2b << 32) | __float_as_uint(res[j] * inv);
 #if ZH_S128L_EXP == 1    // timing experiment (results invalid): no result stores
                     if (res_a2 == 123456.789f) dst[gr->key_off[j]] = v;
@@ -1721,15 +1738,16 @@ void sweep128h_lean_kernel(const u32x4v *__restrict__ Xh, const u32x4v *__restri
                         if (!(take < glen && take < k_top)) {  // (the exact path's visits keep every interval)
                             const uint32_t t_w = take < glen ? (uint32_t)__builtin_amdgcn_readlane((int)topv[j], (int)(take - 1)) : 0xFFFFFFFFu;
                             const uint32_t t_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_pre[j]);
-                            if (fused_pretest(res[j] * inv, a2s, pre[j], t_w < t_q ? t_w : t_q)) continue;
+                            if (fused_pretest(res[j] * inv, a2s, pre[j], t_w < t_q ? t_w : t_q, lane < cnt)) continue;
                         }
                     }
                     fused_slot<FUSE>(res[j] * inv, a2s, idn, lane, gr->b[j], take, glen, k_top, Kc, ap,
-                                     iv + gr->key_off[j] + within0 + lane, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j]);  // (the tile buffer is idle here: the next tile waits in R)
+                                     iv + gr->key_off[j] + within0 + lane, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j], lane < cnt);  // (the tile buffer is idle here: the next tile waits in R)
                 }
         }
         carried = next_fast;
         if (next_fast) { ids = nxt_ids; within0 += 64; }
+      }
     }
 }
 
@@ -1802,17 +1820,23 @@ void sweep128b_lean_kernel(const u32x4v *__restrict__ Xb, const u32x4v *__restri
     for (int c = 0; c < CH; c++) {
         const uint64_t r0 = r_first + 64ull * c;
         if (r0 >= R_grouped) break;
+        uint32_t cntA = 64, cntB = 0;  // (a carried chunk is a full one inside its group)
         if (!carried) {
-            uint32_t g_v, w_v;
-            const bool fast = lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
-            if (!fast) continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
+            uint32_t g_v, w_v, a_v, b_v;
+            if (!chunk_segments(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v, a_v, b_v))
+                continue;  // (wave-uniform: sweep128h_boundary_kernel's chunk)
             g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_v);
             within0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_v);
+            cntA = (uint32_t)__builtin_amdgcn_readfirstlane((int)a_v);
+            cntB = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_v);
         }
+      for (uint32_t seg = 0; seg < (cntB ? 2u : 1u); seg++) {  // the chunk's segments: one, or two where a group ends inside it
+        const uint32_t cnt = seg ? cntB : cntA;
+        if (seg) { g += 1; within0 = 0; }
         const ZhGroup *gr = groups + g;
         const uint32_t leaf_off = gr->leaf_off, glen = gr->len, gsize = gr->gsize;
         if (!carried) {
-            const uint32_t w = within0 + 4u * c16 + h;
+            const uint32_t fr = 4u * c16 + h, w = within0 + (fr < cnt ? fr : cnt - 1);  // (a short segment: the lanes past it hold its last row again)
             ids = leaf_ids ? leaf_ids[(size_t)leaf_off + w] : leaf_off + w;
             issue_byte_tile<0>(Xb, ids, p8, sub, R);
         }
@@ -1828,7 +1852,7 @@ void sweep128b_lean_kernel(const u32x4v *__restrict__ Xb, const u32x4v *__restri
                 Aq[st] = on ? __builtin_bit_cast(f16x8, v) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
-        const bool next_fast = c + 1 < CH && (uint64_t)within0 + 128 <= glen;
+        const bool next_fast = cnt == 64 && cntB == 0 && c + 1 < CH && (uint64_t)within0 + 128 <= glen;
         uint32_t nxt_ids = 0;
         if (next_fast) {
             const uint32_t w = within0 + 64u + 4u * c16 + h;
@@ -1881,7 +1905,7 @@ void sweep128b_lean_kernel(const u32x4v *__restrict__ Xb, const u32x4v *__restri
             uint64_t *const dst = iv + within0 + pi;  // slot j's results of the chunk: its key slice, positions within0 .. within0 + 63 (a permutation of them)
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((uint32_t)j < gsize) __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(res[j]), dst + gr->key_off[j]);
+                if ((uint32_t)j < gsize && pi < cnt) __builtin_nontemporal_store(((uint64_t)a2b << 32) | __float_as_uint(res[j]), dst + gr->key_off[j]);
         } else {
             const uint32_t idn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)nat_src, (int)ids);
             const uint32_t take4 = gr->take4;
@@ -1893,20 +1917,21 @@ void sweep128b_lean_kernel(const u32x4v *__restrict__ Xb, const u32x4v *__restri
                         if (!(take < glen && take < k_top)) {  // (the exact path's visits keep every interval)
                             const uint32_t t_w = take < glen ? (uint32_t)__builtin_amdgcn_readlane((int)topv[j], (int)(take - 1)) : 0xFFFFFFFFu;
                             const uint32_t t_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_pre[j]);
-                            if (fused_pretest(res[j], res_a2, pre[j], t_w < t_q ? t_w : t_q)) continue;
+                            if (fused_pretest(res[j], res_a2, pre[j], t_w < t_q ? t_w : t_q, pi < cnt)) continue;
                         }
                     }
                     fused_slot<FUSE>(res[j], res_a2, idn, lane, gr->b[j], take, glen, k_top, Kc, ap,
-                                     iv + gr->key_off[j] + within0 + pi, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j]);  // (the image is idle here: the next double tile waits in R)
+                                     iv + gr->key_off[j] + within0 + pi, topv[j], reinterpret_cast<uint32_t *>(tl), tau_pre[j], pi < cnt);  // (the image is idle here: the next double tile waits in R)
                 }
         }
         carried = next_fast;
         if (next_fast) { ids = nxt_ids; within0 += 64; }
+      }
     }
 }
 
-// The chunks lean_chunk() turns down -- a group boundary inside the 64 rows, or the launch's short last chunk: ~1 in 70 with leaves of thousands of
-// rows -- in the general per-lane form of sweep128h_kernel, one chunk at a time.  A wave looks at 64 chunks (a lane each: two loads) and
+// The chunks chunk_segments() turns down -- three or more groups inside the 64 rows: none with leaves of thousands of rows, most with leaves of a handful --
+// in the general per-lane form of sweep128h_kernel, one chunk at a time.  A wave looks at 64 chunks (a lane each: two loads) and
 // works through the ones that are its business; |x^|^2 from the Gram diagonal here too.  BYTES: Xh is row_byte128_kernel's copy (a 16-row tile
 // is two load instructions: image row J = 8 i + 2 h + sub = the tile's row J, the image and the K order as in sweep128b_lean_kernel; inv = 1).
 template <int FUSE, bool BYTES>
@@ -1927,8 +1952,8 @@ __global__ __launch_bounds__(256) void sweep128h_boundary_kernel(const u32x4v *_
         bool mine = false;
         if (ci < n_chunks) {
             const uint64_t r0 = row_begin + (ci << 6);
-            uint32_t g_v, w_v;
-            mine = !lean_chunk(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v);
+            uint32_t g_v, w_v, a_v, b_v;
+            mine = !chunk_segments(r0, (uint32_t)(R_grouped - r0 < 64 ? R_grouped - r0 : 64), groupRowOff, n_groups, waveGroup, g_v, w_v, a_v, b_v);
         }
         todo = __ballot(mine);
     }
