@@ -595,7 +595,7 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         # back by a select pass), so the algorithmic bytes per scored row are the row (2 d, once per distinct leaf group) and its 4-byte leaf id
         per_row = 4.0 if fused else 12.0
         kinda = 0 if wl["metric"] != "cosine" else 2  # (approx_interval's kind: 0 the L2 family, 2 the reference's literal cosine key)
-        kname = (("sweep128b_lean_kernel<32, %d>" if byte_rows else "sweep128h_lean_kernel<16, %d>") % kinda) if fused else "sweep128%s_lean_kernel<4, -1>" % ("b" if byte_rows else "h")
+        kname = (("sweep128b_lean_kernel<64, %d>" if byte_rows else "sweep128h_lean_kernel<16, %d>") % kinda) if fused else "sweep128%s_lean_kernel<4, -1>" % ("b" if byte_rows else "h")
         row_b = 1.0 * d if byte_rows else 2.0 * d  # what the copy holds per stored row = what a launch must move per distinct row (traffic: PMC)
         bytes_alg = row_b * rows_per_launch * uniq_frac + per_row * rows_per_launch + 2.0 * d * B / launches_per_batch
         bytes_nosharing = (row_b + per_row) * rows_per_launch

@@ -2123,10 +2123,11 @@ hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, u
 #define ZH_S128F_CH 16  // ... of its fused form: a wave's bound comes from the rows IT has seen (64 chunks = the top_k / 1024 quantile at best)
 #endif
 #ifndef ZH_S128B_LAUNCH_X
-#define ZH_S128B_LAUNCH_X 4   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128): the same ~2 ms as the others' (A/B, cfg5 shard:
-#endif                        // 2: -2 %, 8: -1 % .. +3 % with 4.6-ms launches; profiles/r06_sweep128b_experiments.txt)
+#define ZH_S128B_LAUNCH_X 8   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128): 201.6M rows, ~4.4 ms (A/B on a cfg5 shard,
+#endif                        // profiles/r06_sweep128b_experiments.txt: 2 / 4 / 8 with 64 chunks per wave: 643-650 / 713-715 / 731 k QPS -- the tail of a launch
+                              // and the first waves of the next, which start without bounds, are paid half as often)
 #ifndef ZH_S128B_CH
-#define ZH_S128B_CH 32        // 64-row chunks per wave of the fused byte kernel (8: -11 %, 16: -3.5 %, 48 / 64: level)
+#define ZH_S128B_CH 64        // 64-row chunks per wave of the fused byte kernel (8: -11 %, 16: -3.5 %, 32: -1 % against 64)
 #endif
 uint64_t zh_sweep128h_rows_per_launch(bool lean, bool byte_rows) {
     return (lean ? (byte_rows ? ZH_S128B_LAUNCH_X : 2) : 1) * zh_sweep_rows_per_launch(128);
