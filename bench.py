@@ -817,6 +817,13 @@ def run_workload(env, name, S, rank, steps, warmup, exchange, recall=False, M_ov
         out["host_buffers_qps"] = 3 * qh.shape[0] / (time.perf_counter() - th)
         out["host_buffers"] = {"queries_per_call": int(qh.shape[0]), "calls": 3, "calls_run_as_windows": ix.stats()["host_window_calls_accum"] - hw0,
                                "note": "blocking zh_search_batch calls back to back, queries and results in pageable host memory"}
+        # ... and with SIXTEEN API batches per call: a blocking call pays its pipeline's fill and drain once, so the rate depends on how much it is handed
+        qh16 = np.concatenate([queries[(warmup + i) % n_batches].cpu().numpy() for i in range(16)])
+        ix.search_batch(qh16, k, metric)
+        th = time.perf_counter()
+        ix.search_batch(qh16, k, metric)
+        out["host_buffers"]["qps_at_16_batches_per_call"] = qh16.shape[0] / (time.perf_counter() - th)
+        out["host_buffers"]["queries_per_large_call"] = int(qh16.shape[0])
         # what a latency-bound caller sees: ONE batch through the blocking device-pointer call, results on the host
         lb = []
         for i in range(5):
@@ -1028,6 +1035,7 @@ def compact_line(full, limit=LINE_LIMIT):
     line["value_index_created_late_in_process"] = ((full.get("other_configs") or {}).get("recall_iid") or {}).get("queries_per_s_this_gpu")
     line["host_buffers_qps"] = full.get("host_buffers_qps")
     line["host_buffers_queries_per_call"] = (full.get("host_buffers") or {}).get("queries_per_call")
+    line["host_buffers_qps_at_16_batches_per_call"] = (full.get("host_buffers") or {}).get("qps_at_16_batches_per_call")
     optional = []  # (key, value), most important first
     optional.append(("stage_ms_per_batch", full.get("stage_ms_per_batch")))
     lat = full.get("latency_ms") or {}
@@ -1046,6 +1054,8 @@ def compact_line(full, limit=LINE_LIMIT):
              "frac": r.get("frac"), "launch_ms": r.get("launch_ms"), "traffic_ratio": r.get("traffic_over_algorithmic", r.get("traffic_over_hbm_by_design"))}
         if v.get("host_buffers_qps") is not None:
             e["host_buffers_qps"] = v["host_buffers_qps"]
+            if (v.get("host_buffers") or {}).get("qps_at_16_batches_per_call") is not None:
+                e["host_qps_16_batches_per_call"] = v["host_buffers"]["qps_at_16_batches_per_call"]
         if key == "cfg1_single_query":  # (the single-query configuration: what counts is one blocking call, results on the host)
             e["p50_blocking_single_query_ms"] = (v.get("latency_ms") or {}).get("p50_blocking_single_batch")
         r10 = v.get("recall_at_10")

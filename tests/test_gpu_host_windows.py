@@ -23,10 +23,10 @@ def same(ids, keys, counts, oi, ok, oc):
         assert (ids[b, :c] == oi[b, :c]).all() and (keys[b, :c] == ok[b, :c]).all(), b
 
 
-@pytest.mark.parametrize("ahead", ["0", "1"])
+@pytest.mark.parametrize("ahead", ["0", "1", "2"])
 @pytest.mark.parametrize("d,M,T,k,mode", [(768, 300, 15, 100, "auto"), (384, 256, 15, 10, "approx"), (128, 200, 8, 10, "leaf-half"), (96, 64, 6, 7, "auto")])
 def test_windows_equal_one_batch(za, monkeypatch, d, M, T, k, mode, ahead):
-    # ahead = 1 (ZH_HOST_LOOKAHEAD=1; what the library does by itself where the walk wanders): three contexts, window w + 1 begun before w is finished
+    # ahead = 1 / 2 (ZH_HOST_LOOKAHEAD; 2 = what the library does by itself where the walk wanders): three / four contexts, windows w + 1 (and w + 2) begun before w is finished
     monkeypatch.setenv("ZH_HOST_LOOKAHEAD", ahead)
     n, B = 9000, 700
     kind = 1 if d == 128 else 0

@@ -509,7 +509,12 @@ struct zh_index {
         zh_search_ctx ctx3;
         bool init3 = false;
         hipStream_t s3 = nullptr;
-        hipEvent_t ev_d2h[3] = {nullptr, nullptr, nullptr};
+        // ... and a fourth for TWO windows begun ahead (the finish of window w + 1 -- its walk -- is then queued before window w's results are
+        // waited for: w's prefilter and select run beside it)
+        zh_search_ctx ctx4;
+        bool init4 = false;
+        hipStream_t s4 = nullptr;
+        hipEvent_t ev_d2h[4] = {nullptr, nullptr, nullptr, nullptr};
         DevBuf wQ, wOutIds, wOutKeys, wOutCounts;
         void *h_stage = nullptr;  // pinned staging of a combined batch: queries in, results out (one H2D, three D2H per round)
         size_t h_stage_cap = 0;
@@ -655,8 +660,10 @@ extern "C" void zh_index_destroy(zh_index *ix) {
             if (ln.init) { hipSetDevice(ix->device); ln.ctx.release_all(); }
             if (ln.init2) { hipSetDevice(ix->device); ln.ctx2.release_all(); }
             if (ln.init3) { hipSetDevice(ix->device); ln.ctx3.release_all(); }
+            if (ln.init4) { hipSetDevice(ix->device); ln.ctx4.release_all(); }
             if (ln.s2) hipStreamDestroy(ln.s2);
             if (ln.s3) hipStreamDestroy(ln.s3);
+            if (ln.s4) hipStreamDestroy(ln.s4);
             for (auto &ev : ln.ev_d2h) if (ev) hipEventDestroy(ev);
             ln.wQ.release(); ln.wOutIds.release(); ln.wOutKeys.release(); ln.wOutCounts.release();
             if (ln.s) hipStreamDestroy(ln.s);
@@ -2884,7 +2891,11 @@ static size_t host_windows_wanted(zh_index *ix, size_t B, size_t k, bool *wander
 }
 // returns ZH_OK with every result in the caller's buffers, or an error after which BOTH contexts are idle and nothing is in flight (the caller
 // then runs the classic path: a window that passes a per-batch limit is not an error of the call)
-static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, bool ahead, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
+#ifndef ZH_HOST_AHEAD_WANDER
+#define ZH_HOST_AHEAD_WANDER 2   // windows begun ahead in the wandering regime (profiles/r06_host_calls_refdefault.txt: 1M x 384, default options, queries per
+                                 // second at 1024 / 4096 / 8192 queries per call: none 17.2 / 17.4 / 17.4 k, one 23.1 / 25.1 / 25.5 k, two 23.7 / 28.4 / 29.1 k)
+#endif
+static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, int ahead, const float *q, size_t B, size_t k, int metric, int mode, uint64_t *out_ids,
                                uint64_t *out_keys, uint32_t *out_counts) {
     const uint32_t d = ix->opt.dim;
     int rc;
@@ -2906,9 +2917,10 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, bool
         return ZH_OK;
     };
     if ((rc = init_ctx(&ln.ctx2, &ln.s2, &ln.init2))) return rc;
-    if (ahead && init_ctx(&ln.ctx3, &ln.s3, &ln.init3) != ZH_OK) ahead = false;  // (no room for a third context: two, begin + finish back to back)
-    const int NC = ahead ? 3 : 2;                 // contexts the windows rotate through
-    const size_t A = ahead ? 1 : 0;               // windows begun ahead of the one being finished
+    if (ahead >= 1 && init_ctx(&ln.ctx3, &ln.s3, &ln.init3) != ZH_OK) ahead = 0;  // (no room for a third context: two, begin + finish back to back)
+    if (ahead >= 2 && init_ctx(&ln.ctx4, &ln.s4, &ln.init4) != ZH_OK) ahead = 1;
+    const int NC = 2 + ahead;                     // contexts the windows rotate through
+    const size_t A = (size_t)ahead;               // windows begun ahead of the one being finished
     const size_t nw = (B + wq - 1) / wq, per = (B + nw - 1) / nw;
     const size_t off_ids = B * d * 4, off_keys = off_ids + B * k * 8, off_counts = off_keys + B * k * 8, need = off_counts + B * 4;
     if (need > ln.h_stage_cap) {
@@ -2925,8 +2937,8 @@ static int search_host_windows(zh_index *ix, zh_index::Lane &ln, size_t wq, bool
     uint32_t *dCounts = ln.wOutCounts.as<uint32_t>();
     uint64_t *hIds = reinterpret_cast<uint64_t *>(hs + off_ids), *hKeys = reinterpret_cast<uint64_t *>(hs + off_keys);
     uint32_t *hCounts = reinterpret_cast<uint32_t *>(hs + off_counts);
-    zh_search_ctx *ctxs[3] = {&ln.ctx, &ln.ctx2, &ln.ctx3};
-    hipStream_t str[3] = {ln.s, ln.s2, ln.s3};
+    zh_search_ctx *ctxs[4] = {&ln.ctx, &ln.ctx2, &ln.ctx3, &ln.ctx4};
+    hipStream_t str[4] = {ln.s, ln.s2, ln.s3, ln.s4};
     auto win = [&](size_t w, size_t *b0, size_t *nb) { *b0 = w * per; *nb = std::min(per, B - *b0); };
     auto bail = [&](int code) {  // leave nothing in flight: what was begun is abandoned, what was finished is retired, every stream drained
         const std::string why = g_err;
@@ -3029,8 +3041,8 @@ static void run_group(zh_index *ix, zh_index::Lane &ln, const std::vector<zh_ind
     bool wander = false;
     const size_t wq = grp.size() == 1 ? host_windows_wanted(ix, B, k, &wander) : 0;
     if (wq) {  // one large batch: windows over two contexts (three, one begun ahead, where the walk wanders), copies beside the kernels
-        const char *la_e = getenv("ZH_HOST_LOOKAHEAD");  // tests / A-B, read per call: 0 never, 1 always
-        const bool ahead = la_e ? la_e[0] == '1' : wander;
+        const char *la_e = getenv("ZH_HOST_LOOKAHEAD");  // tests / A-B, read per call: 0 never, 1 / 2 always, that many windows begun ahead
+        const int ahead = la_e ? (la_e[0] == '2' ? 2 : (la_e[0] == '1' ? 1 : 0)) : (wander ? ZH_HOST_AHEAD_WANDER : 0);
         if (search_host_windows(ix, ln, wq, ahead, grp[0]->q, B, k, grp[0]->metric, grp[0]->mode, grp[0]->ids, grp[0]->keys, grp[0]->counts) == ZH_OK) {
             std::lock_guard<std::mutex> ls(ix->stats_mu);
             ix->stats.host_window_calls_accum++;
