@@ -126,7 +126,7 @@ def test_cfg1_10k_384_cosine_top10_single_query_reference_defaults():
 def test_cfg2_1m_384_cosine_top10_batch256():
     import zebra_amd as za
     # corrected key finds the planted neighbour; the reference's literal key returns the LEAST similar rows (F4)
-    _check(za, 1_000_000, 384, "cos", 10, 256, 1024, 15, planted_min=0.3, n_exact=12)
+    _check(za, 1_000_000, 384, "cos", 10, 256, 1024, 15, planted_min=0.3, n_exact=256)
     ix = za.LSHIndex(384, za.LSHIndexOptions(1024, 15), reserve_rows=1_000_000)
     ix.append_synthetic(1_000_000)
     ix.build()
@@ -142,23 +142,25 @@ def test_cfg2_1m_384_cosine_top10_batch256():
 
 def test_cfg3_10m_768_l2_top100_batch1024():
     import zebra_amd as za
-    _check(za, 10_000_000, 768, "l2", 100, 1024, 4096, 15, planted_min=0.6, n_exact=8)
+    _check(za, 10_000_000, 768, "l2", 100, 1024, 4096, 15, planted_min=0.6, n_exact=1024)
 
 
 def _eight_shards_time_multiplexed(N, d, k, B, M, T, metric_name, kind):
     """An 8-GPU configuration END TO END on one GPU: rank r's shard (rows [N/8 r, N/8 (r+1)), its own forest,
     id_base = first row, seed + r exactly as bench.py builds it) is built, searched with the full batch and destroyed,
     one after another; the eight packed results are laid out as the all-gather would leave them and merged by
-    zh_merge_topk_packed_device.  Checked: every shard's answers for 8 queries and its forest against the oracle;
+    zh_merge_topk_packed_device.  Checked: every shard's answers for 512 queries and its forest against the oracle;
     the merged answer of ALL queries against the oracle's merge (zo_merge_topk) of the eight device results; the
-    merged answer of the 8 queries against the all-oracle pipeline (eight synth searches + merge)."""
+    merged answer of the 512 queries against the all-oracle pipeline (eight synth searches + merge)."""
     import torch
     import zebra_amd as za
     from zebra_amd import sharding
     S = 8
     m, om, omode = _metrics(za)[metric_name]
     Q = zo.synth_queries(B, d, N, kind=kind)
-    sel = np.unique(np.linspace(0, B - 1, 8).astype(int))
+    # round 6: 512 queries of the batch (round 5: 8) against the oracle, shard by shard and merged -- the oracle's search is threaded; every query
+    # (sel = np.arange(B)) passes too and takes 80 s (cfg4) / 183 s (cfg5) instead of 52 / 80: the GPU suite is kept near six minutes
+    sel = np.unique(np.linspace(0, B - 1, 512).astype(int))
     W = za.packed_result_words(B, k)
     dev = torch.device("cuda", 0)
     g_packed = torch.empty((S, W), dtype=torch.int64, device=dev)
@@ -218,7 +220,7 @@ def test_cfg5_1b_128d_sift_l2_top10_batch4096_eight_shards_time_multiplexed():
 def test_cfg5_full_shard_125m_128d_sift_l2_top10_batch4096():
     import zebra_amd as za
     # one whole shard of the 1B set (rank 5 of 8: rows [625M, 750M)): 64 GB of integer-valued rows -> exact L2
-    _check(za, 125_000_000, 128, "l2", 10, 4096, 8192, 15, kind=1, planted_min=0.3, n_exact=8, rows0=625_000_000,
+    _check(za, 125_000_000, 128, "l2", 10, 4096, 8192, 15, kind=1, planted_min=0.3, n_exact=4096, rows0=625_000_000,
            n_total=1_000_000_000)
 
 
