@@ -1417,8 +1417,9 @@ __global__ __launch_bounds__(256) void sweep128h_dma_kernel(const u32x4v *__rest
 //   * |x^|^2 is the DIAGONAL of the tile's Gram matrix: four more MFMAs with the B fragments as both operands (the A and B layouts of
 //     v_mfma_f32_16x16x32_f16 coincide) on a matrix pipe that has nothing else to do, three selects and one ds_bpermute;
 //   * the four K-steps chain through one accumulator.
-// A chunk that crosses a group boundary (or the batch's last, short one) is sweep128h_boundary_kernel's: the general per-lane form of the kernel above,
-// one chunk at a time, one launch per batch (chunk_segments() is the predicate both kernels split the chunks by).  Same raw pairs up to the summation
+// A chunk with ONE group boundary in it (and the batch's last, short one) is scored here too, as two SEGMENTS with the lanes past each segment's count
+// switched off (chunk_segments(), last session of round 6); a chunk of three or more groups -- leaves of a handful of rows -- is
+// sweep128h_boundary_kernel's: the general per-lane form of the kernel above, one chunk at a time, one launch per batch.  Same raw pairs up to the summation
 // order inside the matrix pipe (covered by zh_approx_bound's MFMA term, tests/test_gpu_intervals.py) -- the results behind them are bit-identical
 // by construction as before.
 // ---- the fused sweep (round 6).  The stores of the raw pairs -- under 4 % of the sweep's bytes -- cost the lean kernel a fifth of its time (0.99 ms per
@@ -2122,6 +2123,10 @@ hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, u
 #ifndef ZH_S128F_CH
 #define ZH_S128F_CH 16  // ... of its fused form: a wave's bound comes from the rows IT has seen (64 chunks = the top_k / 1024 quantile at best)
 #endif
+#ifndef ZH_S128H_LAUNCH_X
+#define ZH_S128H_LAUNCH_X 4   // rows per launch of the lean kernels over the copy of halves, in units of zh_sweep_rows_per_launch(128): 100.8M rows, ~4.1 ms
+                              // (cfg5 shard on halves, two passes: 2: 377 k QPS, 4: 393-400 k; with 32 / 64 chunks per wave of the fused form: 382-390 / 376-385 k)
+#endif
 #ifndef ZH_S128B_LAUNCH_X
 #define ZH_S128B_LAUNCH_X 8   // rows per launch of the byte kernel, in units of zh_sweep_rows_per_launch(128): 201.6M rows, ~4.4 ms (A/B on a cfg5 shard,
 #endif                        // profiles/r06_sweep128b_experiments.txt: 2 / 4 / 8 with 64 chunks per wave: 643-650 / 713-715 / 731 k QPS -- the tail of a launch
@@ -2130,7 +2135,7 @@ hipError_t zh_launch_exact_register(const ZhVisit *dVisits, uint64_t n_visits, u
 #define ZH_S128B_CH 64        // 64-row chunks per wave of the fused byte kernel (8: -11 %, 16: -3.5 %, 32: -1 % against 64)
 #endif
 uint64_t zh_sweep128h_rows_per_launch(bool lean, bool byte_rows) {
-    return (lean ? (byte_rows ? ZH_S128B_LAUNCH_X : 2) : 1) * zh_sweep_rows_per_launch(128);
+    return (lean ? (byte_rows ? ZH_S128B_LAUNCH_X : ZH_S128H_LAUNCH_X) : 1) * zh_sweep_rows_per_launch(128);
 }
 template <int FUSE, bool BYTES>
 static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, const ZhGroup *dGroups, const uint64_t *dGroupRowOff, uint64_t n_groups,
@@ -2138,7 +2143,9 @@ static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, c
                                   uint32_t k_top, float Kc, hipStream_t s) {
     // zh_sweep_rows_per_launch sizes a launch as ~12 GB of F32 rows (~2 ms of HBM time: other queues get dispatch slots between launches); this sweep
     // reads 256-byte rows -- the same row count was a 1.1-ms launch whose tail (24.6k waves over 4096 wave slots: six rounds, the last one partly
-    // empty) cost 6-7 %: twice the rows, the same ~2.2 ms (cfg5 shard, window 4: 359-367 -> 383-384 k QPS; four times: 390-392 k)
+    // empty) cost 6-7 %: twice the rows, the same ~2.2 ms (cfg5 shard, window 4: 359-367 -> 383-384 k QPS; four times: 390-392 k).  Last session:
+    // four times (ZH_S128H_LAUNCH_X) for the halves, eight (ZH_S128B_LAUNCH_X) for the byte rows -- ~4.2-ms launches; the pipelined contexts' small
+    // kernels did not suffer in the measurement that decided it (the pipelined loop's own QPS)
     const uint64_t rows_per_launch = zh_sweep128h_rows_per_launch(true, BYTES);
     for (uint64_t r = 0; r < R_grouped; r += rows_per_launch) {
         const uint64_t r_end = r + rows_per_launch < R_grouped ? r + rows_per_launch : R_grouped;
@@ -2152,7 +2159,7 @@ static void launch_sweep128h_lean(const void *dXh, const void *dQh, float inv, c
                                (const u32x4v *)dQh, inv, dGroups, dGroupRowOff, n_groups, dWaveGroup, dLeafIds, r, r_end, dIv, ap, k_top, Kc);
     }
 #if ZH_S128L_EXP != 5    // (5: timing experiment without the boundary kernel, results invalid)
-    // the chunks that cross a group boundary, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
+    // the chunks of three or more groups, of the WHOLE batch in one launch (a launch of its own per 25M rows was 0.04-0.06 ms each): a wave
     // looks at 64 chunks.  Chunk boundaries are absolute (every launch above starts on a multiple of 256 rows), so both kernels see the same chunks
     const uint64_t bw = ((R_grouped + 63) / 64 + 63) / 64, bb = (bw + 3) / 4;
     hipLaunchKernelGGL((sweep128h_boundary_kernel<FUSE, BYTES>), dim3((uint32_t)bb), dim3(256), 0, s, (const u32x4v *)dXh, (const u32x4v *)dQh, inv, dGroups,
