@@ -85,7 +85,11 @@ WORKLOADS = {
 # cfg3_window_of_one: the bench line's workload with every batch its own internal batch -- the latency / throughput trade of --window
 # (steps: a multiple of the window and enough windows that the pipeline's fill and drain -- one window's light kernels -- do not show)
 OTHER_CONFIGS = [("cfg3_window_of_one", "cfg3", 1, 12, 1), ("cfg4_one_of_8_shards", "cfg4", 8, 20), ("cfg2", "cfg2", 1, 120),
-                 ("cfg5_one_of_8_shards", "cfg5", 8, 24), ("reference_default_options", "refdefault", 1, 24), ("scale64m_n1", "scale64m", 1, 8),
+                 ("cfg5_one_of_8_shards", "cfg5", 8, 24),
+                 # the same shard with EIGHT API batches per window instead of four (a leaf's rows are loaded once per <= 4 queries of the WINDOW that visit it:
+                 # 0.51 row loads per scored row instead of 0.69) -- throughput for latency, the caller's choice (zh_search_ctx_begin_window)
+                 ("cfg5_shard_window_of_eight", "cfg5", 8, 32, 8),
+                 ("reference_default_options", "refdefault", 1, 24), ("scale64m_n1", "scale64m", 1, 8),
                  ("cfg1_single_query", "cfg1", 1, 60),  # (configs[0]: the reference's own CPU-runnable case; what matters is latency_ms.p50_blocking_single_batch)
                  # north_star's ">= 70 % of HBM on the candidate distance sweep" on a driver-run line: the bench line's workload through the f32
                  # LEAF-MAJOR sweep (zh_set_sweep_mode(1): sweep_kernel<768>, HBM-bound, SURVEY s8(d)'s bytes are what it moves) beside the faster
