@@ -289,6 +289,11 @@ def test_byte_rows_copy_follows_the_stored_rows(za, monkeypatch, variant):
     set_s128h_variant(monkeypatch, variant)
     st = check(ix, f, Q, k, m, om, 0, "bytes again")
     assert st["approx_byte_rows"] == 1, st
+    monkeypatch.setenv("ZH_S128H_PRETEST", "0")   # the fused epilogue without its pre-test (every chunk takes fused_slot): the same answers
+    for mm, omm, omo in all_metrics(za):
+        st = check(ix, f, Q, k, mm, omm, omo, "bytes, no pre-test")
+        assert st["approx_byte_rows"] == 1, st
+    monkeypatch.delenv("ZH_S128H_PRETEST")
     ix.append(X[n:n + n // 2])          # more rows of bytes: added to the copy
     f2 = zo.Forest.build(X[:n + n // 2], M, T)
     ix.set_forest(f2.arrays())
